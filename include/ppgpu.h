@@ -1,0 +1,249 @@
+/*
+ * ppgpu.h — C ABI of the MI355X (gfx950) implementation of the ASV planner's
+ * per-iteration hot path: state sampling -> Dubins edge generation -> per-edge
+ * cost evaluation (occupancy grid + dynamic obstacles + ribbon coverage + heuristic)
+ * -> incumbent min-reduce.
+ *
+ * The reference has no FFI layer; its seam is the C++ virtual
+ *   Planner::Stats Planner::plan(const RibbonManager&, const State&, PlannerConfig,
+ *                                const DubinsPlan&, double timeRemaining)
+ *   (/root/reference/path_planner/src/planner/Planner.h:50-51, called from
+ *    path_planner/src/executive/executive.cpp:189-190),
+ * with the arithmetic living in non-virtual members underneath it.  Each entry
+ * point below names the reference function(s) whose work it replaces; the C++
+ * host mirror of the reference classes (path_planner_amd/host) is built on
+ * nothing but this header, and INTEGRATION.md shows the binding a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *   - every function returns PPGPU_OK (0) or a negative PPGPU_E* code and
+ *     records a message retrievable with ppgpu_last_error(); the C++ host turns
+ *     a non-zero code into std::runtime_error so Executive::planLoop's
+ *     try/catch (executive.cpp:191-200) behaves as it does today;
+ *   - plain pointers and sizes only; `h_` parameters are host memory, `d_`
+ *     parameters are device (HBM) memory owned by the caller;
+ *   - all floating point is IEEE double, exactly as in the reference
+ *     (path_planner_common/include/path_planner_common/State.h:201-202);
+ *   - nothing here falls back to the CPU: if no gfx950 device/code object is
+ *     available ppgpu_create fails.
+ */
+#ifndef PATH_PLANNER_AMD_PPGPU_H
+#define PATH_PLANNER_AMD_PPGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPGPU_OK          0
+#define PPGPU_EINVAL     (-1)  /* bad argument / shape mismatch                      */
+#define PPGPU_EHIP       (-2)  /* a HIP runtime call failed (message has the detail) */
+#define PPGPU_ENODEV     (-3)  /* no usable gfx950 device                            */
+#define PPGPU_ESTATE     (-4)  /* call order violated (e.g. cost before set_config)  */
+#define PPGPU_ECAPACITY  (-5)  /* a fixed device-side capacity was exceeded          */
+#define PPGPU_ERCCL      (-6)  /* an RCCL call failed                                */
+
+typedef struct ppgpu_ctx ppgpu_ctx;
+
+/* RibbonManager::Heuristic, same order
+ * (path_planner/src/planner/utilities/RibbonManager.h:20-26). */
+enum {
+    PPGPU_H_MAX_DISTANCE = 0,
+    PPGPU_H_TSP_POINT_ALL = 1,
+    PPGPU_H_TSP_POINT_K = 2,
+    PPGPU_H_TSP_DUBINS_ALL = 3,
+    PPGPU_H_TSP_DUBINS_K = 4
+};
+
+/* DynamicObstaclesManager implementations behind PlannerConfig::obstaclesManager()
+ * (path_planner/src/planner/PlannerConfig.h:98-104). */
+enum {
+    PPGPU_OBST_NONE = 0,    /* base class: collisionExists == 0 (DynamicObstaclesManager.h:23) */
+    PPGPU_OBST_BINARY = 1   /* BinaryDynamicObstaclesManager.cpp:4-22                           */
+};
+
+/* The scalars of PlannerConfig (PlannerConfig.h:179-207) plus the process-global
+ * ribbon half-width (Ribbon.h:16, Ribbon.cpp:4), the two Edge constants
+ * (Edge.h:151-152) and the RibbonManager heuristic settings
+ * (RibbonManager.h:184-190).  Defaults are the reference's. */
+typedef struct ppgpu_config {
+    double max_speed;                   /* 2.5  */
+    double slow_speed;                  /* 0.5 ; <= 0 means "same as max" (PlannerConfig.h:168-171) */
+    double turning_radius;              /* 8    */
+    double coverage_turning_radius;     /* 16   */
+    double time_horizon;                /* 30   */
+    double time_minimum;                /* 5    */
+    double collision_checking_increment;/* 0.05 */
+    double start_state_time;            /* PlannerConfig::startStateTime() */
+    double ribbon_width;                /* 1.5  Ribbon::RibbonWidth (half width) */
+    double collision_penalty_factor;    /* 600  Edge::collisionPenaltyFactor()   */
+    double time_penalty_factor;         /* 1    Edge::timePenaltyFactor()        */
+    double heuristic_turning_radius;    /* RibbonManager::m_TurningRadius (Dubins-TSP heuristics only) */
+    int32_t heuristic;                  /* PPGPU_H_* */
+    int32_t tsp_k;                      /* RibbonManager::m_K */
+    int32_t branching_factor;           /* 9 */
+    int32_t reserved;
+} ppgpu_config;
+
+/* One open vertex = what Edge::computeTrueCost reads from its start vertex
+ * (Edge.cpp:88,98-99; Vertex.h:180-187): State, g, and the vertex's private
+ * RibbonManager (list of ribbons + coverageCompletedTime). 64 bytes. */
+typedef struct ppgpu_vertex {
+    double x, y, heading, speed, time;  /* State (State.h:201-202)                        */
+    double g;                           /* Vertex::currentCost()                          */
+    double coverage_completed_time;     /* RibbonManager::coverageCompletedTime(), -1 unset */
+    int32_t ribbon_offset;              /* first ribbon of this vertex in the ribbon pool */
+    int32_t ribbon_count;
+} ppgpu_vertex;
+
+/* Bits of ppgpu_edge_result.flags */
+#define PPGPU_F_INFEASIBLE   0x01u /* Edge::infeasible()                                          */
+#define PPGPU_F_THROWS       0x02u /* the reference would throw out of computeTrueCost here
+                                      (DubinsWrapper::sample on an uninitialised / out-of-range
+                                      wrapper, Edge.cpp:178 / DubinsWrapper.cpp:29-35)            */
+#define PPGPU_F_RIBBON_OVF   0x04u /* child ribbon list exceeded the device capacity               */
+#define PPGPU_F_DUBINS_ERR   0x08u /* dubins_path_sample failed twice (DubinsWrapper.cpp:43-45)    */
+#define PPGPU_F_GOAL         0x10u /* SamplingBasedPlanner::goalCondition(child)                   */
+#define PPGPU_F_DONE         0x20u /* child->done()                                                */
+
+/* What Vertex::connect + Edge::computeApproxCost + Edge::computeTrueCost leave
+ * behind for one edge (Edge.cpp:68-206, Vertex.cpp:49-64,97-104). 128 bytes, so a
+ * wavefront writes one record as a single 128-byte transaction. */
+typedef struct ppgpu_edge_result {
+    uint32_t flags;            /* PPGPU_F_*                                              */
+    uint32_t info;             /* bits 0-7 DubinsPathType, bits 8-15 child ribbon count,
+                                  bits 16-31 number of sweep steps executed              */
+    double true_cost;          /* Edge::trueCost()                                       */
+    double collision_penalty;  /* Edge::getSavedCollisionPenalty()                       */
+    double approx_cost;        /* Edge::approxCost()                                     */
+    double end_x, end_y, end_heading, end_speed, end_time; /* child State (Edge.cpp:177-178) */
+    double g, h, f;            /* child currentCost, approxToGo, f                       */
+    double coverage_completed_time; /* child RibbonManager::coverageCompletedTime()      */
+    double param[3];           /* DubinsPath::param of the edge's curve                  */
+} ppgpu_edge_result;
+
+/* Edge descriptor for the list form of ppgpu_cost_edges: which open vertex,
+ * which target state, which (radius, speed) configuration
+ * (SamplingBasedPlanner.cpp:58-63,69-79,134-148). */
+#define PPGPU_EDGE_COVERAGE 0x1u /* use coverage_turning_radius, coverageAllowed = true */
+#define PPGPU_EDGE_SLOW     0x2u /* end state's speed = slow_speed instead of max_speed */
+static inline uint64_t ppgpu_edge_pack(uint32_t vertex, uint32_t target, uint32_t cfg) {
+    return ((uint64_t)(cfg & 0xffu) << 56) | ((uint64_t)(vertex & 0xffffffu) << 32) | (uint64_t)target;
+}
+
+/* ------------------------------------------------------------------ lifecycle */
+
+/* Process-level handle: device context, stream, persistent buffers.  The reference
+ * constructs a new planner every cycle (executive.cpp:85-90); the handle outlives it. */
+int ppgpu_create(int device, ppgpu_ctx** out);
+int ppgpu_destroy(ppgpu_ctx* ctx);
+const char* ppgpu_last_error(void);
+/* Launch on a caller-owned hipStream_t (NULL = the handle's own stream). */
+int ppgpu_set_stream(ppgpu_ctx* ctx, void* hip_stream);
+int ppgpu_synchronize(ppgpu_ctx* ctx);
+
+/* ---------------------------------------------------------------- world state */
+
+/* PlannerConfig setters + Ribbon::RibbonWidth + RibbonManager heuristic. */
+int ppgpu_set_config(ppgpu_ctx* ctx, const ppgpu_config* cfg);
+
+/* Map::isBlocked source.  rows*cols bytes, row 0 = y in [0,res) (i.e. AFTER the
+ * row reversal GridWorldMap's loader applies, GridWorldMap.cpp:25), non-zero =
+ * blocked; queries outside [0,cols*res) x [0,rows*res) are blocked
+ * (GridWorldMap.cpp:84-93).  rows == 0 selects the base Map: nothing is ever
+ * blocked and the extremes are +-DBL_MAX (Map.cpp:4-6, Map.h:34). */
+int ppgpu_set_grid(ppgpu_ctx* ctx, const uint8_t* h_cells, int32_t rows, int32_t cols, double resolution);
+
+/* BinaryDynamicObstaclesManager contents: n rows of
+ * {x, y, heading, speed, time, width, length} exactly as passed to update()
+ * (BinaryDynamicObstaclesManager.cpp:24-35, constructor .h:17-19). */
+int ppgpu_set_obstacles(ppgpu_ctx* ctx, int32_t model, int32_t n, const double* h_obstacles7);
+
+/* The open-vertex array: n vertices and the pool of their ribbons
+ * (4 doubles each: startX, startY, endX, endY; Ribbon.h:126).  Also rebuilds the
+ * per-vertex collision-check time grids (Edge.cpp:114-120,173). */
+int ppgpu_set_vertices(ppgpu_ctx* ctx, int32_t n, const ppgpu_vertex* h_vertices,
+                       int32_t n_ribbons, const double* h_ribbons4);
+
+/* -------------------------------------------------------------------- sampling */
+
+/* StateGenerator(minX,maxX,minY,maxY,minSpeed,maxSpeed,seed,ribbonManager)
+ * (StateGenerator.cpp:5-13,33-38).  bounds6 = {minX,maxX,minY,maxY,minSpeed,maxSpeed};
+ * n_ribbons < 0 selects the ribbon-less constructor.  Clears the sample store. */
+int ppgpu_sampler_init(ppgpu_ctx* ctx, const double* bounds6, uint64_t seed,
+                       int32_t n_ribbons, const double* h_ribbons4);
+
+/* SamplingBasedPlanner::addSamples(generator, n) (SamplingBasedPlanner.cpp:157-164):
+ * draw n_attempts states from the generator's stream, keep those whose cell is
+ * free, append them (in stream order) to the device sample store.
+ * *n_total_out = resulting m_Samples.size(). */
+int ppgpu_sampler_add(ppgpu_ctx* ctx, int64_t n_attempts, int64_t* n_total_out);
+
+/* Replace the sample (target-state) store with caller data; x/y/heading arrays of n. */
+int ppgpu_set_samples(ppgpu_ctx* ctx, int64_t n, const double* h_x, const double* h_y, const double* h_heading);
+/* Copy samples [first, first+n) out as States {x,y,heading,speed,time} (5 doubles each). */
+int ppgpu_get_samples(ppgpu_ctx* ctx, int64_t first, int64_t n, double* h_states5);
+int64_t ppgpu_num_samples(ppgpu_ctx* ctx);
+
+/* ------------------------------------------------------------- edge generation */
+
+/* Edge::computeApproxCost for every (vertex in [v0,v0+nv), sample, radius):
+ * the Dubins length DubinsWrapper::length() (Edge.cpp:11-20, DubinsWrapper.cpp:9-22).
+ * d_lengths receives nv * n_samples * 2 doubles, index ((v-v0)*n_samples + s)*2 + r,
+ * r = 0 turning_radius, r = 1 coverage_turning_radius; -1 for pairs closer than
+ * collision_checking_increment (SamplingBasedPlanner.cpp:111). */
+int ppgpu_dubins_lengths(ppgpu_ctx* ctx, int32_t v0, int32_t nv, double* d_lengths);
+
+/* The k best samples by Dubins length per (vertex, radius) — the result of the
+ * lazy scan in SamplingBasedPlanner::expand (SamplingBasedPlanner.cpp:85-133).
+ * h_sample_index / h_length receive nv*2*k entries (index -1 = fewer than k). */
+int ppgpu_select_nearest(ppgpu_ctx* ctx, int32_t v0, int32_t nv, int32_t k,
+                         int32_t* h_sample_index, double* h_length);
+
+/* --------------------------------------------------------------- edge costing */
+
+/* Dense form: every vertex in [v0,v0+nv) x every sample in [s0,s0+ns) x the
+ * (radius,speed) configurations enabled in cfg_mask (bit c set = configuration c,
+ * c = PPGPU_EDGE_* bits, so 0xF = all four).  Edge e of the launch is
+ *   e = ((v-v0)*ns + (s-s0))*popcount(cfg_mask) + rank of c in cfg_mask.
+ * Results go to d_results[e]; child ribbon lists (ribbon_stride*4 doubles per edge)
+ * to d_child_ribbons, which may be NULL.  Asynchronous on the handle's stream. */
+int ppgpu_cost_edges_dense(ppgpu_ctx* ctx, int32_t v0, int32_t nv, int64_t s0, int64_t ns,
+                           uint32_t cfg_mask, ppgpu_edge_result* d_results,
+                           double* d_child_ribbons, int32_t ribbon_stride);
+
+/* List form: n packed descriptors (ppgpu_edge_pack) in device memory. */
+int ppgpu_cost_edges_list(ppgpu_ctx* ctx, int64_t n, const uint64_t* d_edges,
+                          ppgpu_edge_result* d_results,
+                          double* d_child_ribbons, int32_t ribbon_stride);
+
+/* Convenience for small batches (the host planner's <= 40 edges per expansion):
+ * host descriptors in, host results out, synchronous. */
+int ppgpu_cost_edges_host(ppgpu_ctx* ctx, int64_t n, const uint64_t* h_edges,
+                          ppgpu_edge_result* h_results,
+                          double* h_child_ribbons, int32_t ribbon_stride);
+
+/* Number of edges a dense launch with these arguments produces. */
+int64_t ppgpu_dense_edge_count(int32_t nv, int64_t ns, uint32_t cfg_mask);
+
+/* ---------------------------------------------------------- incumbent selection */
+
+/* Best (smallest f, ties -> smallest edge index) feasible edge of the last costing
+ * launch — the batch analogue of the incumbent update AStarPlanner.cpp:109-117.
+ * goal_only != 0 restricts to children satisfying goalCondition.
+ * d_key2 (device, 2 x uint64) = { bit pattern of f (monotone for f >= 0), edge index },
+ * UINT64_MAX/UINT64_MAX when no edge qualifies.  Asynchronous. */
+int ppgpu_best_edge(ppgpu_ctx* ctx, int64_t n, const ppgpu_edge_result* d_results,
+                    int32_t goal_only, uint64_t edge_index_base, uint64_t* d_key2);
+
+/* Global incumbent across the ranks of one node: lexicographic min of the
+ * per-rank keys with one RCCL collective over xGMI.  rccl_comm is an
+ * ncclComm_t created by the caller.  In place on d_key2. */
+int ppgpu_allreduce_best(ppgpu_ctx* ctx, void* rccl_comm, uint64_t* d_key2);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif
