@@ -1,0 +1,184 @@
+"""ctypes binding of libppgpu.so (include/ppgpu.h).  Glue for tests/ and bench.py.
+
+Importing this module REQUIRES the in-tree HIP library; there is no fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .types import PpgpuConfig, RESULT_DTYPE, VERTEX_DTYPE
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libppgpu.so")
+
+
+class PpgpuError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). path_planner_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_double
+    sig = {
+        "ppgpu_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "ppgpu_destroy": (C.c_int, [vp]),
+        "ppgpu_last_error": (C.c_char_p, []),
+        "ppgpu_set_stream": (C.c_int, [vp, vp]),
+        "ppgpu_synchronize": (C.c_int, [vp]),
+        "ppgpu_set_config": (C.c_int, [vp, C.POINTER(PpgpuConfig)]),
+        "ppgpu_set_grid": (C.c_int, [vp, vp, i32, i32, dbl]),
+        "ppgpu_set_obstacles": (C.c_int, [vp, i32, i32, vp]),
+        "ppgpu_set_vertices": (C.c_int, [vp, i32, vp, i32, vp]),
+        "ppgpu_sampler_init": (C.c_int, [vp, vp, u64, i32, vp]),
+        "ppgpu_sampler_add": (C.c_int, [vp, i64, C.POINTER(i64)]),
+        "ppgpu_set_samples": (C.c_int, [vp, i64, vp, vp, vp]),
+        "ppgpu_get_samples": (C.c_int, [vp, i64, i64, vp]),
+        "ppgpu_num_samples": (i64, [vp]),
+        "ppgpu_dubins_lengths": (C.c_int, [vp, i32, i32, vp]),
+        "ppgpu_select_nearest": (C.c_int, [vp, i32, i32, i32, vp, vp]),
+        "ppgpu_cost_edges_dense": (C.c_int, [vp, i32, i32, i64, i64, u32, vp, vp, i32]),
+        "ppgpu_cost_edges_list": (C.c_int, [vp, i64, vp, vp, vp, i32]),
+        "ppgpu_cost_edges_host": (C.c_int, [vp, i64, vp, vp, vp, i32]),
+        "ppgpu_dense_edge_count": (i64, [i32, i64, u32]),
+        "ppgpu_best_edge": (C.c_int, [vp, i64, vp, i32, u64, vp]),
+        "ppgpu_allreduce_best": (C.c_int, [vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)   # AttributeError here = the library does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    return lib, list(sig)
+
+
+LIB, EXPORTS = _load()
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data
+    return int(a)   # raw device pointer (e.g. torch.Tensor.data_ptr())
+
+
+class Context:
+    """One ppgpu_ctx.  Methods mirror the C entry points one to one."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        rc = LIB.ppgpu_create(device, C.byref(h))
+        if rc != 0:
+            raise PpgpuError(f"ppgpu_create: {LIB.ppgpu_last_error().decode()}")
+        self._h = h
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise PpgpuError(f"{what} failed ({rc}): {LIB.ppgpu_last_error().decode()}")
+
+    def close(self):
+        if self._h:
+            LIB.ppgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        self._ck(LIB.ppgpu_set_stream(self._h, stream_ptr), "ppgpu_set_stream")
+
+    def synchronize(self):
+        self._ck(LIB.ppgpu_synchronize(self._h), "ppgpu_synchronize")
+
+    def set_config(self, cfg):
+        self.cfg = cfg
+        self._ck(LIB.ppgpu_set_config(self._h, C.byref(cfg)), "ppgpu_set_config")
+
+    def set_grid(self, cells, resolution):
+        if cells is None:
+            self._ck(LIB.ppgpu_set_grid(self._h, None, 0, 0, 0.0), "ppgpu_set_grid")
+            return
+        cells = np.ascontiguousarray(cells, dtype=np.uint8)
+        self._ck(LIB.ppgpu_set_grid(self._h, _ptr(cells), cells.shape[0], cells.shape[1], float(resolution)), "ppgpu_set_grid")
+
+    def set_obstacles(self, obst7, model=1):
+        if obst7 is None or len(obst7) == 0:
+            self._ck(LIB.ppgpu_set_obstacles(self._h, 0, 0, None), "ppgpu_set_obstacles")
+            return
+        o = np.ascontiguousarray(obst7, dtype=np.float64).reshape(-1, 7)
+        self._ck(LIB.ppgpu_set_obstacles(self._h, model, o.shape[0], _ptr(o)), "ppgpu_set_obstacles")
+
+    def set_vertices(self, vertices, ribbons4):
+        v = np.ascontiguousarray(vertices, dtype=VERTEX_DTYPE)
+        r = np.ascontiguousarray(ribbons4, dtype=np.float64).reshape(-1, 4)
+        self._ck(LIB.ppgpu_set_vertices(self._h, v.shape[0], _ptr(v), r.shape[0], _ptr(r) if r.shape[0] else None),
+                 "ppgpu_set_vertices")
+
+    def sampler_init(self, bounds6, seed, ribbons4=None):
+        b = np.ascontiguousarray(bounds6, dtype=np.float64)
+        if ribbons4 is None:
+            self._ck(LIB.ppgpu_sampler_init(self._h, _ptr(b), int(seed), -1, None), "ppgpu_sampler_init")
+        else:
+            r = np.ascontiguousarray(ribbons4, dtype=np.float64).reshape(-1, 4)
+            self._ck(LIB.ppgpu_sampler_init(self._h, _ptr(b), int(seed), r.shape[0], _ptr(r) if r.shape[0] else None),
+                     "ppgpu_sampler_init")
+
+    def sampler_add(self, n_attempts):
+        tot = C.c_int64()
+        self._ck(LIB.ppgpu_sampler_add(self._h, int(n_attempts), C.byref(tot)), "ppgpu_sampler_add")
+        return tot.value
+
+    def set_samples(self, x, y, heading):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        h = np.ascontiguousarray(heading, dtype=np.float64)
+        self._ck(LIB.ppgpu_set_samples(self._h, x.shape[0], _ptr(x), _ptr(y), _ptr(h)), "ppgpu_set_samples")
+
+    def num_samples(self):
+        return LIB.ppgpu_num_samples(self._h)
+
+    def get_samples(self, first=0, n=None):
+        if n is None:
+            n = self.num_samples() - first
+        out = np.zeros((n, 5), dtype=np.float64)
+        self._ck(LIB.ppgpu_get_samples(self._h, first, n, _ptr(out)), "ppgpu_get_samples")
+        return out
+
+    def dubins_lengths(self, v0, nv, d_lengths):
+        self._ck(LIB.ppgpu_dubins_lengths(self._h, v0, nv, _ptr(d_lengths)), "ppgpu_dubins_lengths")
+
+    def select_nearest(self, v0, nv, k):
+        idx = np.zeros((nv, 2, k), dtype=np.int32)
+        ln = np.zeros((nv, 2, k), dtype=np.float64)
+        self._ck(LIB.ppgpu_select_nearest(self._h, v0, nv, k, _ptr(idx), _ptr(ln)), "ppgpu_select_nearest")
+        return idx, ln
+
+    def cost_edges_dense(self, v0, nv, s0, ns, cfg_mask, d_results, d_child=None, stride=0):
+        self._ck(LIB.ppgpu_cost_edges_dense(self._h, v0, nv, s0, ns, cfg_mask, _ptr(d_results), _ptr(d_child), stride),
+                 "ppgpu_cost_edges_dense")
+
+    def cost_edges_list(self, n, d_edges, d_results, d_child=None, stride=0):
+        self._ck(LIB.ppgpu_cost_edges_list(self._h, n, _ptr(d_edges), _ptr(d_results), _ptr(d_child), stride),
+                 "ppgpu_cost_edges_list")
+
+    def cost_edges_host(self, edges, stride=0):
+        e = np.ascontiguousarray(edges, dtype=np.uint64)
+        res = np.zeros(e.shape[0], dtype=RESULT_DTYPE)
+        child = np.zeros((e.shape[0], stride, 4), dtype=np.float64) if stride > 0 else None
+        self._ck(LIB.ppgpu_cost_edges_host(self._h, e.shape[0], _ptr(e), _ptr(res), _ptr(child), stride), "ppgpu_cost_edges_host")
+        return (res, child) if stride > 0 else res
+
+    @staticmethod
+    def dense_edge_count(nv, ns, cfg_mask):
+        return LIB.ppgpu_dense_edge_count(nv, ns, cfg_mask)
+
+    def best_edge(self, n, d_results, d_key2, goal_only=False, base=0):
+        self._ck(LIB.ppgpu_best_edge(self._h, n, _ptr(d_results), 1 if goal_only else 0, base, _ptr(d_key2)), "ppgpu_best_edge")

@@ -1,0 +1,448 @@
+// pp_kernels.h — the gfx950 kernels of the hot path.  Included once by ppgpu.hip.
+#pragma once
+#include "pp_device.h"
+#include "../../include/ppgpu.h"
+
+// Everything a costing launch needs, passed by value (kernarg segment, scalar loads).
+struct PPParams {
+    // PlannerConfig / Edge constants / RibbonManager settings
+    double max_speed, slow_speed, rho, rho_cov, horizon, tmin, inc_d, sst, ribw, cpf, tpf;
+    int heuristic, tsp_k;
+    // world
+    PPGrid grid;
+    const PPObst* obst; int n_obst;
+    // open vertices
+    const ppgpu_vertex* verts; const double* ribbons; const double* tgrid; int ng; int nverts;
+    // targets
+    const double* sx; const double* sy; const double* sh; long long n_samples;
+    // edges: explicit list, or dense enumeration when edges == nullptr
+    const unsigned long long* edges; long long n_edges;
+    int v0, nv; long long s0, ns; unsigned cfg_mask; int per;
+    // outputs
+    ppgpu_edge_result* out; double* child; int stride;
+};
+
+// ------------------------------------------------------------------------------------------
+// Collision-check time grid, one row per open vertex (Edge.cpp:114-120,173): the reference
+// advances `intermediate.time() += timeIncrement` once per step, so step times are a running
+// sum, not t0 + k*inc; they depend only on the source vertex's time, hence one table per vertex
+// (ng entries), built sequentially by one lane per vertex.
+__global__ void pp_k_time_grid(const ppgpu_vertex* verts, int nverts, double sst, double inc_d, double max_speed,
+                               int ng, double* tgrid) {
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nverts) return;
+    double timeIncrement = inc_d / max_speed;                 // Edge.cpp:114
+    double t = verts[v].time;
+    double timeSinceStart = t - sst;                          // :117
+    double timeNudge = fmod(timeSinceStart, timeIncrement);   // :118
+    t += timeNudge;                                           // :119
+    double* row = tgrid + (size_t)v * ng;
+    for (int k = 0; k < ng; k++) {
+        row[k] = t;
+        t += timeIncrement;                                   // :173
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Edge costing: one wavefront per edge, 4 edges per 256-thread workgroup.
+//
+//   phase 0 (uniform)   Vertex::connect + Edge::computeApproxCost: Dubins solve, curve constants
+//   phase A (64 lanes)  64 consecutive collision-check steps at a time: closed-form pose,
+//                       occupancy lookup, dynamic-obstacle box tests
+//   phase B (uniform + ribbon-per-lane)  the sequential coverage state machine of
+//                       Edge.cpp:153-171, visited only at its event steps
+//   phase C             end state, last cover, cost, g/h/f, one 128-byte record per edge
+__global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
+    __shared__ double lds_all[4][PP_WAVE * 4];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = pp_lane();
+    const long long e = (long long)blockIdx.x * 4 + wave;
+    if (e >= p.n_edges) return;
+    double* lds = lds_all[wave];
+
+    // ---- which edge
+    unsigned vi, target, cbits;
+    if (p.edges) {
+        unsigned long long d = p.edges[e];
+        target = (unsigned)(d & 0xffffffffull);
+        vi = (unsigned)((d >> 32) & 0xffffffull);
+        cbits = (unsigned)(d >> 56);
+    } else {
+        long long q = e / p.per;
+        int rank = (int)(e - q * p.per);
+        long long vv = q / p.ns;
+        target = (unsigned)(p.s0 + (q - vv * p.ns));
+        vi = (unsigned)(p.v0 + vv);
+        unsigned m = p.cfg_mask;
+        for (int i = 0; i < rank; i++) m &= m - 1;   // drop `rank` lowest set bits
+        cbits = (unsigned)(__ffs((int)m) - 1);
+    }
+    vi = (unsigned)__builtin_amdgcn_readfirstlane((int)vi);
+    target = (unsigned)__builtin_amdgcn_readfirstlane((int)target);
+    cbits = (unsigned)__builtin_amdgcn_readfirstlane((int)cbits);
+
+    unsigned flags = 0;
+    ppgpu_edge_result* rec = p.out + e;
+    if (vi >= (unsigned)p.nverts || (long long)target >= p.n_samples) {
+        // malformed descriptor: fail loudly in the record, touch nothing else
+        if (lane == 0) { rec->flags = PPGPU_F_INFEASIBLE | PPGPU_F_THROWS | PPGPU_F_DUBINS_ERR; rec->info = 0; }
+        return;
+    }
+
+    const ppgpu_vertex* V = p.verts + vi;
+    const double srcX = V->x, srcY = V->y, srcH = V->heading, srcT = V->time, srcG = V->g;
+    double cct = V->coverage_completed_time;
+    int nrib = V->ribbon_count;
+    const bool cov = (cbits & PPGPU_EDGE_COVERAGE) != 0;
+    const double rho = cov ? p.rho_cov : p.rho;                       // Edge.cpp:73-76
+    const double speed = (cbits & PPGPU_EDGE_SLOW) ? p.slow_speed : p.max_speed;
+    const double tgtX = p.sx[target], tgtY = p.sy[target], tgtH = p.sh[target];
+
+    // this vertex's ribbons, one per lane (Vertex::connect copies the parent's RibbonManager, Vertex.cpp:24)
+    PPRibbon rib = {0, 0, 0, 0};
+    if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
+    if (lane < nrib) {
+        const double* rp = p.ribbons + 4 * ((size_t)V->ribbon_offset + lane);
+        rib.sx = rp[0]; rib.sy = rp[1]; rib.ex = rp[2]; rib.ey = rp[3];
+    }
+    const bool startedDone = (nrib == 0);                             // Edge.cpp:93
+
+    // ---- phase 0: the curve (Edge::computeApproxCost -> DubinsWrapper::set)
+    const bool colocated = (srcX == tgtX) && (srcY == tgtY) && (srcH == tgtH);   // State::isCoLocated
+    PPDubins dub;
+    pp_dubins_shortest(srcX, srcY, pp_yaw(srcH), tgtX, tgtY, pp_yaw(tgtH), rho, dub);
+    PPCurve cv;
+    pp_curve_init(cv, srcX, srcY, pp_yaw(srcH), rho, dub);
+    const double approx = cv.length / speed * 1.0;                    // Edge.cpp:17
+    const double wEnd = srcT + cv.length / speed;                     // DubinsWrapper::setEndTime
+    double endTime = fmin(p.horizon + 1e-12 + p.sst, wEnd);           // Edge.cpp:90
+    bool infeasible = (srcT >= endTime);                              // :102-110
+    bool throwsRef = colocated || (dub.type < 0);
+    if (dub.type < 0) flags |= PPGPU_F_DUBINS_ERR;
+
+    // ---- sweep state
+    const double* tg = p.tgrid + (size_t)vi * p.ng;
+    int rdt = -1;                       // `auto ribbonsDoneTime = -1;` is an int (Edge.cpp:92)
+    int nextEvent = 0;                  // toCoverDistance starts at 0: step 0 is an event
+    int hitsAcc = 0;
+    int steps = 0;
+    double ix = srcX, iy = srcY, ih = srcH;   // `intermediate` pose
+    double lastHeading = srcH;                // Edge.cpp:96
+    double carryHeading = srcH;
+    double tfinal = tg[0];
+    bool dubErr = false;
+    const double w = p.ribw;
+    const double inc_d = p.inc_d;
+
+    if (!throwsRef) {
+        for (int base = 0;; base += PP_WAVE) {
+            const int k = base + lane;
+            const double t = (k < p.ng) ? tg[k] : INFINITY;
+            const double tFirst = pp_readlane(t, 0);
+            if (!(tFirst < endTime)) { tfinal = tFirst; break; }      // `while (intermediate.time() < endTime)`
+            const bool valid = t < endTime;
+
+            // phase A: pose + static + dynamic obstacles for 64 steps
+            double x = 0, y = 0, heading = 0;
+            bool blk = false;
+            int hits = 0;
+            if (valid) {
+                double dist = (t - srcT) * speed;                     // DubinsWrapper.cpp:36
+                if (dist < 0 || dist > cv.length) dist = dist - 1e-5; // EDUBPARAM retry, :39-42
+                if (dist < 0 || dist > cv.length) { dubErr = true; dist = fmin(fmax(dist, 0.0), cv.length); }
+                double yaw;
+                pp_curve_sample(cv, dist, x, y, yaw);
+                heading = pp_heading_from_yaw(yaw);                   // :47
+                blk = pp_is_blocked(p.grid, x, y);                    // Edge.cpp:144
+                hits = pp_obstacle_hits(p.obst, p.n_obst, x, y, t);   // :150-151
+            }
+            double prevHeading = __shfl_up(heading, 1, PP_WAVE);
+            if (lane == 0) prevHeading = carryHeading;
+
+            const unsigned long long bm = __ballot(blk);
+            const int fb = bm ? (__ffsll((long long)bm) - 1) : PP_WAVE;
+            const int nvalid = __popcll(__ballot(valid));
+            const int limit = fb < nvalid ? fb : nvalid;
+
+            // phase B: coverage events among steps [0, limit)
+            int lastEv = -1;
+            while (true) {
+                const int j = nextEvent - base;
+                if (j >= limit) break;
+                const double tj = pp_readlane(t, j);
+                if (!(tj < endTime)) break;
+                const double xj = pp_readlane(x, j), yj = pp_readlane(y, j);
+                const double hj = pp_readlane(heading, j), phj = pp_readlane(prevHeading, j);
+                const double D = pp_ribbons_min_distance(rib, nrib, w, xj, yj);          // Edge.cpp:158
+                if (cov || phj == hj) {                                                   // :159
+                    nrib = pp_ribbons_cover(rib, nrib, w, xj, yj, lds);                  // :160
+                    if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
+                }
+                if (nrib == 0) {                                                          // :162-170
+                    if (cct == -1) cct = tj;
+                    rdt = (int)tj;
+                    endTime = fmin(endTime, cct + p.tmin);
+                }
+                lastEv = j;
+                // steps until toCoverDistance <= increment again (:153-154): m subtractions
+                int m = 0;
+                if (D > inc_d) {
+                    const double qd = D / inc_d;
+                    if (qd > (double)(p.ng + 2)) {
+                        m = p.ng + 1;                                  // beyond the grid: never again
+                    } else {
+                        const int m0 = (int)ceil(qd - 1.0);
+                        const double r = fma(-(double)m0, inc_d, D);   // D - m0*inc, one rounding
+                        const double margin = (double)m0 * D * 5e-16 + 1e-12;
+                        if (m0 >= 1 && r > margin && r < inc_d - margin) {
+                            m = m0;                                    // the running subtraction cannot differ
+                        } else {
+                            double tc = D;                             // too close to call: do it the long way
+                            while (tc > inc_d && m <= p.ng) { tc -= inc_d; m++; }
+                        }
+                    }
+                }
+                nextEvent = base + j + m + 1;
+            }
+
+            const int cnt = __popcll(__ballot(valid && (t < endTime)));
+            int nexec = cnt > lastEv + 1 ? cnt : lastEv + 1;
+            nexec = nexec < limit ? nexec : limit;
+            if (lane < nexec) hitsAcc += hits;
+
+            if (fb < nvalid && nexec == fb) {           // reached the blocked step: `break` at :146
+                infeasible = true;
+                ix = pp_readlane(x, fb); iy = pp_readlane(y, fb); ih = pp_readlane(heading, fb);
+                lastHeading = pp_readlane(prevHeading, fb);
+                tfinal = pp_readlane(t, fb);
+                steps = base + fb + 1;
+                break;
+            }
+            if (nexec < PP_WAVE) {                      // loop condition failed inside this chunk
+                ix = pp_readlane(x, nexec - 1); iy = pp_readlane(y, nexec - 1); ih = pp_readlane(heading, nexec - 1);
+                lastHeading = ih;
+                tfinal = pp_readlane(t, nexec);
+                steps = base + nexec;
+                break;
+            }
+            ix = pp_readlane(x, 63); iy = pp_readlane(y, 63); ih = pp_readlane(heading, 63);
+            lastHeading = ih;
+            carryHeading = ih;
+            steps = base + PP_WAVE;
+        }
+    }
+    if (__ballot(dubErr) != 0ull) flags |= PPGPU_F_DUBINS_ERR;
+
+    // ---- phase C
+    // end()->state().time() = endTime; wrapper.sample(end state)  (Edge.cpp:177-178)
+    if (!throwsRef && !(srcT <= endTime && wEnd >= endTime)) throwsRef = true;   // DubinsWrapper::containsTime
+    double endX = 0, endY = 0, endHeading = 0;
+    if (!throwsRef) {
+        double dist = (endTime - srcT) * speed;
+        if (dist < 0 || dist > cv.length) dist = dist - 1e-5;
+        if (dist < 0 || dist > cv.length) { flags |= PPGPU_F_DUBINS_ERR; dist = fmin(fmax(dist, 0.0), cv.length); }
+        double yaw;
+        pp_curve_sample(cv, dist, endX, endY, yaw);
+        endHeading = pp_heading_from_yaw(yaw);
+        // cover the last little bit (:182-191)
+        if (cov || lastHeading == ih) {
+            nrib = pp_ribbons_cover(rib, nrib, w, ix, iy, lds);
+            if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
+        }
+        if (nrib == 0) {
+            if (cct == -1) cct = tfinal;
+            rdt = (int)tfinal;
+        }
+    }
+    const int hitsTotal = pp_wave_sum_i(hitsAcc);
+    const double penalty = (double)hitsTotal * p.cpf;                             // :150-151 summed
+    const double netTime = endTime - srcT;                                        // Edge::netTime
+    double tc = fmax(netTime - ((nrib == 0) ? (endTime - (double)rdt) : 0), 0);  // :197
+    if (startedDone) tc = 0;                                                      // :198
+    const double trueCost = tc * p.tpf + penalty;                                 // :199
+    const double g = srcG + trueCost;                                             // Vertex::setCurrentCost
+
+    // Vertex::computeApproxToGo (Vertex.cpp:49-64): child ribbons -> LDS, heuristic, / maxSpeed
+    double hdist = 0;
+    if (!throwsRef && nrib > 0) {
+        if (lane < nrib) { lds[lane * 4 + 0] = rib.sx; lds[lane * 4 + 1] = rib.sy; lds[lane * 4 + 2] = rib.ex; lds[lane * 4 + 3] = rib.ey; }
+        pp_wave_lds_fence();
+        if (p.heuristic == PPGPU_H_MAX_DISTANCE) {
+            hdist = pp_h_max_distance(lds, nrib, w, endX, endY);
+        } else if (nrib > PP_TSP_MAX) {
+            flags |= PPGPU_F_RIBBON_OVF;
+        } else if (p.heuristic == PPGPU_H_TSP_POINT_ALL) {
+            hdist = pp_h_tsp_point(lds, nrib, w, PP_TSP_MAX, false, endX, endY);
+        } else if (p.heuristic == PPGPU_H_TSP_POINT_K) {
+            hdist = pp_h_tsp_point(lds, nrib, w, p.tsp_k, true, endX, endY);
+        } else {
+            flags |= PPGPU_F_DUBINS_ERR;   // Dubins-TSP heuristics are not on the device path yet
+        }
+        pp_wave_lds_fence();
+    }
+    const double h = hdist / p.max_speed * p.tpf;
+
+    if (infeasible) flags |= PPGPU_F_INFEASIBLE;
+    if (throwsRef) flags |= PPGPU_F_THROWS | PPGPU_F_INFEASIBLE;
+    if (!throwsRef) {
+        if (nrib == 0) flags |= PPGPU_F_DONE;
+        // SamplingBasedPlanner::goalCondition (SamplingBasedPlanner.cpp:42-50)
+        const double coverageDoneTime = cct + p.tmin;
+        const double nonCoverageDoneTime = p.sst + p.horizon;
+        if (endTime >= nonCoverageDoneTime || (nrib == 0 && endTime >= coverageDoneTime)) flags |= PPGPU_F_GOAL;
+    }
+
+    // ---- one 128-byte record, lanes 0..15 write one 8-byte slot each
+    {
+        const unsigned info = (unsigned)((dub.type < 0 ? 0 : dub.type) & 0xff) | ((unsigned)(nrib & 0xff) << 8) |
+                              ((unsigned)(steps & 0xffff) << 16);
+        double v;
+        switch (lane) {
+            case 0: v = __hiloint2double((int)info, (int)flags); break;   // {flags (low), info (high)}
+            case 1: v = trueCost; break;
+            case 2: v = penalty; break;
+            case 3: v = approx; break;
+            case 4: v = endX; break;
+            case 5: v = endY; break;
+            case 6: v = endHeading; break;
+            case 7: v = speed; break;
+            case 8: v = endTime; break;
+            case 9: v = g; break;
+            case 10: v = h; break;
+            case 11: v = g + h; break;
+            case 12: v = cct; break;
+            case 13: v = dub.p0; break;
+            case 14: v = dub.p1; break;
+            default: v = dub.p2; break;
+        }
+        if (throwsRef && lane != 0) v = 0;
+        if (lane < 16) reinterpret_cast<double*>(rec)[lane] = v;
+    }
+    if (p.child && !throwsRef) {
+        if (lane < nrib && lane < p.stride) {
+            double* c = p.child + ((size_t)e * p.stride + lane) * 4;
+            c[0] = rib.sx; c[1] = rib.sy; c[2] = rib.ex; c[3] = rib.ey;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Dubins lengths from open vertices to every sample, both radii (Edge::computeApproxCost for the
+// k-nearest selection in SamplingBasedPlanner::expand, SamplingBasedPlanner.cpp:109-119).
+// Thread per (vertex, sample); sample loads are coalesced, the vertex is a scalar load.
+__global__ __launch_bounds__(256) void pp_k_dubins_lengths(const ppgpu_vertex* verts, int v0, const double* sx,
+                                                           const double* sy, const double* sh, long long ns, double rho,
+                                                           double rho_cov, double inc_d, double* out) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = blockIdx.y;
+    if (s >= ns) return;
+    const ppgpu_vertex* V = verts + v0 + v;
+    const double ax = V->x, ay = V->y, ayaw = pp_yaw(V->heading);
+    const double bx = sx[s], by = sy[s], byaw = pp_yaw(sh[s]);
+    double l0 = -1, l1 = -1;
+    if (sqrt((ax - bx) * (ax - bx) + (ay - by) * (ay - by)) > inc_d) {   // State::distanceTo, :111
+        PPDubins d;
+        pp_dubins_shortest(ax, ay, ayaw, bx, by, byaw, rho, d);
+        l0 = pp_dubins_length(d, rho);
+        pp_dubins_shortest(ax, ay, ayaw, bx, by, byaw, rho_cov, d);
+        l1 = pp_dubins_length(d, rho_cov);
+    }
+    double2 o; o.x = l0; o.y = l1;
+    reinterpret_cast<double2*>(out)[(size_t)v * ns + s] = o;
+}
+
+// k smallest (length, index) per (vertex, radius); one 256-thread workgroup each.  Round j finds
+// the lexicographic successor of round j-1's winner, so no exclusion list is needed.
+__global__ __launch_bounds__(256) void pp_k_select_nearest(const double* lengths, long long ns, int k, int* out_idx,
+                                                           double* out_len) {
+    __shared__ double sl[256];
+    __shared__ long long si[256];
+    const int vr = blockIdx.x;               // vertex * 2 + radius
+    const int v = vr >> 1, r = vr & 1;
+    const double* L = lengths + ((size_t)v * ns) * 2 + r;
+    double prevL = -INFINITY;
+    long long prevI = -1;
+    for (int j = 0; j < k; j++) {
+        double bl = INFINITY;
+        long long bi = -1;
+        for (long long s = threadIdx.x; s < ns; s += 256) {
+            double l = L[s * 2];
+            if (l < 0) continue;                                           // closer than the increment: skipped
+            bool after = (l > prevL) || (l == prevL && s > prevI);
+            if (after && (l < bl || (l == bl && (bi < 0 || s < bi)))) { bl = l; bi = s; }
+        }
+        sl[threadIdx.x] = bl; si[threadIdx.x] = bi;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+                double l2 = sl[threadIdx.x + o]; long long i2 = si[threadIdx.x + o];
+                double l1 = sl[threadIdx.x]; long long i1 = si[threadIdx.x];
+                if (i2 >= 0 && (i1 < 0 || l2 < l1 || (l2 == l1 && i2 < i1))) { sl[threadIdx.x] = l2; si[threadIdx.x] = i2; }
+            }
+            __syncthreads();
+        }
+        prevL = sl[0]; prevI = si[0];
+        if (threadIdx.x == 0) { out_idx[(size_t)vr * k + j] = (int)prevI; out_len[(size_t)vr * k + j] = prevI >= 0 ? prevL : -1.0; }
+        __syncthreads();
+        if (prevI < 0) {                                                    // fewer than k candidates
+            for (int jj = j + 1; jj < k; jj++) if (threadIdx.x == 0) { out_idx[(size_t)vr * k + jj] = -1; out_len[(size_t)vr * k + jj] = -1.0; }
+            break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Incumbent selection: lexicographic min of (bits of f, edge index) over feasible edges — the
+// batch form of `if (!best || v->f() < best->f()) best = v` (AStarPlanner.cpp:109-117).
+// Stage 1: wave shuffle-reduce + LDS across the 4 waves -> one partial per workgroup;
+// stage 2: one workgroup over the partials.  Deterministic (no atomics).
+__device__ __forceinline__ void pp_key_min(unsigned long long& f, unsigned long long& i, unsigned long long f2, unsigned long long i2) {
+    if (f2 < f || (f2 == f && i2 < i)) { f = f2; i = i2; }
+}
+__device__ __forceinline__ void pp_key_wave_min(unsigned long long& f, unsigned long long& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long f2 = __shfl_xor(f, o, PP_WAVE), i2 = __shfl_xor(i, o, PP_WAVE);
+        pp_key_min(f, i, f2, i2);
+    }
+}
+__global__ __launch_bounds__(256) void pp_k_best_stage1(const ppgpu_edge_result* res, long long n, int goal_only,
+                                                        unsigned long long base, unsigned long long* partial) {
+    __shared__ unsigned long long sf[4], si[4];
+    unsigned long long f = ~0ull, idx = ~0ull;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        unsigned fl = res[e].flags;
+        bool ok = !(fl & PPGPU_F_INFEASIBLE) && (!goal_only || (fl & PPGPU_F_GOAL));
+        if (ok) {
+            unsigned long long fb = (unsigned long long)__double_as_longlong(res[e].f);
+            pp_key_min(f, idx, fb, base + (unsigned long long)e);
+        }
+    }
+    pp_key_wave_min(f, idx);
+    if (pp_lane() == 0) { sf[threadIdx.x >> 6] = f; si[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) pp_key_min(f, idx, sf[w], si[w]);
+        partial[2 * blockIdx.x] = f; partial[2 * blockIdx.x + 1] = idx;
+    }
+}
+__global__ __launch_bounds__(256) void pp_k_best_stage2(const unsigned long long* partial, int nparts, unsigned long long* key2) {
+    __shared__ unsigned long long sf[4], si[4];
+    unsigned long long f = ~0ull, idx = ~0ull;
+    for (int i = threadIdx.x; i < nparts; i += 256) pp_key_min(f, idx, partial[2 * i], partial[2 * i + 1]);
+    pp_key_wave_min(f, idx);
+    if (pp_lane() == 0) { sf[threadIdx.x >> 6] = f; si[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) pp_key_min(f, idx, sf[w], si[w]);
+        key2[0] = f; key2[1] = idx;
+    }
+}
+// after an all-gather of per-rank keys: lexicographic min of `n` (f, idx) pairs
+__global__ void pp_k_key_min_n(const unsigned long long* keys, int n, unsigned long long* key2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned long long f = ~0ull, idx = ~0ull;
+        for (int i = 0; i < n; i++) pp_key_min(f, idx, keys[2 * i], keys[2 * i + 1]);
+        key2[0] = f; key2[1] = idx;
+    }
+}

@@ -1,0 +1,292 @@
+// pp_sampler.h — StateGenerator on the device, bit-exact with libstdc++'s stream.
+//
+// Reference: path_planner/src/planner/utilities/StateGenerator.{h,cpp}.
+//   * std::default_random_engine == minstd_rand0: x <- 16807 x mod (2^31 - 1)
+//   * every uniform_real_distribution<double> draw = generate_canonical<double,53> = TWO engine
+//     calls: ((e1 - 1) + (e2 - 1) * R) / (R * R), R = 2^31 - 2, evaluated in double
+//   * g++ evaluates State(x(), y(), heading(), speed(), 0)'s arguments right to left, so a sample
+//     consumes the draws speed, heading, y, x  (SURVEY.md section 8 a-1 probe)
+//   * with ribbons a 5th draw decides (u < pi/50) whether the state is projected onto the nearest
+//     ribbon, and only then a 6th draw decides the heading flip (StateGenerator.cpp:21-28)
+//
+// So the stream is measured in "pair slots" (one double draw each); sample i starts at slot q_i,
+// q_{i+1} = q_i + 5 + proj(q_i), where proj(q) is a pure function of the slot (the draw at q + 4).
+// The LCG admits O(log n) jump-ahead, so proj() is evaluated for every slot in parallel; which
+// slots the chain actually visits is a linear recurrence over GF(2)-like booleans,
+//     vis[q+1] = vis[q-4] & !proj[q-4]  |  vis[q-5] & proj[q-5],
+// i.e. a prefix "product" of 6x6 boolean matrices — an associative scan.  A second (integer) scan
+// ranks the visited slots, giving every sample its slot; samples are then generated one per thread.
+#pragma once
+#include "pp_device.h"
+
+#define PP_SCAN_TILE 2048   // elements per 256-thread workgroup in the scan kernels (8 per thread)
+
+struct PPSamplerState {
+    double b[6];               // minX, maxX, minY, maxY, minSpeed, maxSpeed
+    unsigned seed;             // engine state before the first call
+    int on_ribbons;            // m_SampleOnRibbons
+    int n_ribbons;
+    int initialised;
+    unsigned long long pos;    // pair slots consumed so far
+};
+
+// ------------------------------------------------------------------------------ minstd_rand0
+#define PP_LCG_M 2147483647ull
+__device__ __forceinline__ unsigned pp_mulmod(unsigned a, unsigned b) {
+    unsigned long long p = (unsigned long long)a * (unsigned long long)b;   // < 2^62
+    unsigned long long r = (p & PP_LCG_M) + (p >> 31);                      // < 2^32
+    r = (r & PP_LCG_M) + (r >> 31);
+    if (r >= PP_LCG_M) r -= PP_LCG_M;
+    return (unsigned)r;
+}
+// engine state after `k` calls from state x
+__device__ inline unsigned pp_lcg_jump(unsigned x, unsigned long long k) {
+    unsigned a = 16807u, acc = 1u;
+    while (k) {
+        if (k & 1ull) acc = pp_mulmod(acc, a);
+        a = pp_mulmod(a, a);
+        k >>= 1;
+    }
+    return pp_mulmod(x, acc);
+}
+// one generate_canonical<double,53> from state x (advanced by two calls)
+__device__ __forceinline__ double pp_canonical(unsigned& x) {
+    const double R = 2147483646.0;
+    x = pp_mulmod(x, 16807u);
+    double sum = (double)(x - 1u) * 1.0;
+    double tmp = R;
+    x = pp_mulmod(x, 16807u);
+    sum += (double)(x - 1u) * tmp;
+    tmp *= R;
+    double ret = sum / tmp;
+    if (ret >= 1.0) ret = 0.99999999999999988897769753748434595763683319091796875;   // nextafter(1, 0)
+    return ret;
+}
+__device__ __forceinline__ double pp_uniform(unsigned& x, double a, double b) { return pp_canonical(x) * (b - a) + a; }
+
+// ------------------------------------------------------------------------------ 1. proj bits
+// proj[qi] bit 0 = (5th draw of a sample starting at slot pos + qi) < pi/50   (StateGenerator.cpp:22)
+__global__ __launch_bounds__(256) void pp_k_proj_bits(unsigned seed, unsigned long long pos, long long nq, unsigned char* proj) {
+    long long qi = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    unsigned x = pp_lcg_jump(seed, 2ull * (pos + (unsigned long long)qi + 4ull));
+    double u = pp_uniform(x, 0, PP_TWO_PI);
+    proj[qi] = (u < PP_PI / 50) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------ 2. chain scan
+// 6x6 boolean matrix, row i in bits [6i, 6i+6); C = A after B.
+__device__ __forceinline__ unsigned long long pp_bm_compose(unsigned long long A, unsigned long long B) {
+    unsigned long long C = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        unsigned ra = (unsigned)((A >> (6 * i)) & 63ull);
+        unsigned rc = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) rc |= ((ra >> k) & 1u) ? (unsigned)((B >> (6 * k)) & 63ull) : 0u;
+        C |= (unsigned long long)rc << (6 * i);
+    }
+    return C;
+}
+#define PP_BM_IDENTITY (1ull | (2ull << 6) | (4ull << 12) | (8ull << 18) | (16ull << 24) | (32ull << 30))
+// transition of slot qi: V_{q+1} = M V_q with V_q = (vis[q], vis[q-1], ..., vis[q-5])
+__device__ __forceinline__ unsigned long long pp_bm_step(const unsigned char* proj, long long qi) {
+    unsigned p4 = qi >= 4 ? (proj[qi - 4] & 1u) : 0u;
+    unsigned p5 = qi >= 5 ? (proj[qi - 5] & 1u) : 0u;
+    unsigned row0 = ((p4 ^ 1u) << 4) | (p5 << 5);
+    return (unsigned long long)row0 | (1ull << 6) | (2ull << 12) | (4ull << 18) | (8ull << 24) | (16ull << 30);
+}
+// inclusive scan over the 256 thread aggregates of a workgroup; returns this thread's EXCLUSIVE prefix
+// (identity for thread 0) and the workgroup aggregate through `total`.  Later elements compose on the left.
+__device__ inline unsigned long long pp_bm_block_scan(unsigned long long agg, unsigned long long* sh, unsigned long long& total) {
+    const int t = threadIdx.x;
+    sh[t] = agg;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        unsigned long long mine = sh[t];
+        unsigned long long other = (t >= o) ? sh[t - o] : PP_BM_IDENTITY;
+        __syncthreads();
+        sh[t] = pp_bm_compose(mine, other);
+        __syncthreads();
+    }
+    total = sh[255];
+    unsigned long long excl = (t == 0) ? PP_BM_IDENTITY : sh[t - 1];
+    __syncthreads();
+    return excl;
+}
+__global__ __launch_bounds__(256) void pp_k_chain_reduce(const unsigned char* proj, long long nq, unsigned long long* blk) {
+    __shared__ unsigned long long sh[256];
+    long long q0 = (long long)blockIdx.x * PP_SCAN_TILE + (long long)threadIdx.x * 8;
+    unsigned long long agg = PP_BM_IDENTITY;
+    for (int i = 0; i < 8; i++) {
+        long long q = q0 + i;
+        if (q < nq) agg = pp_bm_compose(pp_bm_step(proj, q), agg);
+    }
+    unsigned long long total;
+    pp_bm_block_scan(agg, sh, total);
+    if (threadIdx.x == 0) blk[blockIdx.x] = total;
+}
+// exclusive scan of the workgroup aggregates, in place (at most PP_SCAN_TILE of them)
+__global__ __launch_bounds__(256) void pp_k_chain_scan_blocks(unsigned long long* blk, int nblk) {
+    __shared__ unsigned long long sh[256];
+    int b0 = threadIdx.x * 8;
+    unsigned long long loc[8];
+    unsigned long long agg = PP_BM_IDENTITY;
+    for (int i = 0; i < 8; i++) {
+        loc[i] = (b0 + i < nblk) ? blk[b0 + i] : PP_BM_IDENTITY;
+        agg = pp_bm_compose(loc[i], agg);
+    }
+    unsigned long long total;
+    unsigned long long pre = pp_bm_block_scan(agg, sh, total);
+    for (int i = 0; i < 8; i++) {
+        if (b0 + i < nblk) blk[b0 + i] = pre;
+        pre = pp_bm_compose(loc[i], pre);
+    }
+}
+// vis[q] = (P_q e_0)[0] = P_q[0][0]; stored as bit 1 of proj[q]
+__global__ __launch_bounds__(256) void pp_k_chain_apply(unsigned char* proj, long long nq, const unsigned long long* blk) {
+    __shared__ unsigned long long sh[256];
+    long long q0 = (long long)blockIdx.x * PP_SCAN_TILE + (long long)threadIdx.x * 8;
+    unsigned long long m[8];
+    unsigned long long agg = PP_BM_IDENTITY;
+    for (int i = 0; i < 8; i++) {
+        long long q = q0 + i;
+        m[i] = (q < nq) ? pp_bm_step(proj, q) : PP_BM_IDENTITY;
+        agg = pp_bm_compose(m[i], agg);
+    }
+    unsigned long long total;
+    unsigned long long pre = pp_bm_block_scan(agg, sh, total);
+    pre = pp_bm_compose(pre, blk[blockIdx.x]);
+    unsigned vis[8];
+    for (int i = 0; i < 8; i++) {
+        vis[i] = (unsigned)(pre & 1ull);
+        pre = pp_bm_compose(m[i], pre);
+    }
+    __syncthreads();   // every thread has read its proj[q-4], proj[q-5] neighbours (bit 0 only is read; bit 1 written)
+    for (int i = 0; i < 8; i++) {
+        long long q = q0 + i;
+        if (q < nq) proj[q] = (unsigned char)((proj[q] & 1u) | (vis[i] << 1));
+    }
+}
+
+// ------------------------------------------------------------------------------ 3. integer scans
+__device__ inline unsigned pp_u32_block_scan(unsigned agg, unsigned* sh, unsigned& total) {
+    const int t = threadIdx.x;
+    sh[t] = agg;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        unsigned v = (t >= o) ? sh[t - o] : 0u;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    total = sh[255];
+    unsigned excl = (t == 0) ? 0u : sh[t - 1];
+    __syncthreads();
+    return excl;
+}
+__global__ __launch_bounds__(256) void pp_k_count_reduce(const unsigned char* flags, long long n, unsigned mask, unsigned* blk) {
+    __shared__ unsigned sh[256];
+    long long i0 = (long long)blockIdx.x * PP_SCAN_TILE + (long long)threadIdx.x * 8;
+    unsigned cnt = 0;
+    for (int i = 0; i < 8; i++) if (i0 + i < n && (flags[i0 + i] & mask)) cnt++;
+    unsigned total;
+    pp_u32_block_scan(cnt, sh, total);
+    if (threadIdx.x == 0) blk[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void pp_k_count_scan_blocks(unsigned* blk, int nblk) {
+    __shared__ unsigned sh[256];
+    int b0 = threadIdx.x * 8;
+    unsigned loc[8], agg = 0;
+    for (int i = 0; i < 8; i++) { loc[i] = (b0 + i < nblk) ? blk[b0 + i] : 0u; agg += loc[i]; }
+    unsigned total;
+    unsigned pre = pp_u32_block_scan(agg, sh, total);
+    for (int i = 0; i < 8; i++) { if (b0 + i < nblk) blk[b0 + i] = pre; pre += loc[i]; }
+}
+// slot of sample i for i < n, and the absolute slot of sample n (= where the next call resumes)
+__global__ __launch_bounds__(256) void pp_k_chain_positions(const unsigned char* proj, long long nq, const unsigned* blk,
+                                                            long long n, unsigned* qpos, unsigned long long* end_slot) {
+    __shared__ unsigned sh[256];
+    long long q0 = (long long)blockIdx.x * PP_SCAN_TILE + (long long)threadIdx.x * 8;
+    unsigned cnt = 0;
+    for (int i = 0; i < 8; i++) if (q0 + i < nq && (proj[q0 + i] & 2u)) cnt++;
+    unsigned total;
+    unsigned rank = pp_u32_block_scan(cnt, sh, total) + blk[blockIdx.x];
+    for (int i = 0; i < 8; i++) {
+        long long q = q0 + i;
+        if (q < nq && (proj[q] & 2u)) {
+            if ((long long)rank < n) qpos[rank] = (unsigned)q;
+            else if ((long long)rank == n) *end_slot = (unsigned long long)q;   // relative; host adds pos
+            rank++;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ 4. generate
+// RibbonManager::projectOntoNearestRibbon (RibbonManager.cpp:220-232) + Ribbon::getProjectionAsState
+// (Ribbon.cpp:80-88): nearest by perpendicular distance to the infinite line, first minimum wins.
+__device__ inline void pp_project_onto_nearest(const double* rb, int n, double& x, double& y, double& heading) {
+    if (n == 0) return;
+    double mn = PP_DBL_MAX;
+    PPRibbon best = {0, 0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        PPRibbon r = {rb[4 * i], rb[4 * i + 1], rb[4 * i + 2], rb[4 * i + 3]};
+        double d = pp_ribbon_line_distance(r, x, y);
+        if (d < mn) { mn = d; best = r; }
+    }
+    double px, py;
+    pp_ribbon_projection(best, x, y, px, py);
+    // State::setHeadingTowards(endX, endY) (State.cpp:51-57,64-67)
+    double dx = best.ex - px;
+    double dy = best.ey - py;
+    double h = PP_PI_2 - atan2(dy, dx);
+    if (h < 0) h += PP_TWO_PI;
+    x = px; y = py; heading = h;
+}
+
+__global__ __launch_bounds__(256) void pp_k_generate(PPSamplerState s, const unsigned* qpos, const unsigned char* proj,
+                                                     const double* ribbons, long long n, double* cand) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long rel = qpos ? (unsigned long long)qpos[i] : 4ull * (unsigned long long)i;
+    unsigned x = pp_lcg_jump(s.seed, 2ull * (s.pos + rel));
+    double speed = pp_uniform(x, s.b[4], s.b[5]);   // drawn first (right-to-left argument evaluation)
+    (void)speed;                                    // expand() overwrites it (SamplingBasedPlanner.cpp:113)
+    double heading = pp_uniform(x, 0, PP_TWO_PI);
+    double yy = pp_uniform(x, s.b[2], s.b[3]);
+    double xx = pp_uniform(x, s.b[0], s.b[1]);
+    if (s.on_ribbons) {
+        double u5 = pp_uniform(x, 0, PP_TWO_PI);
+        if (u5 < PP_PI / 50) {                       // StateGenerator.cpp:22
+            pp_project_onto_nearest(ribbons, s.n_ribbons, xx, yy, heading);
+            double u6 = pp_uniform(x, 0, PP_TWO_PI);
+            if (u6 < PP_PI) heading += PP_PI;        // :24-26, no wrap
+        }
+    }
+    cand[i] = xx; cand[n + i] = yy; cand[2 * n + i] = heading;
+}
+
+// ------------------------------------------------------------------------------ 5. map filter + compaction
+__global__ __launch_bounds__(256) void pp_k_keep_flags(PPGrid g, const double* cand, long long n, unsigned char* keep) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    keep[i] = pp_is_blocked(g, cand[i], cand[n + i]) ? 0 : 1;   // SamplingBasedPlanner.cpp:161
+}
+__global__ __launch_bounds__(256) void pp_k_compact_samples(const unsigned char* keep, long long n, const unsigned* blk,
+                                                            const double* cand, double* sx, double* sy, double* sh,
+                                                            long long base, unsigned long long* total_out) {
+    __shared__ unsigned shm[256];
+    long long i0 = (long long)blockIdx.x * PP_SCAN_TILE + (long long)threadIdx.x * 8;
+    unsigned cnt = 0;
+    for (int i = 0; i < 8; i++) if (i0 + i < n && keep[i0 + i]) cnt++;
+    unsigned total;
+    unsigned rank = pp_u32_block_scan(cnt, shm, total) + blk[blockIdx.x];
+    for (int i = 0; i < 8; i++) {
+        long long j = i0 + i;
+        if (j < n && keep[j]) {
+            sx[base + rank] = cand[j]; sy[base + rank] = cand[n + j]; sh[base + rank] = cand[2 * n + j];
+            rank++;
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *total_out = (unsigned long long)rank;
+}

@@ -1,0 +1,546 @@
+// ppgpu.hip — C ABI (include/ppgpu.h) over the gfx950 kernels in pp_kernels.h / pp_sampler.h.
+//
+// Build (see __graft_entry__.build()):
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared ppgpu.hip -o libppgpu.so
+// -ffp-contract=off is part of the contract: the reference rounds every product and sum
+// separately (baseline x86-64), and so must the device code.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ppgpu.h"
+#include "pp_kernels.h"
+#include "pp_sampler.h"
+
+static thread_local std::string g_err = "";
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(call)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (call);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(PPGPU_EHIP, std::string(#call) + ": " + hipGetErrorString(_e));            \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    int reserve(size_t n, bool keep, hipStream_t s) {
+        if (n <= cap) return PPGPU_OK;
+        size_t ncap = cap ? cap : 64;
+        while (ncap < n) ncap *= 2;
+        T* np = nullptr;
+        HIP_TRY(hipMalloc((void**)&np, ncap * sizeof(T)));
+        if (keep && p && cap) {
+            HIP_TRY(hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+        if (p) HIP_TRY(hipFree(p));
+        p = np; cap = ncap;
+        return PPGPU_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct ppgpu_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    bool have_cfg = false;
+    ppgpu_config cfg{};
+    // Map
+    DevBuf<uint32_t> grid;
+    int rows = 0, cols = 0, wpr = 0;
+    double res = 0;
+    // dynamic obstacles
+    DevBuf<PPObst> obst;
+    int n_obst = 0;
+    // open vertices
+    DevBuf<ppgpu_vertex> verts;
+    DevBuf<double> ribbons, tgrid;
+    int nverts = 0, nribbons = 0, ng = 0;
+    // sample (target state) store, SoA
+    DevBuf<double> sx, sy, sh;
+    long long n_samples = 0;
+    // sampler (StateGenerator) state
+    PPSamplerState sampler{};
+    DevBuf<double> samp_ribbons;
+    DevBuf<unsigned char> s_bytes;      // scan / compaction scratch
+    DevBuf<unsigned long long> s_u64;
+    DevBuf<unsigned> s_u32a, s_u32b;
+    DevBuf<double> s_cand;              // candidate states before the map filter
+    // scratch for host-convenience entry points and reductions
+    DevBuf<unsigned long long> tmp_edges, partial;
+    DevBuf<ppgpu_edge_result> tmp_results;
+    DevBuf<double> tmp_child, tmp_lengths, tmp_len_out;
+    DevBuf<int> tmp_idx;
+    DevBuf<unsigned long long> gather;
+};
+
+static int require_cfg(ppgpu_ctx* c) {
+    if (!c) return fail(PPGPU_EINVAL, "null context");
+    if (!c->have_cfg) return fail(PPGPU_ESTATE, "ppgpu_set_config must be called first");
+    return PPGPU_OK;
+}
+
+extern "C" {
+
+const char* ppgpu_last_error(void) { return g_err.c_str(); }
+
+int ppgpu_create(int device, ppgpu_ctx** out) {
+    if (!out) return fail(PPGPU_EINVAL, "out is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(PPGPU_ENODEV, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(PPGPU_ENODEV, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PPGPU_ENODEV, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+    ppgpu_ctx* c = new ppgpu_ctx();
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    *out = c;
+    return PPGPU_OK;
+}
+
+int ppgpu_destroy(ppgpu_ctx* c) {
+    if (!c) return PPGPU_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->grid.release(); c->obst.release(); c->verts.release(); c->ribbons.release(); c->tgrid.release();
+    c->sx.release(); c->sy.release(); c->sh.release(); c->samp_ribbons.release();
+    c->s_bytes.release(); c->s_u64.release(); c->s_u32a.release(); c->s_u32b.release(); c->s_cand.release();
+    c->tmp_edges.release(); c->partial.release(); c->tmp_results.release(); c->tmp_child.release();
+    c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release();
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return PPGPU_OK;
+}
+
+int ppgpu_set_stream(ppgpu_ctx* c, void* s) {
+    if (!c) return fail(PPGPU_EINVAL, "null context");
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return PPGPU_OK;
+}
+
+int ppgpu_synchronize(ppgpu_ctx* c) {
+    if (!c) return fail(PPGPU_EINVAL, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PPGPU_OK;
+}
+
+int ppgpu_set_config(ppgpu_ctx* c, const ppgpu_config* cfg) {
+    if (!c || !cfg) return fail(PPGPU_EINVAL, "null argument");
+    if (!(cfg->max_speed > 0) || !(cfg->collision_checking_increment > 0) || !(cfg->turning_radius > 0) ||
+        !(cfg->coverage_turning_radius > 0) || !(cfg->time_horizon > 0))
+        return fail(PPGPU_EINVAL, "config: speeds, radii, increment and horizon must be positive");
+    if (cfg->heuristic < PPGPU_H_MAX_DISTANCE || cfg->heuristic > PPGPU_H_TSP_DUBINS_K)
+        return fail(PPGPU_EINVAL, "config: unknown heuristic");
+    if (cfg->heuristic == PPGPU_H_TSP_DUBINS_ALL || cfg->heuristic == PPGPU_H_TSP_DUBINS_K)
+        return fail(PPGPU_EINVAL, "config: the Dubins-TSP heuristics are not implemented on the device path yet");
+    double steps = cfg->time_horizon / (cfg->collision_checking_increment / cfg->max_speed);
+    if (!(steps < 60000.0)) return fail(PPGPU_ECAPACITY, "config: more than 60000 collision-check steps per edge");
+    c->cfg = *cfg;
+    c->have_cfg = true;
+    c->ng = (int)steps + 8;
+    c->nverts = 0;  // time grids depend on the config: vertices must be set again
+    return PPGPU_OK;
+}
+
+int ppgpu_set_grid(ppgpu_ctx* c, const uint8_t* cells, int32_t rows, int32_t cols, double res) {
+    if (!c) return fail(PPGPU_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (rows == 0) { c->rows = c->cols = c->wpr = 0; c->res = 0; return PPGPU_OK; }
+    if (!cells || rows < 0 || cols <= 0 || !(res > 0)) return fail(PPGPU_EINVAL, "grid: bad shape or resolution");
+    int wpr = (cols + 31) / 32;
+    std::vector<uint32_t> bits((size_t)rows * wpr, 0u);
+    for (int r = 0; r < rows; r++) {
+        const uint8_t* row = cells + (size_t)r * cols;
+        uint32_t* brow = bits.data() + (size_t)r * wpr;
+        for (int x = 0; x < cols; x++)
+            if (row[x]) brow[x >> 5] |= 1u << (x & 31);
+    }
+    int rc = c->grid.reserve(bits.size(), false, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->grid.p, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->rows = rows; c->cols = cols; c->wpr = wpr; c->res = res;
+    return PPGPU_OK;
+}
+
+int ppgpu_set_obstacles(ppgpu_ctx* c, int32_t model, int32_t n, const double* o7) {
+    if (!c) return fail(PPGPU_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (model == PPGPU_OBST_NONE || n == 0) { c->n_obst = 0; return PPGPU_OK; }
+    if (model != PPGPU_OBST_BINARY) return fail(PPGPU_EINVAL, "obstacles: unknown model");
+    if (n < 0 || !o7) return fail(PPGPU_EINVAL, "obstacles: bad arguments");
+    std::vector<PPObst> h((size_t)n);
+    for (int i = 0; i < n; i++) {
+        const double* o = o7 + 7 * (size_t)i;
+        // Obstacle(x, y, heading, speed, time, width, length): Yaw = M_PI_2 - heading
+        // (BinaryDynamicObstaclesManager.h:17-19); strict: Width += 2, Length += 2 (.cpp:8-11)
+        double yaw = M_PI_2 - o[2];
+        h[i].X = o[0]; h[i].Y = o[1];
+        h[i].cosYaw = std::cos(yaw); h[i].sinYaw = std::sin(yaw);
+        h[i].Speed = o[3]; h[i].Time = o[4];
+        h[i].halfW = (o[5] + 2) / 2;
+        h[i].halfL = (o[6] + 2) / 2;
+    }
+    int rc = c->obst.reserve((size_t)n, false, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->obst.p, h.data(), h.size() * sizeof(PPObst), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n_obst = n;
+    return PPGPU_OK;
+}
+
+int ppgpu_set_vertices(ppgpu_ctx* c, int32_t n, const ppgpu_vertex* hv, int32_t n_ribbons, const double* hr) {
+    int rc = require_cfg(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (n <= 0 || !hv || n_ribbons < 0 || (n_ribbons > 0 && !hr)) return fail(PPGPU_EINVAL, "vertices: bad arguments");
+    if (n >= (1 << 24)) return fail(PPGPU_ECAPACITY, "vertices: at most 2^24-1 open vertices");
+    for (int i = 0; i < n; i++) {
+        if (hv[i].ribbon_count < 0 || hv[i].ribbon_offset < 0 || hv[i].ribbon_offset + hv[i].ribbon_count > n_ribbons)
+            return fail(PPGPU_EINVAL, "vertices: ribbon range outside the pool");
+        if (hv[i].ribbon_count > PP_WAVE) return fail(PPGPU_ECAPACITY, "vertices: more than 64 ribbons on one vertex");
+        if (hv[i].time < c->cfg.start_state_time) return fail(PPGPU_EINVAL, "vertices: vertex time before start_state_time");
+    }
+    if ((rc = c->verts.reserve((size_t)n, false, c->stream))) return rc;
+    if ((rc = c->ribbons.reserve((size_t)(n_ribbons > 0 ? n_ribbons : 1) * 4, false, c->stream))) return rc;
+    if ((rc = c->tgrid.reserve((size_t)n * c->ng, false, c->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->verts.p, hv, (size_t)n * sizeof(ppgpu_vertex), hipMemcpyHostToDevice, c->stream));
+    if (n_ribbons > 0)
+        HIP_TRY(hipMemcpyAsync(c->ribbons.p, hr, (size_t)n_ribbons * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pp_k_time_grid, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->verts.p, n, c->cfg.start_state_time,
+                       c->cfg.collision_checking_increment, c->cfg.max_speed, c->ng, c->tgrid.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the host arrays may go away after return
+    c->nverts = n; c->nribbons = n_ribbons;
+    return PPGPU_OK;
+}
+
+// ------------------------------------------------------------------------------ samples
+int ppgpu_set_samples(ppgpu_ctx* c, int64_t n, const double* hx, const double* hy, const double* hh) {
+    if (!c) return fail(PPGPU_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (n < 0 || (n > 0 && (!hx || !hy || !hh))) return fail(PPGPU_EINVAL, "samples: bad arguments");
+    if (n >= (1ll << 32)) return fail(PPGPU_ECAPACITY, "samples: at most 2^32-1");
+    int rc;
+    size_t need = (size_t)(n > 0 ? n : 1);
+    if ((rc = c->sx.reserve(need, false, c->stream)) || (rc = c->sy.reserve(need, false, c->stream)) ||
+        (rc = c->sh.reserve(need, false, c->stream)))
+        return rc;
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(c->sx.p, hx, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->sy.p, hy, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->sh.p, hh, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    c->n_samples = n;
+    return PPGPU_OK;
+}
+
+int ppgpu_get_samples(ppgpu_ctx* c, int64_t first, int64_t n, double* out5) {
+    int rc = require_cfg(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (first < 0 || n < 0 || first + n > c->n_samples || (n > 0 && !out5)) return fail(PPGPU_EINVAL, "get_samples: range");
+    if (n == 0) return PPGPU_OK;
+    std::vector<double> x((size_t)n), y((size_t)n), h((size_t)n);
+    HIP_TRY(hipMemcpyAsync(x.data(), c->sx.p + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(y.data(), c->sy.p + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(h.data(), c->sh.p + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < n; i++) {
+        out5[5 * i] = x[(size_t)i]; out5[5 * i + 1] = y[(size_t)i]; out5[5 * i + 2] = h[(size_t)i];
+        // speed is not stored per sample: expand() overwrites it with maxSpeed before any use
+        // (SamplingBasedPlanner.cpp:113), so the store keeps x, y, heading only.
+        out5[5 * i + 3] = c->cfg.max_speed;
+        out5[5 * i + 4] = 0;   // State(..., 0) (StateGenerator.cpp:16-20)
+    }
+    return PPGPU_OK;
+}
+
+int64_t ppgpu_num_samples(ppgpu_ctx* c) { return c ? c->n_samples : 0; }
+
+int ppgpu_sampler_init(ppgpu_ctx* c, const double* b6, uint64_t seed, int32_t n_ribbons, const double* hr) {
+    int rc = require_cfg(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!b6) return fail(PPGPU_EINVAL, "sampler: bounds are null");
+    if (n_ribbons > 0 && !hr) return fail(PPGPU_EINVAL, "sampler: ribbons are null");
+    if (n_ribbons > 1024) return fail(PPGPU_ECAPACITY, "sampler: more than 1024 ribbons");
+    PPSamplerState& s = c->sampler;
+    for (int i = 0; i < 6; i++) s.b[i] = b6[i];
+    // std::linear_congruential_engine::seed: c == 0 and s mod m == 0 -> 1
+    unsigned long long x = seed % 2147483647ull;
+    s.seed = (unsigned)(x == 0 ? 1 : x);
+    s.on_ribbons = n_ribbons >= 0 ? 1 : 0;   // the ribbon constructor sets m_SampleOnRibbons even for an empty manager
+    s.n_ribbons = n_ribbons > 0 ? n_ribbons : 0;
+    s.pos = 0;
+    s.initialised = 1;
+    if (n_ribbons > 0) {
+        if ((rc = c->samp_ribbons.reserve((size_t)n_ribbons * 4, false, c->stream))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->samp_ribbons.p, hr, (size_t)n_ribbons * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    c->n_samples = 0;
+    return PPGPU_OK;
+}
+
+int ppgpu_sampler_add(ppgpu_ctx* c, int64_t n_attempts, int64_t* n_total_out) {
+    int rc = require_cfg(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->sampler.initialised) return fail(PPGPU_ESTATE, "ppgpu_sampler_init must be called first");
+    if (n_attempts < 0) return fail(PPGPU_EINVAL, "sampler: negative count");
+    if (n_attempts == 0) { if (n_total_out) *n_total_out = c->n_samples; return PPGPU_OK; }
+    if (n_attempts > (1ll << 26)) return fail(PPGPU_ECAPACITY, "sampler: at most 2^26 attempts per call");
+    const long long n = n_attempts;
+    PPSamplerState& s = c->sampler;
+    hipStream_t st = c->stream;
+    // worst case every sample is projected: 6 pair-slots per sample
+    const long long nq = s.on_ribbons ? (6 * n + 8) : n;
+    size_t need_samples = (size_t)(c->n_samples + n);
+    if ((rc = c->sx.reserve(need_samples, true, st)) || (rc = c->sy.reserve(need_samples, true, st)) ||
+        (rc = c->sh.reserve(need_samples, true, st)))
+        return rc;
+    if ((rc = c->s_cand.reserve((size_t)n * 3, false, st))) return rc;
+    if ((rc = c->s_bytes.reserve((size_t)(nq > n ? nq : n) + 64, false, st))) return rc;
+    const int nblk_q = (int)((nq + PP_SCAN_TILE - 1) / PP_SCAN_TILE);
+    const int nblk_n = (int)((n + PP_SCAN_TILE - 1) / PP_SCAN_TILE);
+    if ((rc = c->s_u64.reserve((size_t)nblk_q + 64, false, st))) return rc;
+    if ((rc = c->s_u32a.reserve((size_t)(nq > n ? nq : n) + 64, false, st))) return rc;
+    if ((rc = c->s_u32b.reserve((size_t)(nblk_q > nblk_n ? nblk_q : nblk_n) + 64, false, st))) return rc;
+    if (nblk_q > PP_SCAN_TILE || nblk_n > PP_SCAN_TILE) return fail(PPGPU_ECAPACITY, "sampler: batch too large for the two-level scan");
+
+    unsigned char* proj = c->s_bytes.p;           // per pair-slot: would a sample starting here be projected?
+    unsigned* qpos = c->s_u32a.p;                 // pair-slot of sample i (compacted)
+    unsigned* blk32 = c->s_u32b.p;
+    unsigned long long* blk64 = c->s_u64.p;
+    long long end_pos_host = 0;
+    HIP_TRY(hipMemsetAsync(c->s_u64.p + nblk_q + 8, 0, 16 * sizeof(unsigned long long), st));
+
+    if (s.on_ribbons) {
+        // 1. proj[q] for every even stream offset 2q in range (thread per q, LCG jump-ahead)
+        hipLaunchKernelGGL(pp_k_proj_bits, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, s.seed, s.pos, nq, proj);
+        // 2. visited[q]: the chain q -> q + 5 + proj[q] as a scan of 6x6 boolean transition matrices
+        hipLaunchKernelGGL(pp_k_chain_reduce, dim3(nblk_q), dim3(256), 0, st, proj, nq, blk64);
+        hipLaunchKernelGGL(pp_k_chain_scan_blocks, dim3(1), dim3(256), 0, st, blk64, nblk_q);
+        hipLaunchKernelGGL(pp_k_chain_apply, dim3(nblk_q), dim3(256), 0, st, proj, nq, blk64);   // proj[q] |= visited << 1
+        // 3. rank the visited slots: sample index of each, and slot of each sample
+        hipLaunchKernelGGL(pp_k_count_reduce, dim3(nblk_q), dim3(256), 0, st, proj, nq, 2, blk32);
+        hipLaunchKernelGGL(pp_k_count_scan_blocks, dim3(1), dim3(256), 0, st, blk32, nblk_q);
+        hipLaunchKernelGGL(pp_k_chain_positions, dim3(nblk_q), dim3(256), 0, st, proj, nq, blk32, n, qpos, c->s_u64.p + nblk_q + 8);
+    }
+    // 4. generate the n candidate states (thread per sample)
+    hipLaunchKernelGGL(pp_k_generate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, s.on_ribbons ? qpos : nullptr,
+                       s.on_ribbons ? proj : nullptr, c->samp_ribbons.p, n, c->s_cand.p);
+    // 5. SamplingBasedPlanner::addSamples' map filter, order-preserving compaction into the store
+    PPGrid g{c->grid.p, c->rows, c->cols, c->wpr, c->res};
+    unsigned char* keep = proj;  // the projection bits are no longer needed once the candidates exist
+    hipLaunchKernelGGL(pp_k_keep_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, c->s_cand.p, n, keep);
+    hipLaunchKernelGGL(pp_k_count_reduce, dim3(nblk_n), dim3(256), 0, st, keep, n, 1, blk32);
+    hipLaunchKernelGGL(pp_k_count_scan_blocks, dim3(1), dim3(256), 0, st, blk32, nblk_n);
+    unsigned long long* d_total = c->s_u64.p + nblk_q + 16;
+    hipLaunchKernelGGL(pp_k_compact_samples, dim3(nblk_n), dim3(256), 0, st, keep, n, blk32, c->s_cand.p, c->sx.p, c->sy.p,
+                       c->sh.p, c->n_samples, d_total);
+    HIP_TRY(hipGetLastError());
+    unsigned long long h2[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(&h2[0], d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (s.on_ribbons)
+        HIP_TRY(hipMemcpyAsync(&h2[1], c->s_u64.p + nblk_q + 8, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (s.on_ribbons && h2[1] == 0) return fail(PPGPU_EHIP, "sampler: chain scan did not reach the end of the batch");
+    end_pos_host = s.on_ribbons ? (long long)(s.pos + h2[1]) : (long long)(s.pos + n * 4);
+    s.pos = (unsigned long long)end_pos_host;   // pair-slots consumed so far (2 engine calls each)
+    c->n_samples += (long long)h2[0];
+    if (n_total_out) *n_total_out = c->n_samples;
+    return PPGPU_OK;
+}
+
+// ------------------------------------------------------------------------------ edge generation
+static void fill_params(ppgpu_ctx* c, PPParams& p) {
+    const ppgpu_config& g = c->cfg;
+    p.max_speed = g.max_speed;
+    p.slow_speed = g.slow_speed <= 0 ? g.max_speed : g.slow_speed;   // PlannerConfig::slowSpeed()
+    p.rho = g.turning_radius; p.rho_cov = g.coverage_turning_radius;
+    p.horizon = g.time_horizon; p.tmin = g.time_minimum; p.inc_d = g.collision_checking_increment;
+    p.sst = g.start_state_time; p.ribw = g.ribbon_width;
+    p.cpf = g.collision_penalty_factor; p.tpf = g.time_penalty_factor;
+    p.heuristic = g.heuristic; p.tsp_k = g.tsp_k;
+    p.grid = PPGrid{c->grid.p, c->rows, c->cols, c->wpr, c->res};
+    p.obst = c->obst.p; p.n_obst = c->n_obst;
+    p.verts = c->verts.p; p.ribbons = c->ribbons.p; p.tgrid = c->tgrid.p; p.ng = c->ng; p.nverts = c->nverts;
+    p.sx = c->sx.p; p.sy = c->sy.p; p.sh = c->sh.p; p.n_samples = c->n_samples;
+}
+
+static int require_world(ppgpu_ctx* c) {
+    int rc = require_cfg(c);
+    if (rc) return rc;
+    if (c->nverts <= 0) return fail(PPGPU_ESTATE, "ppgpu_set_vertices must be called (after ppgpu_set_config)");
+    if (c->n_samples <= 0) return fail(PPGPU_ESTATE, "no samples: call ppgpu_sampler_add or ppgpu_set_samples");
+    return PPGPU_OK;
+}
+
+int ppgpu_dubins_lengths(ppgpu_ctx* c, int32_t v0, int32_t nv, double* d_lengths) {
+    int rc = require_world(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (v0 < 0 || nv <= 0 || v0 + nv > c->nverts || !d_lengths) return fail(PPGPU_EINVAL, "dubins_lengths: vertex range");
+    if (nv > 65535) return fail(PPGPU_ECAPACITY, "dubins_lengths: at most 65535 vertices per call");
+    const long long ns = c->n_samples;
+    hipLaunchKernelGGL(pp_k_dubins_lengths, dim3((unsigned)((ns + 255) / 256), (unsigned)nv), dim3(256), 0, c->stream, c->verts.p,
+                       v0, c->sx.p, c->sy.p, c->sh.p, ns, c->cfg.turning_radius, c->cfg.coverage_turning_radius,
+                       c->cfg.collision_checking_increment, d_lengths);
+    HIP_TRY(hipGetLastError());
+    return PPGPU_OK;
+}
+
+int ppgpu_select_nearest(ppgpu_ctx* c, int32_t v0, int32_t nv, int32_t k, int32_t* h_idx, double* h_len) {
+    int rc = require_world(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (k <= 0 || !h_idx || !h_len) return fail(PPGPU_EINVAL, "select_nearest: bad arguments");
+    const long long ns = c->n_samples;
+    if ((rc = c->tmp_lengths.reserve((size_t)nv * ns * 2, false, c->stream))) return rc;
+    if ((rc = ppgpu_dubins_lengths(c, v0, nv, c->tmp_lengths.p))) return rc;
+    size_t nout = (size_t)nv * 2 * k;
+    if ((rc = c->tmp_idx.reserve(nout, false, c->stream)) || (rc = c->tmp_len_out.reserve(nout, false, c->stream))) return rc;
+    hipLaunchKernelGGL(pp_k_select_nearest, dim3((unsigned)(nv * 2)), dim3(256), 0, c->stream, c->tmp_lengths.p, ns, k,
+                       c->tmp_idx.p, c->tmp_len_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_idx, c->tmp_idx.p, nout * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(h_len, c->tmp_len_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PPGPU_OK;
+}
+
+// ------------------------------------------------------------------------------ edge costing
+int64_t ppgpu_dense_edge_count(int32_t nv, int64_t ns, uint32_t cfg_mask) {
+    return (int64_t)nv * ns * (int64_t)__builtin_popcount(cfg_mask & 0xFu);
+}
+
+static int launch_cost(ppgpu_ctx* c, PPParams& p) {
+    if (p.n_edges <= 0) return PPGPU_OK;
+    long long blocks = (p.n_edges + 3) / 4;
+    if (blocks > 0x7fffffffll) return fail(PPGPU_ECAPACITY, "cost_edges: too many edges for one launch");
+    hipLaunchKernelGGL(pp_k_cost_edges, dim3((unsigned)blocks), dim3(256), 0, c->stream, p);
+    HIP_TRY(hipGetLastError());
+    return PPGPU_OK;
+}
+
+int ppgpu_cost_edges_dense(ppgpu_ctx* c, int32_t v0, int32_t nv, int64_t s0, int64_t ns, uint32_t cfg_mask,
+                           ppgpu_edge_result* d_results, double* d_child, int32_t stride) {
+    int rc = require_world(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    cfg_mask &= 0xFu;
+    if (v0 < 0 || nv <= 0 || v0 + nv > c->nverts) return fail(PPGPU_EINVAL, "cost_edges_dense: vertex range");
+    if (s0 < 0 || ns <= 0 || s0 + ns > c->n_samples) return fail(PPGPU_EINVAL, "cost_edges_dense: sample range");
+    if (!cfg_mask || !d_results) return fail(PPGPU_EINVAL, "cost_edges_dense: empty configuration mask or null results");
+    if (d_child && stride <= 0) return fail(PPGPU_EINVAL, "cost_edges_dense: ribbon_stride must be positive");
+    PPParams p;
+    fill_params(c, p);
+    p.edges = nullptr;
+    p.v0 = v0; p.nv = nv; p.s0 = s0; p.ns = ns; p.cfg_mask = cfg_mask; p.per = __builtin_popcount(cfg_mask);
+    p.n_edges = (long long)nv * ns * p.per;
+    p.out = d_results; p.child = d_child; p.stride = stride;
+    return launch_cost(c, p);
+}
+
+int ppgpu_cost_edges_list(ppgpu_ctx* c, int64_t n, const uint64_t* d_edges, ppgpu_edge_result* d_results, double* d_child,
+                          int32_t stride) {
+    int rc = require_world(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (n < 0 || (n > 0 && (!d_edges || !d_results))) return fail(PPGPU_EINVAL, "cost_edges_list: bad arguments");
+    if (d_child && stride <= 0) return fail(PPGPU_EINVAL, "cost_edges_list: ribbon_stride must be positive");
+    PPParams p;
+    fill_params(c, p);
+    p.edges = (const unsigned long long*)d_edges;
+    p.v0 = 0; p.nv = 0; p.s0 = 0; p.ns = 1; p.cfg_mask = 0; p.per = 1;
+    p.n_edges = n;
+    p.out = d_results; p.child = d_child; p.stride = stride;
+    return launch_cost(c, p);
+}
+
+int ppgpu_cost_edges_host(ppgpu_ctx* c, int64_t n, const uint64_t* h_edges, ppgpu_edge_result* h_results, double* h_child,
+                          int32_t stride) {
+    int rc = require_world(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (n < 0 || (n > 0 && (!h_edges || !h_results))) return fail(PPGPU_EINVAL, "cost_edges_host: bad arguments");
+    if (n == 0) return PPGPU_OK;
+    if (h_child && stride <= 0) return fail(PPGPU_EINVAL, "cost_edges_host: ribbon_stride must be positive");
+    if ((rc = c->tmp_edges.reserve((size_t)n, false, c->stream))) return rc;
+    if ((rc = c->tmp_results.reserve((size_t)n, false, c->stream))) return rc;
+    if (h_child && (rc = c->tmp_child.reserve((size_t)n * stride * 4, false, c->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->tmp_edges.p, h_edges, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    if (h_child) HIP_TRY(hipMemsetAsync(c->tmp_child.p, 0, (size_t)n * stride * 4 * sizeof(double), c->stream));
+    if ((rc = ppgpu_cost_edges_list(c, n, (const uint64_t*)c->tmp_edges.p, c->tmp_results.p, h_child ? c->tmp_child.p : nullptr, stride)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(h_results, c->tmp_results.p, (size_t)n * sizeof(ppgpu_edge_result), hipMemcpyDeviceToHost, c->stream));
+    if (h_child)
+        HIP_TRY(hipMemcpyAsync(h_child, c->tmp_child.p, (size_t)n * stride * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PPGPU_OK;
+}
+
+// ------------------------------------------------------------------------------ incumbent
+int ppgpu_best_edge(ppgpu_ctx* c, int64_t n, const ppgpu_edge_result* d_results, int32_t goal_only, uint64_t base,
+                    uint64_t* d_key2) {
+    if (!c) return fail(PPGPU_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (n < 0 || !d_key2 || (n > 0 && !d_results)) return fail(PPGPU_EINVAL, "best_edge: bad arguments");
+    int nparts = (int)((n + 255) / 256);
+    if (nparts > 1024) nparts = 1024;
+    if (nparts < 1) nparts = 1;
+    int rc = c->partial.reserve((size_t)nparts * 2, false, c->stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pp_k_best_stage1, dim3(nparts), dim3(256), 0, c->stream, d_results, (long long)n, goal_only,
+                       (unsigned long long)base, c->partial.p);
+    hipLaunchKernelGGL(pp_k_best_stage2, dim3(1), dim3(256), 0, c->stream, c->partial.p, nparts, (unsigned long long*)d_key2);
+    HIP_TRY(hipGetLastError());
+    return PPGPU_OK;
+}
+
+}  // extern "C"
+
+// RCCL is loaded lazily so that single-GPU users (and the CPU-only build check) do not need it.
+#include <dlfcn.h>
+extern "C" int ppgpu_allreduce_best(ppgpu_ctx* c, void* comm, uint64_t* d_key2) {
+    if (!c || !comm || !d_key2) return fail(PPGPU_EINVAL, "allreduce_best: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    typedef int (*allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+    typedef int (*count_t)(void*, int*);
+    static void* lib = nullptr;
+    static allgather_t allgather = nullptr;
+    static count_t count = nullptr;
+    if (!lib) {
+        lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return fail(PPGPU_ERCCL, std::string("cannot load librccl.so: ") + dlerror());
+        allgather = (allgather_t)dlsym(lib, "ncclAllGather");
+        count = (count_t)dlsym(lib, "ncclCommCount");
+        if (!allgather || !count) return fail(PPGPU_ERCCL, "librccl.so lacks ncclAllGather/ncclCommCount");
+    }
+    int world = 0;
+    if (count(comm, &world) != 0 || world <= 0) return fail(PPGPU_ERCCL, "ncclCommCount failed");
+    int rc = c->gather.reserve((size_t)world * 2, false, c->stream);
+    if (rc) return rc;
+    // one collective: 16 bytes per rank over xGMI; ncclUint64 == 5 in the NCCL ABI
+    if (allgather(d_key2, c->gather.p, 2, 5, comm, c->stream) != 0) return fail(PPGPU_ERCCL, "ncclAllGather failed");
+    hipLaunchKernelGGL(pp_k_key_min_n, dim3(1), dim3(64), 0, c->stream, c->gather.p, world, (unsigned long long*)d_key2);
+    HIP_TRY(hipGetLastError());
+    return PPGPU_OK;
+}

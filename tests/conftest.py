@@ -1,0 +1,23 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build_oracle():
+    """The CPU checker (oracle/libpp_oracle.so) is built on demand; it is test infrastructure only."""
+    so = os.path.join(ROOT, "oracle", "libpp_oracle.so")
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("pp_oracle.cpp", "pp_oracle_c.cpp", "pp_oracle.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    yield

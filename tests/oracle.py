@@ -1,0 +1,291 @@
+"""ctypes binding of oracle/libpp_oracle.so (the CPU checker) and, when present, of
+oracle/_ref/libpp_ref.so (the reference's own standalone sources compiled in place).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from path_planner_amd.types import PpgpuConfig, RESULT_DTYPE, VERTEX_DTYPE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "libpp_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libpp_ref.so")
+
+vp, dbl, i32, i64, u64 = C.c_void_p, C.c_double, C.c_int, C.c_long, C.c_uint64
+
+
+def _build():
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("pp_oracle.cpp", "pp_oracle_c.cpp", "pp_oracle.hpp")]
+    if not os.path.exists(ORACLE_SO) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+
+
+_build()
+O = C.CDLL(ORACLE_SO)
+
+
+class PlanStats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("generated", C.c_uint64), ("expanded", C.c_uint64), ("iterations", C.c_uint64),
+                ("plan_f", dbl), ("plan_collision_penalty", dbl), ("plan_time_penalty", dbl), ("plan_h", dbl),
+                ("plan_depth", C.c_uint64), ("first_goal_iteration", C.c_int64), ("plan_len", C.c_int32), ("threw", C.c_int32)]
+
+
+def _sig(lib, name, res, args):
+    f = getattr(lib, name)
+    f.restype, f.argtypes = res, args
+
+
+for _n, _r, _a in [
+    ("ppo_dubins_shortest_path", i32, [vp, vp, dbl, vp]),
+    ("ppo_dubins_word", i32, [i32, vp, vp, dbl, vp]),
+    ("ppo_dubins_path_length", dbl, [vp]),
+    ("ppo_dubins_path_sample", i32, [vp, dbl, vp]),
+    ("ppo_dubins_extract_subpath", i32, [vp, dbl, vp]),
+    ("ppo_wrapper_sample", i32, [vp, vp, dbl, dbl, dbl, vp, vp]),
+    ("ppo_state_yaw", dbl, [dbl]),
+    ("ppo_state_heading_to", dbl, [dbl, dbl, dbl, dbl]),
+    ("ppo_state_move", None, [vp, dbl]),
+    ("ppo_state_push", None, [vp, dbl, vp]),
+    ("ppo_set_ribbon_width", None, [dbl]),
+    ("ppo_get_ribbon_width", dbl, []),
+    ("ppo_ribbons_add", i32, [vp, i32, i32, dbl, dbl, dbl, dbl]),
+    ("ppo_ribbons_cover", i32, [vp, i32, i32, dbl, dbl, i32]),
+    ("ppo_ribbons_cover_between", i32, [vp, i32, i32, dbl, dbl, dbl, dbl, i32]),
+    ("ppo_ribbons_min_distance", dbl, [vp, i32, dbl, dbl]),
+    ("ppo_ribbons_heuristic", dbl, [vp, i32, i32, i32, dbl, dbl, dbl, dbl]),
+    ("ppo_ribbons_nearest_endpoint", i32, [vp, i32, vp, vp]),
+    ("ppo_ribbons_project", None, [vp, i32, vp]),
+    ("ppo_ribbon_projection", None, [vp, dbl, dbl, vp]),
+    ("ppo_ribbon_contains", i32, [vp, dbl, dbl, i32]),
+    ("ppo_ribbon_contains_projection", i32, [vp, dbl, dbl]),
+    ("ppo_ribbon_distance", dbl, [vp, dbl, dbl]),
+    ("ppo_ribbon_covered", i32, [vp, i32]),
+    ("ppo_ribbon_split", None, [vp, dbl, dbl, i32, vp]),
+    ("ppo_ribbon_end_states", None, [vp, vp, vp]),
+    ("ppo_world_create", vp, []),
+    ("ppo_world_destroy", None, [vp]),
+    ("ppo_world_set_config", None, [vp, C.POINTER(PpgpuConfig)]),
+    ("ppo_world_set_grid", None, [vp, vp, i32, i32, dbl]),
+    ("ppo_world_load_grid_text", i32, [vp, C.c_char_p, C.POINTER(i32), C.POINTER(dbl)]),
+    ("ppo_world_get_cells", None, [vp, vp]),
+    ("ppo_world_extremes", None, [vp, vp]),
+    ("ppo_world_is_blocked", i32, [vp, dbl, dbl]),
+    ("ppo_world_is_blocked_many", None, [vp, i64, vp, vp, vp]),
+    ("ppo_world_set_obstacles", None, [vp, i32, i32, vp]),
+    ("ppo_world_collision_exists", dbl, [vp, dbl, dbl, dbl, i32]),
+    ("ppo_sampler_generate", None, [vp, u64, i32, vp, i64, i64, vp, vp]),
+    ("ppo_add_samples", i64, [vp, vp, u64, i32, vp, i64, i64, vp]),
+    ("ppo_cost_edges", i32, [vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i32]),
+    ("ppo_dubins_lengths", i32, [vp, vp, i32, i32, i64, vp, vp, vp, vp]),
+    ("ppo_plan", i32, [vp, i32, vp, dbl, vp, i32, i32, i32, vp, dbl, dbl, dbl, C.POINTER(PlanStats), vp, i32, vp, i32, vp, i64,
+                        C.POINTER(i64)]),
+    ("ppo_hardware_threads", i32, []),
+]:
+    _sig(O, _n, _r, _a)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class World:
+    """Grid + obstacles + config of the oracle."""
+
+    def __init__(self, cfg, grid=None, res=0.0, obst=None):
+        self.h = O.ppo_world_create()
+        self.cfg = cfg
+        O.ppo_world_set_config(self.h, C.byref(cfg))
+        if grid is not None:
+            g = np.ascontiguousarray(grid, dtype=np.uint8)
+            O.ppo_world_set_grid(self.h, _p(g), g.shape[0], g.shape[1], float(res))
+        if obst is not None and len(obst):
+            o = f64(obst).reshape(-1, 7)
+            O.ppo_world_set_obstacles(self.h, 1, o.shape[0], _p(o))
+
+    def __del__(self):
+        try:
+            O.ppo_world_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_config(self, cfg):
+        self.cfg = cfg
+        O.ppo_world_set_config(self.h, C.byref(cfg))
+
+    def is_blocked(self, x, y):
+        x, y = f64(x), f64(y)
+        out = np.zeros(x.shape[0], dtype=np.uint8)
+        O.ppo_world_is_blocked_many(self.h, x.shape[0], _p(x), _p(y), _p(out))
+        return out
+
+    def collision_exists(self, x, y, t, strict=True):
+        return O.ppo_world_collision_exists(self.h, x, y, t, 1 if strict else 0)
+
+    def add_samples(self, bounds6, seed, ribbons4, skip, n):
+        b = f64(bounds6)
+        out = np.zeros((n, 5), dtype=np.float64)
+        if ribbons4 is None:
+            k = O.ppo_add_samples(self.h, _p(b), seed, -1, None, skip, n, _p(out))
+        else:
+            r = f64(ribbons4).reshape(-1, 4)
+            k = O.ppo_add_samples(self.h, _p(b), seed, r.shape[0], _p(r) if r.shape[0] else None, skip, n, _p(out))
+        return out[:k].copy()
+
+    def cost_edges(self, vertices, ribbons4, sx, sy, sh, edges, stride=0, threads=1):
+        O.ppo_world_set_config(self.h, C.byref(self.cfg))
+        v = np.ascontiguousarray(vertices, dtype=VERTEX_DTYPE)
+        r = f64(ribbons4).reshape(-1, 4)
+        if r.shape[0] == 0:
+            r = np.zeros((1, 4))
+        sx, sy, sh = f64(sx), f64(sy), f64(sh)
+        e = np.ascontiguousarray(edges, dtype=np.uint64)
+        out = np.zeros(e.shape[0], dtype=RESULT_DTYPE)
+        child = np.zeros((e.shape[0], stride, 4), dtype=np.float64) if stride > 0 else None
+        rc = O.ppo_cost_edges(self.h, _p(v), _p(r), _p(sx), _p(sy), _p(sh), e.shape[0], _p(e), _p(out), _p(child), stride, threads)
+        assert rc == 0
+        return (out, child) if stride > 0 else out
+
+    def dubins_lengths(self, vertices, v0, nv, sx, sy, sh):
+        v = np.ascontiguousarray(vertices, dtype=VERTEX_DTYPE)
+        sx, sy, sh = f64(sx), f64(sy), f64(sh)
+        out = np.zeros((nv, sx.shape[0], 2), dtype=np.float64)
+        O.ppo_dubins_lengths(self.h, _p(v), v0, nv, sx.shape[0], _p(sx), _p(sy), _p(sh), _p(out))
+        return out
+
+    def plan(self, ribbons4, start5, time_remaining, clock_t0, clock_dt, initial_samples=100, cct=-1.0, prev11=None,
+             use_brown_paths=False, dump_edges=0):
+        O.ppo_world_set_config(self.h, C.byref(self.cfg))
+        r = f64(ribbons4).reshape(-1, 4)
+        s = f64(start5)
+        st = PlanStats()
+        plan = np.zeros((64, 11))
+        itf = np.full(256, np.nan)
+        prev = f64(prev11).reshape(-1, 11) if prev11 is not None else np.zeros((0, 11))
+        dump = np.zeros((dump_edges, 16)) if dump_edges else None
+        ne = i64()
+        rc = O.ppo_plan(self.h, r.shape[0], _p(r) if r.shape[0] else None, cct, _p(s), initial_samples, 1 if use_brown_paths else 0,
+                        prev.shape[0], _p(prev) if prev.shape[0] else None, time_remaining, clock_t0, clock_dt, C.byref(st),
+                        _p(plan), 64, _p(itf), 256, _p(dump), dump_edges, C.byref(ne))
+        return rc, st, plan[:max(st.plan_len, 0)].copy(), itf[:st.iterations].copy(), (dump[:min(ne.value, dump_edges)] if dump_edges else None)
+
+
+def sampler_generate(bounds6, seed, ribbons4, skip, n):
+    b = f64(bounds6)
+    out = np.zeros((n, 5))
+    d = C.c_uint64()
+    if ribbons4 is None:
+        O.ppo_sampler_generate(_p(b), seed, -1, None, skip, n, _p(out), C.byref(d))
+    else:
+        r = f64(ribbons4).reshape(-1, 4)
+        O.ppo_sampler_generate(_p(b), seed, r.shape[0], _p(r) if r.shape[0] else None, skip, n, _p(out), C.byref(d))
+    return out, d.value
+
+
+def dubins_shortest_path(q0, q1, rho):
+    q0, q1 = f64(q0), f64(q1)
+    out = np.zeros(8)
+    e = O.ppo_dubins_shortest_path(_p(q0), _p(q1), rho, _p(out))
+    return e, out
+
+
+def dubins_sample(path8, t):
+    p = f64(path8)
+    q = np.zeros(3)
+    e = O.ppo_dubins_path_sample(_p(p), t, _p(q))
+    return e, q
+
+
+def yaw(heading):
+    return O.ppo_state_yaw(heading)
+
+
+def ribbons_heuristic(ribbons4, heuristic, K, x, y, yaw_=0.0, turning_radius=8.0):
+    r = f64(ribbons4).reshape(-1, 4)
+    return O.ppo_ribbons_heuristic(_p(r) if r.shape[0] else None, r.shape[0], heuristic, K, turning_radius, x, y, yaw_)
+
+
+def ribbons_add(ribbons4, x1, y1, x2, y2, cap=64):
+    r = np.zeros((cap, 4))
+    n = len(ribbons4)
+    if n:
+        r[:n] = f64(ribbons4).reshape(-1, 4)
+    m = O.ppo_ribbons_add(_p(r), n, cap, x1, y1, x2, y2)
+    return r[:m].copy()
+
+
+def ribbons_cover(ribbons4, x, y, strict, cap=64):
+    r = np.zeros((cap, 4))
+    n = len(ribbons4)
+    if n:
+        r[:n] = f64(ribbons4).reshape(-1, 4)
+    m = O.ppo_ribbons_cover(_p(r), n, cap, x, y, 1 if strict else 0)
+    return r[:m].copy()
+
+
+def ribbons_cover_between(ribbons4, x1, y1, x2, y2, strict, cap=64):
+    r = np.zeros((cap, 4))
+    n = len(ribbons4)
+    if n:
+        r[:n] = f64(ribbons4).reshape(-1, 4)
+    m = O.ppo_ribbons_cover_between(_p(r), n, cap, x1, y1, x2, y2, 1 if strict else 0)
+    return r[:m].copy()
+
+
+def ribbons_min_distance(ribbons4, x, y):
+    r = f64(ribbons4).reshape(-1, 4)
+    return O.ppo_ribbons_min_distance(_p(r) if r.shape[0] else None, r.shape[0], x, y)
+
+
+def ribbons_nearest_endpoint(ribbons4, s5):
+    r = f64(ribbons4).reshape(-1, 4)
+    s = f64(s5)
+    out = np.zeros(5)
+    rc = O.ppo_ribbons_nearest_endpoint(_p(r), r.shape[0], _p(s), _p(out))
+    return rc, out
+
+
+# ---------------------------------------------------------------- the reference's own objects (optional)
+REF = None
+if os.path.exists(REF_SO):
+    REF = C.CDLL(REF_SO)
+    for _n, _r, _a in [
+        ("ref_state_yaw", dbl, [dbl]),
+        ("ref_state_heading_to", dbl, [dbl, dbl, dbl, dbl]),
+        ("ref_state_move", None, [vp, dbl]),
+        ("ref_state_push", None, [vp, dbl, vp]),
+        ("ref_state_distance_to", dbl, [vp, dbl, dbl]),
+        ("ref_state_heading_difference", dbl, [vp, dbl]),
+        ("ref_set_ribbon_width", None, [dbl]),
+        ("ref_ribbon_min_length", dbl, []),
+        ("ref_ribbon_projection", None, [vp, dbl, dbl, vp]),
+        ("ref_ribbon_contains", i32, [vp, dbl, dbl, i32]),
+        ("ref_ribbon_contains_projection", i32, [vp, dbl, dbl]),
+        ("ref_ribbon_distance", dbl, [vp, dbl, dbl]),
+        ("ref_ribbon_length", dbl, [vp]),
+        ("ref_ribbon_covered", i32, [vp, i32]),
+        ("ref_ribbon_split", None, [vp, dbl, dbl, i32, vp]),
+        ("ref_ribbon_end_states", None, [vp, vp, vp]),
+        ("ref_ribbon_projection_as_state", None, [vp, dbl, dbl, vp]),
+        ("ref_grid_load", vp, [C.c_char_p]),
+        ("ref_grid_free", None, [vp]),
+        ("ref_grid_is_blocked", i32, [vp, dbl, dbl]),
+        ("ref_grid_is_blocked_many", None, [vp, i64, vp, vp, vp]),
+        ("ref_grid_extremes", None, [vp, vp]),
+        ("ref_grid_resolution", dbl, [vp]),
+        ("ref_base_map_is_blocked", i32, [dbl, dbl]),
+        ("ref_base_map_extremes", None, [vp]),
+        ("ref_obst_create", vp, []),
+        ("ref_obst_free", None, [vp]),
+        ("ref_obst_update", None, [vp, C.c_uint, dbl, dbl, dbl, dbl, dbl, dbl, dbl]),
+        ("ref_obst_collision_exists", dbl, [vp, dbl, dbl, dbl, i32]),
+    ]:
+        _sig(REF, _n, _r, _a)
