@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py — edges costed per second on the BASELINE.json workload, one process per GPU.
+
+One "step" = one planner iteration's hot path over one batch of synthetic input, all of it on
+the device: draw the batch of states from the StateGenerator stream (this rank's shard), drop the
+ones on blocked cells, generate the Dubins edge from the open vertex to every kept sample under
+the four (radius, speed) configurations, cost every edge (collision sweep, dynamic-obstacle
+penalty, ribbon coverage, heuristic), min-reduce the best (f, edge).  With N > 1 the batch is
+sharded by sample index and one RCCL collective per step combines the per-rank incumbents.
+
+Workload (config.workload): SURVEY.md 8(d) config 3 — 65 536 sample attempts per GPU per
+iteration, 2048x2048 occupancy grid at 0.1 m with 10 % blocked, 16 moving obstacles, 5 ribbons,
+TSP(K=2) heuristic; edges = root x kept samples x {rho 8, 16} x {2.5, 0.5 m/s}.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X datasheet, non-matrix fp64 (not in the microarch guide)
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=65536, help="sample attempts per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from path_planner_amd import api, workloads
+    from path_planner_amd.types import RESULT_DTYPE, F_INFEASIBLE
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    w = workloads.config3()
+    B = args.batch
+    ctx = api.Context(local)
+    stream = torch.cuda.Stream(dev)          # a real (non-null) stream shared by the kernels, torch events and RCCL
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
+    ctx.set_config(w.cfg)
+    ctx.set_grid(w.grid, w.res)
+    ctx.set_obstacles(w.obst)
+    ctx.set_vertices(w.root(), w.ribbons4)
+
+    max_edges = 4 * B
+    d_res = torch.zeros(max_edges * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    d_key2 = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_gather = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+    kernel_events = []
+
+    def step(timed):
+        ctx.sampler_init(w.bounds6, w.seed, w.ribbons4)
+        if rank:
+            ctx.sampler_skip(rank * B)        # this rank's shard of the iteration's batch
+        n = ctx.sampler_add(B)
+        ne = 4 * n
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        ctx.cost_edges_dense(0, 1, 0, n, 0xF, d_res.data_ptr())
+        ev1.record(stream)
+        ctx.best_edge(ne, d_res.data_ptr(), d_key2.data_ptr(), goal_only=False, base=rank * max_edges)
+        if world > 1:
+            dist.all_gather_into_tensor(d_gather, d_key2)          # one collective: 16 B per rank over xGMI
+            ctx.key_min(world, d_gather.data_ptr(), d_key2.data_ptr())
+        if timed:
+            kernel_events.append((ev0, ev1))
+        return ne
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    edges = 0
+    for _ in range(args.steps):
+        edges += step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([float(edges), elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        e_sum = tot[0:1].clone()
+        t_max = tot[1:2].clone()
+        dist.all_reduce(e_sum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        total_edges, t = float(e_sum.item()), float(t_max.item())
+    else:
+        total_edges, t = float(edges), elapsed
+
+    if rank == 0:
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in kernel_events]))
+        res = d_res.cpu().numpy().view(RESULT_DTYPE)[: edges // args.steps]
+        n_edges_launch = len(res)
+        steps_mean = float((res["info"] >> 16).mean())
+        feas_frac = float(((res["flags"] & F_INFEASIBLE) == 0).mean())
+        M = 0 if w.obst is None else len(w.obst)
+        R = len(w.ribbons4)
+        # algorithmic bytes / flops per edge with the MEASURED mean step count
+        bytes_per_edge = 88 + 32 + 32 * R + 56 * M / 4.0 + 150 + steps_mean / 8.0
+        flops_per_edge = 1000 + steps_mean * (70 + 21 * M) + 4.0e4
+        ach_gbs = bytes_per_edge * n_edges_launch / (kern_ms * 1e-3) / 1e9
+        ach_tf = flops_per_edge * n_edges_launch / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")   # written from a separate rocprofv3 --pmc pass
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        key = d_key2.cpu().numpy().view(np.uint64)
+        out = {
+            "metric": "Dubins edges costed/sec on 2048x2048 grid",
+            "value": total_edges / t,
+            "unit": "edges/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * t / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": w.name, "grid": "2048x2048 @0.1m, 10% blocked", "samples_per_iter_per_gpu": B,
+                       "dynamic_obstacles": M, "ribbons": R, "heuristic": "TspPointRobotNoSplitKRibbons K=2",
+                       "edges_per_iter_per_gpu": n_edges_launch, "sharding": "sample batch split by rank, 1 all-gather/iter"},
+            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "pp_k_cost_edges", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_edge": bytes_per_edge,
+                         "note": "this sweep is fp64-VALU bound, not HBM bound (SURVEY 8d): see valu_fp64"},
+            "valu_fp64": {"achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TFLOPS,
+                          "algorithmic_flops_per_edge": flops_per_edge},
+            "workload_stats": {"mean_sweep_steps_per_edge": steps_mean, "feasible_fraction": feas_frac,
+                               "kernel_edges_per_s": n_edges_launch / (kern_ms * 1e-3),
+                               "best_f": float(np.array([key[0]], dtype=np.uint64).view(np.float64)[0]), "best_edge": int(key[1])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out.update(cpu_baseline_and_parity(ctx, w, res))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline_and_parity(ctx, w, gpu_res):
+    """Time the CPU oracle (restatement of the reference path, kind "port") on a bounded sample of the same
+    edge list, on this box's host cores, and gate the run on parity for those edges."""
+    import numpy as np
+    import oracle as orc
+    from parity import compare_results
+    from path_planner_amd.types import edge_pack
+
+    samples = ctx.get_samples()
+    world = orc.World(w.cfg, w.grid, w.res, w.obst)
+    # the GPU box gives one GPU a 16-core CPU share; never oversubscribe it
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    n_multi = min(len(samples), 4096)       # 16384 edges over all cores
+    n_single = min(len(samples), 512)       # 2048 edges on one core
+    def edges_for(n):
+        ne = 4 * n
+        return edge_pack(np.zeros(ne, dtype=np.uint64), np.repeat(np.arange(n), 4), np.tile(np.arange(4), n))
+    t0 = time.perf_counter()
+    cpu1 = world.cost_edges(w.root(), w.ribbons4, samples[:, 0], samples[:, 1], samples[:, 2], edges_for(n_single), threads=1)
+    t1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cpu = world.cost_edges(w.root(), w.ribbons4, samples[:, 0], samples[:, 1], samples[:, 2], edges_for(n_multi), threads=cores)
+    tm = time.perf_counter() - t0
+    rep = compare_results(gpu_res[: 4 * n_multi], cpu)
+    return {
+        "cpu_baseline": {"value": 4 * n_multi / tm, "unit": "edges/s", "cores": cores, "kind": "port",
+                         "sample": f"first {4 * n_multi} edges of the same launch, static chunks over {cores} threads; "
+                                   f"single thread on the first {4 * n_single} edges: {4 * n_single / t1:.1f} edges/s",
+                         "single_thread_value": 4 * n_single / t1},
+        "parity": {"ok": rep["ok"], "edges_checked": rep["n"], "flags_equal": rep["flags_equal"], "worst_rel": rep["worst_rel"]},
+    }
+
+
+if __name__ == "__main__":
+    main()

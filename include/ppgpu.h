@@ -180,6 +180,10 @@ int ppgpu_sampler_init(ppgpu_ctx* ctx, const double* bounds6, uint64_t seed,
  * *n_total_out = resulting m_Samples.size(). */
 int ppgpu_sampler_add(ppgpu_ctx* ctx, int64_t n_attempts, int64_t* n_total_out);
 
+/* Advance the generator by n_attempts states without storing them (rank r of a sharded
+ * batch skips the r * batch attempts that belong to lower ranks; SURVEY.md 8 e). */
+int ppgpu_sampler_skip(ppgpu_ctx* ctx, int64_t n_attempts);
+
 /* Replace the sample (target-state) store with caller data; x/y/heading arrays of n. */
 int ppgpu_set_samples(ppgpu_ctx* ctx, int64_t n, const double* h_x, const double* h_y, const double* h_heading);
 /* Copy samples [first, first+n) out as States {x,y,heading,speed,time} (5 doubles each). */
@@ -236,6 +240,10 @@ int64_t ppgpu_dense_edge_count(int32_t nv, int64_t ns, uint32_t cfg_mask);
  * UINT64_MAX/UINT64_MAX when no edge qualifies.  Asynchronous. */
 int ppgpu_best_edge(ppgpu_ctx* ctx, int64_t n, const ppgpu_edge_result* d_results,
                     int32_t goal_only, uint64_t edge_index_base, uint64_t* d_key2);
+
+/* Lexicographic min of n keys {f bits, edge index} resident on the device into d_key2 — the
+ * combine step after an all-gather issued on the caller's own communicator. Asynchronous. */
+int ppgpu_key_min(ppgpu_ctx* ctx, int32_t n, const uint64_t* d_keys, uint64_t* d_key2);
 
 /* Global incumbent across the ranks of one node: lexicographic min of the
  * per-rank keys with one RCCL collective over xGMI.  rccl_comm is an

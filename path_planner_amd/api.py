@@ -36,6 +36,7 @@ def _load():
         "ppgpu_set_vertices": (C.c_int, [vp, i32, vp, i32, vp]),
         "ppgpu_sampler_init": (C.c_int, [vp, vp, u64, i32, vp]),
         "ppgpu_sampler_add": (C.c_int, [vp, i64, C.POINTER(i64)]),
+        "ppgpu_sampler_skip": (C.c_int, [vp, i64]),
         "ppgpu_set_samples": (C.c_int, [vp, i64, vp, vp, vp]),
         "ppgpu_get_samples": (C.c_int, [vp, i64, i64, vp]),
         "ppgpu_num_samples": (i64, [vp]),
@@ -46,6 +47,7 @@ def _load():
         "ppgpu_cost_edges_host": (C.c_int, [vp, i64, vp, vp, vp, i32]),
         "ppgpu_dense_edge_count": (i64, [i32, i64, u32]),
         "ppgpu_best_edge": (C.c_int, [vp, i64, vp, i32, u64, vp]),
+        "ppgpu_key_min": (C.c_int, [vp, i32, vp, vp]),
         "ppgpu_allreduce_best": (C.c_int, [vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
@@ -136,6 +138,9 @@ class Context:
         self._ck(LIB.ppgpu_sampler_add(self._h, int(n_attempts), C.byref(tot)), "ppgpu_sampler_add")
         return tot.value
 
+    def sampler_skip(self, n_attempts):
+        self._ck(LIB.ppgpu_sampler_skip(self._h, int(n_attempts)), "ppgpu_sampler_skip")
+
     def set_samples(self, x, y, heading):
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.ascontiguousarray(y, dtype=np.float64)
@@ -182,3 +187,6 @@ class Context:
 
     def best_edge(self, n, d_results, d_key2, goal_only=False, base=0):
         self._ck(LIB.ppgpu_best_edge(self._h, n, _ptr(d_results), 1 if goal_only else 0, base, _ptr(d_key2)), "ppgpu_best_edge")
+
+    def key_min(self, n, d_keys, d_key2):
+        self._ck(LIB.ppgpu_key_min(self._h, n, _ptr(d_keys), _ptr(d_key2)), "ppgpu_key_min")

@@ -297,6 +297,61 @@ int ppgpu_sampler_init(ppgpu_ctx* c, const double* b6, uint64_t seed, int32_t n_
     return PPGPU_OK;
 }
 
+// Steps 1-3 of the sampler: which stream slots do the next n samples start at?  Leaves qpos[0..n)
+// (relative slots) in c->s_u32a, the projection bits in c->s_bytes and the relative slot of sample n
+// (= where the stream resumes) in *d_end (device).  Without ribbons the layout is fixed (4 slots per sample).
+static int sampler_chain(ppgpu_ctx* c, long long n, long long& nq, int& nblk_q, unsigned long long** d_end) {
+    PPSamplerState& s = c->sampler;
+    hipStream_t st = c->stream;
+    int rc;
+    nq = s.on_ribbons ? (6 * n + 8) : n;   // worst case every sample is projected: 6 slots per sample
+    nblk_q = (int)((nq + PP_SCAN_TILE - 1) / PP_SCAN_TILE);
+    if (nblk_q > PP_SCAN_TILE) return fail(PPGPU_ECAPACITY, "sampler: batch too large for the two-level scan (max ~690k samples per call)");
+    if ((rc = c->s_bytes.reserve((size_t)nq + 64, false, st))) return rc;
+    if ((rc = c->s_u64.reserve((size_t)nblk_q + 64, false, st))) return rc;
+    if ((rc = c->s_u32a.reserve((size_t)nq + 64, false, st))) return rc;
+    if ((rc = c->s_u32b.reserve((size_t)nblk_q + 64, false, st))) return rc;
+    *d_end = c->s_u64.p + nblk_q + 8;
+    HIP_TRY(hipMemsetAsync(c->s_u64.p + nblk_q + 8, 0, 16 * sizeof(unsigned long long), st));
+    if (!s.on_ribbons) return PPGPU_OK;
+    unsigned char* proj = c->s_bytes.p;
+    // 1. proj[q] for every slot in range (thread per slot, LCG jump-ahead)
+    hipLaunchKernelGGL(pp_k_proj_bits, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, s.seed, s.pos, nq, proj);
+    // 2. visited[q]: the chain q -> q + 5 + proj[q] as a scan of 6x6 boolean transition matrices
+    hipLaunchKernelGGL(pp_k_chain_reduce, dim3(nblk_q), dim3(256), 0, st, proj, nq, c->s_u64.p);
+    hipLaunchKernelGGL(pp_k_chain_scan_blocks, dim3(1), dim3(256), 0, st, c->s_u64.p, nblk_q);
+    hipLaunchKernelGGL(pp_k_chain_apply, dim3(nblk_q), dim3(256), 0, st, proj, nq, c->s_u64.p);
+    // 3. rank the visited slots: slot of each sample, and of sample n
+    hipLaunchKernelGGL(pp_k_count_reduce, dim3(nblk_q), dim3(256), 0, st, proj, nq, 2u, c->s_u32b.p);
+    hipLaunchKernelGGL(pp_k_count_scan_blocks, dim3(1), dim3(256), 0, st, c->s_u32b.p, nblk_q);
+    hipLaunchKernelGGL(pp_k_chain_positions, dim3(nblk_q), dim3(256), 0, st, proj, nq, c->s_u32b.p, n, c->s_u32a.p, *d_end);
+    HIP_TRY(hipGetLastError());
+    return PPGPU_OK;
+}
+
+int ppgpu_sampler_skip(ppgpu_ctx* c, int64_t n_attempts) {
+    int rc = require_cfg(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->sampler.initialised) return fail(PPGPU_ESTATE, "ppgpu_sampler_init must be called first");
+    if (n_attempts < 0) return fail(PPGPU_EINVAL, "sampler: negative count");
+    PPSamplerState& s = c->sampler;
+    long long left = n_attempts;
+    while (left > 0) {
+        long long n = left < 524288 ? left : 524288;
+        if (!s.on_ribbons) { s.pos += 4ull * (unsigned long long)n; left -= n; continue; }
+        long long nq; int nblk_q; unsigned long long* d_end;
+        if ((rc = sampler_chain(c, n, nq, nblk_q, &d_end))) return rc;
+        unsigned long long rel = 0;
+        HIP_TRY(hipMemcpyAsync(&rel, d_end, sizeof(rel), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (rel == 0) return fail(PPGPU_EHIP, "sampler: chain scan did not reach the end of the batch");
+        s.pos += rel;
+        left -= n;
+    }
+    return PPGPU_OK;
+}
+
 int ppgpu_sampler_add(ppgpu_ctx* c, int64_t n_attempts, int64_t* n_total_out) {
     int rc = require_cfg(c);
     if (rc) return rc;
@@ -304,44 +359,21 @@ int ppgpu_sampler_add(ppgpu_ctx* c, int64_t n_attempts, int64_t* n_total_out) {
     if (!c->sampler.initialised) return fail(PPGPU_ESTATE, "ppgpu_sampler_init must be called first");
     if (n_attempts < 0) return fail(PPGPU_EINVAL, "sampler: negative count");
     if (n_attempts == 0) { if (n_total_out) *n_total_out = c->n_samples; return PPGPU_OK; }
-    if (n_attempts > (1ll << 26)) return fail(PPGPU_ECAPACITY, "sampler: at most 2^26 attempts per call");
+    if (n_attempts > 524288) return fail(PPGPU_ECAPACITY, "sampler: at most 524288 attempts per call");
     const long long n = n_attempts;
     PPSamplerState& s = c->sampler;
     hipStream_t st = c->stream;
-    // worst case every sample is projected: 6 pair-slots per sample
-    const long long nq = s.on_ribbons ? (6 * n + 8) : n;
     size_t need_samples = (size_t)(c->n_samples + n);
     if ((rc = c->sx.reserve(need_samples, true, st)) || (rc = c->sy.reserve(need_samples, true, st)) ||
         (rc = c->sh.reserve(need_samples, true, st)))
         return rc;
     if ((rc = c->s_cand.reserve((size_t)n * 3, false, st))) return rc;
-    if ((rc = c->s_bytes.reserve((size_t)(nq > n ? nq : n) + 64, false, st))) return rc;
-    const int nblk_q = (int)((nq + PP_SCAN_TILE - 1) / PP_SCAN_TILE);
+    long long nq; int nblk_q; unsigned long long* d_end;
+    if ((rc = sampler_chain(c, n, nq, nblk_q, &d_end))) return rc;
     const int nblk_n = (int)((n + PP_SCAN_TILE - 1) / PP_SCAN_TILE);
-    if ((rc = c->s_u64.reserve((size_t)nblk_q + 64, false, st))) return rc;
-    if ((rc = c->s_u32a.reserve((size_t)(nq > n ? nq : n) + 64, false, st))) return rc;
-    if ((rc = c->s_u32b.reserve((size_t)(nblk_q > nblk_n ? nblk_q : nblk_n) + 64, false, st))) return rc;
-    if (nblk_q > PP_SCAN_TILE || nblk_n > PP_SCAN_TILE) return fail(PPGPU_ECAPACITY, "sampler: batch too large for the two-level scan");
-
-    unsigned char* proj = c->s_bytes.p;           // per pair-slot: would a sample starting here be projected?
-    unsigned* qpos = c->s_u32a.p;                 // pair-slot of sample i (compacted)
+    unsigned char* proj = c->s_bytes.p;
+    unsigned* qpos = c->s_u32a.p;
     unsigned* blk32 = c->s_u32b.p;
-    unsigned long long* blk64 = c->s_u64.p;
-    long long end_pos_host = 0;
-    HIP_TRY(hipMemsetAsync(c->s_u64.p + nblk_q + 8, 0, 16 * sizeof(unsigned long long), st));
-
-    if (s.on_ribbons) {
-        // 1. proj[q] for every even stream offset 2q in range (thread per q, LCG jump-ahead)
-        hipLaunchKernelGGL(pp_k_proj_bits, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, s.seed, s.pos, nq, proj);
-        // 2. visited[q]: the chain q -> q + 5 + proj[q] as a scan of 6x6 boolean transition matrices
-        hipLaunchKernelGGL(pp_k_chain_reduce, dim3(nblk_q), dim3(256), 0, st, proj, nq, blk64);
-        hipLaunchKernelGGL(pp_k_chain_scan_blocks, dim3(1), dim3(256), 0, st, blk64, nblk_q);
-        hipLaunchKernelGGL(pp_k_chain_apply, dim3(nblk_q), dim3(256), 0, st, proj, nq, blk64);   // proj[q] |= visited << 1
-        // 3. rank the visited slots: sample index of each, and slot of each sample
-        hipLaunchKernelGGL(pp_k_count_reduce, dim3(nblk_q), dim3(256), 0, st, proj, nq, 2, blk32);
-        hipLaunchKernelGGL(pp_k_count_scan_blocks, dim3(1), dim3(256), 0, st, blk32, nblk_q);
-        hipLaunchKernelGGL(pp_k_chain_positions, dim3(nblk_q), dim3(256), 0, st, proj, nq, blk32, n, qpos, c->s_u64.p + nblk_q + 8);
-    }
     // 4. generate the n candidate states (thread per sample)
     hipLaunchKernelGGL(pp_k_generate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, s.on_ribbons ? qpos : nullptr,
                        s.on_ribbons ? proj : nullptr, c->samp_ribbons.p, n, c->s_cand.p);
@@ -349,20 +381,18 @@ int ppgpu_sampler_add(ppgpu_ctx* c, int64_t n_attempts, int64_t* n_total_out) {
     PPGrid g{c->grid.p, c->rows, c->cols, c->wpr, c->res};
     unsigned char* keep = proj;  // the projection bits are no longer needed once the candidates exist
     hipLaunchKernelGGL(pp_k_keep_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, c->s_cand.p, n, keep);
-    hipLaunchKernelGGL(pp_k_count_reduce, dim3(nblk_n), dim3(256), 0, st, keep, n, 1, blk32);
+    hipLaunchKernelGGL(pp_k_count_reduce, dim3(nblk_n), dim3(256), 0, st, keep, n, 1u, blk32);
     hipLaunchKernelGGL(pp_k_count_scan_blocks, dim3(1), dim3(256), 0, st, blk32, nblk_n);
-    unsigned long long* d_total = c->s_u64.p + nblk_q + 16;
+    unsigned long long* d_total = d_end + 8;
     hipLaunchKernelGGL(pp_k_compact_samples, dim3(nblk_n), dim3(256), 0, st, keep, n, blk32, c->s_cand.p, c->sx.p, c->sy.p,
                        c->sh.p, c->n_samples, d_total);
     HIP_TRY(hipGetLastError());
     unsigned long long h2[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(&h2[0], d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    if (s.on_ribbons)
-        HIP_TRY(hipMemcpyAsync(&h2[1], c->s_u64.p + nblk_q + 8, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&h2[1], d_end, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (s.on_ribbons && h2[1] == 0) return fail(PPGPU_EHIP, "sampler: chain scan did not reach the end of the batch");
-    end_pos_host = s.on_ribbons ? (long long)(s.pos + h2[1]) : (long long)(s.pos + n * 4);
-    s.pos = (unsigned long long)end_pos_host;   // pair-slots consumed so far (2 engine calls each)
+    s.pos = s.on_ribbons ? (s.pos + h2[1]) : (s.pos + 4ull * (unsigned long long)n);   // slots consumed so far
     c->n_samples += (long long)h2[0];
     if (n_total_out) *n_total_out = c->n_samples;
     return PPGPU_OK;
@@ -510,6 +540,16 @@ int ppgpu_best_edge(ppgpu_ctx* c, int64_t n, const ppgpu_edge_result* d_results,
     hipLaunchKernelGGL(pp_k_best_stage1, dim3(nparts), dim3(256), 0, c->stream, d_results, (long long)n, goal_only,
                        (unsigned long long)base, c->partial.p);
     hipLaunchKernelGGL(pp_k_best_stage2, dim3(1), dim3(256), 0, c->stream, c->partial.p, nparts, (unsigned long long*)d_key2);
+    HIP_TRY(hipGetLastError());
+    return PPGPU_OK;
+}
+
+// Lexicographic min of n (f bits, index) pairs already resident on the device (e.g. the output of an
+// all-gather issued by the caller's own communicator).
+int ppgpu_key_min(ppgpu_ctx* c, int32_t n, const uint64_t* d_keys, uint64_t* d_key2) {
+    if (!c || !d_keys || !d_key2 || n <= 0) return fail(PPGPU_EINVAL, "key_min: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(pp_k_key_min_n, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)d_keys, n, (unsigned long long*)d_key2);
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;
 }

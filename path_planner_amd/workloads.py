@@ -53,13 +53,20 @@ def blob_grid(n, res, frac, seed, start_xy, keep_free_radius=10.0, blob=32):
     return g
 
 
-def obstacles(n, seed, extent, time=1.0, width=10.0, length=30.0, max_speed=3.0):
-    """n rows {x, y, heading, speed, time, width, length} (BinaryDynamicObstaclesManager::update arguments)."""
+def obstacles(n, seed, extent, time=1.0, width=10.0, length=30.0, max_speed=3.0, keep_free=None):
+    """n rows {x, y, heading, speed, time, width, length} (BinaryDynamicObstaclesManager::update arguments).
+    keep_free = (x, y, radius): redraw an obstacle whose centre starts closer than radius to (x, y), so that the
+    vehicle does not begin the plan inside a box."""
     rng = SplitMix64(seed)
     o = np.zeros((n, 7), dtype=np.float64)
-    for i in range(n):
-        o[i] = [rng.uniform(0, extent), rng.uniform(0, extent), rng.uniform(0, 2 * math.pi), rng.uniform(0, max_speed),
-                time, width, length]
+    i = 0
+    while i < n:
+        row = [rng.uniform(0, extent), rng.uniform(0, extent), rng.uniform(0, 2 * math.pi), rng.uniform(0, max_speed),
+               time, width, length]
+        if keep_free is not None and math.hypot(row[0] - keep_free[0], row[1] - keep_free[1]) < keep_free[2]:
+            continue
+        o[i] = row
+        i += 1
     return o
 
 
@@ -121,7 +128,7 @@ def config3(n_samples=65536, n_obst=16):
     ext = 2048 * 0.1
     c = ext / 2
     grid = blob_grid(2048, 0.1, 0.10, 2, (c, c))
-    obst = obstacles(n_obst, 3, ext) if n_obst else None
+    obst = obstacles(n_obst, 3, ext, keep_free=(c, c, 40.0)) if n_obst else None
     rib = [[c - 20, c + 12 + 8 * i, c + 20, c + 12 + 8 * i] for i in range(5)]
     return Workload("cfg3_2048_10pct_65536_obst%d" % n_obst, grid, 0.1, obst, rib, [c, c, 0, 2.5, 1], n_samples, 7, cfg,
                     n_vertices=64)
