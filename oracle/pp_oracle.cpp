@@ -756,6 +756,7 @@ double computeTrueCost(const Vertex& start, Vertex& end, const Config& config) {
     double toCoverDistance = 0;
     double lastHeading = start.state.heading;
     end.steps = 0;
+    end.events = end.mutations = 0;
 
     if (intermediate.time >= endTime) end.infeasible = true;  // :102-110
 
@@ -782,8 +783,15 @@ double computeTrueCost(const Vertex& start, Vertex& end, const Config& config) {
             toCoverDistance -= config.collisionCheckingIncrement;
         } else {
             toCoverDistance = end.ribbons.minDistanceFrom(intermediate.x, intermediate.y);
+            end.events++;
             if (end.coverageAllowed || lastHeading == intermediate.heading) {
+                auto before = end.ribbons.ribbons;
                 end.ribbons.cover(intermediate.x, intermediate.y, true);
+                bool same = before.size() == end.ribbons.ribbons.size();
+                for (size_t q = 0; same && q < before.size(); q++)
+                    same = before[q].sx == end.ribbons.ribbons[q].sx && before[q].sy == end.ribbons.ribbons[q].sy &&
+                           before[q].ex == end.ribbons.ribbons[q].ex && before[q].ey == end.ribbons.ribbons[q].ey;
+                if (!same) end.mutations++;
             }
             if (end.ribbons.done()) {
                 if (end.ribbons.coverageCompletedTime == -1) end.ribbons.setCoverageCompletedTime(intermediate.time);

@@ -170,6 +170,7 @@ struct Vertex {
     bool threw = false;              // computeTrueCost would have thrown
     double edgeApproxCost = -1, edgeTrueCost = -1, collisionPenalty = 0;
     int steps = 0;                   // sweep iterations executed (diagnostic)
+    int events = 0, mutations = 0;   // coverage events / events that changed the ribbon list (diagnostic)
     double f() const { return currentCost + approxToGo; }
     int depth(const std::vector<Vertex>& arena) const;
 };

@@ -291,6 +291,7 @@ long ppo_add_samples(void* w, const double* b6, uint64_t seed, int n_ribbons, co
 }
 
 // ------------------------------------------------------------------ edges
+static thread_local int g_last_events = 0, g_last_mutations = 0;
 static void cost_one(const World& W, const Config& cfg, const ppgpu_vertex* verts, const double* pool,
                      const double* sx, const double* sy, const double* sh, uint64_t desc, ppgpu_edge_result* out,
                      double* child, int stride) {
@@ -314,6 +315,7 @@ static void cost_one(const World& W, const Config& cfg, const ppgpu_vertex* vert
     } catch (SampleError&) {
         threw = true;
     }
+    g_last_events = end.events; g_last_mutations = end.mutations;
     uint32_t flags = 0;
     if (end.infeasible) flags |= PPGPU_F_INFEASIBLE;
     if (threw) flags |= PPGPU_F_THROWS | PPGPU_F_INFEASIBLE;
@@ -463,6 +465,18 @@ int ppo_plan(void* w, int n_ribbons, const double* ribbons4, double cct, const d
     for (int i = 0; i < (int)s.iterationBestF.size() && i < iter_cap; i++) iter_best_f[i] = s.iterationBestF[i];
     if (n_edges_out) *n_edges_out = ne;
     return 0;
+}
+
+// diagnostic: coverage events / ribbon-list mutations per edge (single-threaded)
+void ppo_edge_event_stats(void* w, const ppgpu_vertex* verts, const double* pool, const double* sx, const double* sy,
+                          const double* sh, long n, const uint64_t* edges, int* stats2) {
+    World* W = (World*)w;
+    Config cfg = make_config(*W);
+    ppgpu_edge_result r;
+    for (long e = 0; e < n; e++) {
+        cost_one(*W, cfg, verts, pool, sx, sy, sh, edges[e], &r, nullptr, 0);
+        stats2[2 * e] = g_last_events; stats2[2 * e + 1] = g_last_mutations;
+    }
 }
 
 int ppo_hardware_threads() { return (int)std::thread::hardware_concurrency(); }

@@ -10,7 +10,7 @@ import numpy as np
 from .types import PpgpuConfig, RESULT_DTYPE, VERTEX_DTYPE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libppgpu.so")
+LIB_PATH = os.environ.get("PPGPU_LIB_OVERRIDE") or os.path.join(_HERE, "csrc", "libppgpu.so")   # override: tools/ablate.py only
 
 
 class PpgpuError(RuntimeError):

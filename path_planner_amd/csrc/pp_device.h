@@ -276,23 +276,53 @@ __device__ __forceinline__ bool pp_is_blocked(const PPGrid& g, double x, double 
 // ----------------------------------------------------------------------------- dynamic obstacles
 // BinaryDynamicObstaclesManager::Obstacle with the per-call constants hoisted on the HOST with
 // the host libm (ppgpu_set_obstacles): cosYaw/sinYaw = cos/sin(M_PI_2 - heading), halfL/halfW =
-// (Length + 2) / 2, (Width + 2) / 2 for the strict test used by Edge::computeTrueCost (Edge.cpp:151).
-struct PPObst { double X, Y, cosYaw, sinYaw, Speed, Time, halfL, halfW; };
+// (Length + 2) / 2, (Width + 2) / 2 for the strict test used by Edge::computeTrueCost (Edge.cpp:151);
+// reach = sqrt(halfL^2 + halfW^2) rounded up: no point farther than that from the centre can hit.
+struct PPObst { double X, Y, cosYaw, sinYaw, Speed, Time, halfL, halfW, reach, pad; };
 
-// BinaryDynamicObstaclesManager::collisionExists(x, y, t, strict=true)  (.cpp:4-22)
-__device__ __forceinline__ int pp_obstacle_hits(const PPObst* __restrict__ ob, int n, double x, double y, double t) {
+// One obstacle's contribution to BinaryDynamicObstaclesManager::collisionExists(x, y, t, strict=true)
+// (.cpp:4-22): project to t, translate, rotate by +Yaw, strict box test.
+__device__ __forceinline__ int pp_obstacle_hit(const PPObst& o, double x, double y, double t) {
+    double dt = t - o.Time;
+    double ddx = o.Speed * dt * o.cosYaw;
+    double ddy = o.Speed * dt * o.sinYaw;
+    double X = o.X + ddx;
+    double Y = o.Y + ddy;
+    double tx = x - X;
+    double ty = y - Y;
+    double rx = tx * o.cosYaw - ty * o.sinYaw;
+    double ry = tx * o.sinYaw + ty * o.cosYaw;
+    return (fabs(rx) < o.halfL && fabs(ry) < o.halfW) ? 1 : 0;
+}
+
+// Hit count for this lane's step, for 64 consecutive steps held one per lane.
+// Culling (exact): lane i first tests obstacle i against the whole chunk — every valid lane's pose lies
+// within `span` of lane 0's pose (c0x, c0y at time t0) and every obstacle moves at most |Speed|*tspan
+// during the chunk, so an obstacle farther than reach + span + |Speed|*tspan (+ slack) from lane 0's pose
+// at t0 cannot hit any lane.  Only the survivors (usually none or one) get the exact test.
+__device__ inline int pp_obstacle_hits_chunk(const PPObst* __restrict__ ob, int n, double x, double y, double t, bool valid,
+                                             double c0x, double c0y, double t0, double span, double tspan) {
     int sum = 0;
-    for (int i = 0; i < n; i++) {
-        double dt = t - ob[i].Time;
-        double ddx = ob[i].Speed * dt * ob[i].cosYaw;
-        double ddy = ob[i].Speed * dt * ob[i].sinYaw;
-        double X = ob[i].X + ddx;
-        double Y = ob[i].Y + ddy;
-        double tx = x - X;
-        double ty = y - Y;
-        double rx = tx * ob[i].cosYaw - ty * ob[i].sinYaw;
-        double ry = tx * ob[i].sinYaw + ty * ob[i].cosYaw;
-        if (fabs(rx) < ob[i].halfL && fabs(ry) < ob[i].halfW) sum++;
+    const int lane = pp_lane();
+    for (int b = 0; b < n; b += PP_WAVE) {
+        const int oi = b + lane;
+        bool near = false;
+        if (oi < n) {
+            const PPObst o = ob[oi];
+            double dt = t0 - o.Time;
+            double X = o.X + o.Speed * dt * o.cosYaw;
+            double Y = o.Y + o.Speed * dt * o.sinYaw;
+            double R = o.reach + span + fabs(o.Speed) * tspan + 1e-3;
+            double dx = c0x - X, dy = c0y - Y;
+            near = !(dx * dx + dy * dy > R * R);
+        }
+        unsigned long long m = __ballot(near);
+        while (m) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const PPObst& o = ob[b + j];       // wave-uniform address: scalar load
+            if (valid) sum += pp_obstacle_hit(o, x, y, t);
+        }
     }
     return sum;
 }
@@ -328,39 +358,42 @@ __device__ __forceinline__ double pp_ribbon_line_distance(const PPRibbon& r, dou
     return (fabs((r.ey - r.sy) * x - (r.ex - r.sx) * y + r.ex * r.sy - r.ey * r.sx)) / sqrt(pp_sq_len(r.sx, r.sy, r.ex, r.ey));
 }
 
-// RibbonManager::minDistanceFrom (RibbonManager.cpp:142-152): lane i holds ribbon i (i < n).
-__device__ inline double pp_ribbons_min_distance(const PPRibbon& r, int n, double w, double x, double y) {
+// One coverage event of Edge::computeTrueCost (Edge.cpp:158-161), lane i holding ribbon i (i < n):
+//   D = RibbonManager::minDistanceFrom(x, y)                    (RibbonManager.cpp:142-152)
+//   if (doCover) RibbonManager::cover(x, y, strict = true)      (RibbonManager.cpp:14-22, Ribbon::split
+//                                                                Ribbon.cpp:9-17, Ribbon::covered :23-25)
+// Both need the same projection and perpendicular distance per ribbon; they are computed once.
+// cover() preserves list order: old ribbon i contributes [front part, if split and not covered] then
+// [itself / the remainder, if not covered].  lds = this wave's 64 x 4-double scratch.
+// Returns the new ribbon count (may exceed 64 -> the caller flags overflow).
+__device__ inline int pp_ribbons_event(PPRibbon& r, int n, double w, double x, double y, bool doCover, double* lds, double& D) {
+    D = 0;
     if (n == 0) return 0;
-    bool act = pp_lane() < n;
-    bool contains = false;
-    double m = PP_DBL_MAX;
+    const int lane = pp_lane();
+    const bool act = lane < n;
+    double px = 0, py = 0, ld = 0;
+    bool cp = false;
     if (act) {
-        double px, py;
         pp_ribbon_projection(r, x, y, px, py);
-        contains = pp_ribbon_contains_projection(r, px, py) && (pp_ribbon_line_distance(r, x, y) < w);
-        double dStart = pp_dist(r.sx, r.sy, x, y);
-        double dEnd = pp_dist(r.ex, r.ey, x, y);
-        m = fmin(fmin(m, dEnd), dStart);
+        cp = pp_ribbon_contains_projection(r, px, py);
+        ld = pp_ribbon_line_distance(r, x, y);
     }
-    if (__ballot(contains) != 0ull) return 0;
-    return pp_wave_min(m);
-}
-
-// RibbonManager::cover(x, y, strict=true) (RibbonManager.cpp:14-22 with Ribbon::split, Ribbon.cpp:9-17,
-// and Ribbon::covered, Ribbon.cpp:23-25).  The list order is preserved: each old ribbon i contributes
-// [front part, if it was split and the front is not covered] then [itself/remainder, if not covered].
-// lds = this wave's 64 x 4-double scratch.  Returns the new count (may exceed 64 -> caller flags overflow).
-__device__ inline int pp_ribbons_cover(PPRibbon& r, int n, double w, double x, double y, double* lds) {
-    if (n == 0) return 0;
-    int lane = pp_lane();
-    bool act = lane < n;
+    // minDistanceFrom: 0 as soon as one ribbon contains the point (non-strict width), else nearest endpoint
+    if (__ballot(act && cp && (ld < w)) == 0ull) {
+        double m = PP_DBL_MAX;
+        if (act) {
+            double dStart = pp_dist(r.sx, r.sy, x, y);
+            double dEnd = pp_dist(r.ex, r.ey, x, y);
+            m = fmin(fmin(m, dEnd), dStart);
+        }
+        D = pp_wave_min(m);
+    }
+    if (!doCover) return n;
     const double minLength = 2 * w;                                  // Ribbon::minLength (Ribbon.cpp:52-58)
     const double thr = minLength * minLength / (2.0 * 2.0);          // covered(strict): c_StrictModifier^2
     bool split = false, keepF = false, keepR = false;
-    double px = 0, py = 0;
     if (act) {
-        pp_ribbon_projection(r, x, y, px, py);
-        split = pp_ribbon_contains_projection(r, px, py) && (pp_ribbon_line_distance(r, x, y) < (w / 2.0));
+        split = cp && (ld < (w / 2.0));                              // Ribbon::contains(strict) (Ribbon.cpp:39-43)
         if (split) {
             keepF = !(pp_sq_len(r.sx, r.sy, px, py) < thr);
             keepR = !(pp_sq_len(px, py, r.ex, r.ey) < thr);
@@ -368,13 +401,17 @@ __device__ inline int pp_ribbons_cover(PPRibbon& r, int n, double w, double x, d
             keepR = !(pp_sq_len(r.sx, r.sy, r.ex, r.ey) < thr);
         }
     }
-    unsigned long long mS = __ballot(split), mF = __ballot(keepF), mR = __ballot(keepR);
-    unsigned long long actMask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-    if (mS == 0ull && mR == actMask) return n;  // nothing split, nothing erased
-    unsigned long long below = (1ull << lane) - 1ull;
-    int posF = __popcll(mF & below) + __popcll(mR & below);
-    int posR = posF + (keepF ? 1 : 0);
-    int total = __popcll(mF) + __popcll(mR);
+    const unsigned long long mS = __ballot(split), mF = __ballot(keepF), mR = __ballot(keepR);
+    const unsigned long long actMask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    if (mS == 0ull && mR == actMask) return n;                       // nothing split, nothing erased
+    if (mF == 0ull && mR == actMask) {                               // splits whose fronts all vanish: starts move, order kept
+        if (split) { r.sx = px; r.sy = py; }
+        return n;
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int posF = __popcll(mF & below) + __popcll(mR & below);
+    const int posR = posF + (keepF ? 1 : 0);
+    const int total = __popcll(mF) + __popcll(mR);
     if (keepF && posF < 64) { lds[posF * 4 + 0] = r.sx; lds[posF * 4 + 1] = r.sy; lds[posF * 4 + 2] = px; lds[posF * 4 + 3] = py; }
     if (keepR && posR < 64) {
         lds[posR * 4 + 0] = split ? px : r.sx; lds[posR * 4 + 1] = split ? py : r.sy;
@@ -387,16 +424,17 @@ __device__ inline int pp_ribbons_cover(PPRibbon& r, int n, double w, double x, d
 }
 
 // ----------------------------------------------------------------------------- heuristics
-#define PP_TSP_MAX 8   // device limit on ribbons for the brute-force TSP heuristics
+#define PP_TSP_MAX 8      // device limit on ribbons for the brute-force TSP heuristics
+#define PP_RIB_LDS 5      // doubles per ribbon in the heuristic's LDS image: sx, sy, ex, ey, length
 
-// RibbonManager::maxDistance (RibbonManager.cpp:234-248); ribbons in lds (n of them, 4 doubles each)
+// RibbonManager::maxDistance (RibbonManager.cpp:234-248); ribbons in lds (n of them)
 __device__ inline double pp_h_max_distance(const double* lds, int n, double w, double x, double y) {
     double sumLength = 0, mn = PP_DBL_MAX, mx = 0;
     for (int i = 0; i < n; i++) {
-        double sx = lds[i * 4], sy = lds[i * 4 + 1], ex = lds[i * 4 + 2], ey = lds[i * 4 + 3];
-        sumLength += sqrt(pp_sq_len(sx, sy, ex, ey)) - 2 * w;
-        double dStart = pp_dist(sx, sy, x, y);
-        double dEnd = pp_dist(ex, ey, x, y);
+        const double* rb = lds + PP_RIB_LDS * i;
+        sumLength += rb[4] - 2 * w;
+        double dStart = pp_dist(rb[0], rb[1], x, y);
+        double dEnd = pp_dist(rb[2], rb[3], x, y);
         mn = fmin(fmin(mn, dEnd), dStart);
         mx = fmax(fmax(mx, dEnd), dStart);
     }
@@ -408,111 +446,118 @@ __device__ inline double pp_h_max_distance(const double* lds, int n, double w, d
 // The reference is a depth-first enumeration: at each level it (K variant only) stable-sorts the
 // remaining ribbons by DESCENDING nearest-endpoint distance from the current point
 // (list::sort with comp = min1 > min2), branches on the first min(K, n) of them in both
-// directions, and takes the min of the leaves' accumulated distance
+// directions, and returns the min over leaves of the accumulated
 //   soFar' = fmax(soFar + len - 2w + dist(point, entry endpoint), 0).
-// Here the leaves are numbered in that same depth-first order (level 0 = most significant digit);
-// each lane walks a contiguous range of leaves like an odometer, re-deriving only the levels whose
-// digit changed, and the wave min-reduces.  fmin/fmax are exact, so the result is bit-identical
-// to the sequential recursion.
-__device__ inline double pp_h_tsp_point(const double* lds, int n, double w, int K, bool sortK, double x0, double y0) {
-    if (n == 0) return 0;
-    const int lane = pp_lane();
-    // branching per level and leaf count
-    unsigned long long total = 1;
-    int bl[PP_TSP_MAX];
-#pragma unroll
-    for (int l = 0; l < PP_TSP_MAX; l++) {
-        int rem = n - l;
-        int c = rem < K ? rem : K;
-        bl[l] = (l < n) ? 2 * c : 1;
-        if (l < n) total *= (unsigned long long)bl[l];
-    }
-    if (total == 0) return PP_DBL_MAX;  // K <= 0: the reference's loop never runs and returns DBL_MAX
-    unsigned long long lo = total * (unsigned long long)lane / 64ull;
-    unsigned long long hi = total * (unsigned long long)(lane + 1) / 64ull;
+// fmin/fmax are exact, so any evaluation order gives the same bits.  Here the first Ls levels
+// (the "prefix", chosen so that there are >= 64 prefixes when the tree is that large) are spread
+// over the lanes — every lane walks ITS prefix with the same control flow, only the digits differ —
+// and the remaining levels are enumerated by one wave-uniform odometer, so that no lane ever waits
+// for another lane's branch.  Each tree node is sorted once.
+struct PPTspNode { double px, py, sf; unsigned ord; };
 
-    double px[PP_TSP_MAX + 1], py[PP_TSP_MAX + 1], sf[PP_TSP_MAX + 1];
-    unsigned ord[PP_TSP_MAX + 1];   // remaining ribbons in list order entering level l, 4 bits each
-    unsigned srt[PP_TSP_MAX];       // the order the level branches on
-    int dig[PP_TSP_MAX];
-    px[0] = x0; py[0] = y0; sf[0] = 0;
-    ord[0] = 0x76543210u;
+__device__ __forceinline__ unsigned pp_tsp_sort(const double* lds, unsigned ord, int rem, double px, double py) {
+    double key[PP_TSP_MAX];
+    unsigned id[PP_TSP_MAX];
 #pragma unroll
-    for (int l = 0; l < PP_TSP_MAX; l++) { dig[l] = -1; srt[l] = 0; }
-
-    double best = PP_DBL_MAX;
-    const double twoW = 2 * w;
-    for (unsigned long long leaf = lo; leaf < hi; leaf++) {
-        // digits of this leaf, most significant = level 0
-        int nd[PP_TSP_MAX];
-        unsigned long long rest = leaf;
-#pragma unroll
-        for (int l = PP_TSP_MAX - 1; l >= 0; l--) {
-            if (l < n) { nd[l] = (int)(rest % (unsigned long long)bl[l]); rest /= (unsigned long long)bl[l]; }
-            else nd[l] = 0;
+    for (int i = 0; i < PP_TSP_MAX; i++) {
+        id[i] = (ord >> (4 * i)) & 0xfu;
+        key[i] = 0;
+        if (i < rem) {
+            const double* rb = lds + PP_RIB_LDS * id[i];
+            key[i] = fmin(pp_dist(px, py, rb[0], rb[1]), pp_dist(px, py, rb[2], rb[3]));
         }
-        bool changedAbove = false;  // some digit above this level changed -> this level's node is new
+    }
+    // stable insertion sort, descending key: an element moves left only past strictly smaller keys
 #pragma unroll
-        for (int l = 0; l < PP_TSP_MAX; l++) {
-            if (l < n) {
-                bool nodeNew = changedAbove || (dig[l] < 0);
-                if (nodeNew) {
-                    // (re)build the branching order of this node
-                    unsigned o = ord[l];
-                    if (sortK) {
-                        const int rem = n - l;
-                        double key[PP_TSP_MAX];
-                        unsigned id[PP_TSP_MAX];
+    for (int i = 1; i < PP_TSP_MAX; i++) {
+        if (i < rem) {
 #pragma unroll
-                        for (int i = 0; i < PP_TSP_MAX; i++) {
-                            id[i] = (o >> (4 * i)) & 0xfu;
-                            key[i] = 0;
-                            if (i < rem) {
-                                const double* rb = lds + 4 * id[i];
-                                key[i] = fmin(pp_dist(px[l], py[l], rb[0], rb[1]), pp_dist(px[l], py[l], rb[2], rb[3]));
-                            }
-                        }
-                        // stable insertion sort, descending key (comp(a,b) = key_a > key_b)
-#pragma unroll
-                        for (int i = 1; i < PP_TSP_MAX; i++) {
-#pragma unroll
-                            for (int j = i; j >= 1; j--) {
-                                if (i < rem && key[j] > key[j - 1]) {
-                                    double tk = key[j]; key[j] = key[j - 1]; key[j - 1] = tk;
-                                    unsigned ti = id[j]; id[j] = id[j - 1]; id[j - 1] = ti;
-                                }
-                            }
-                        }
-                        o = 0;
-#pragma unroll
-                        for (int i = 0; i < PP_TSP_MAX; i++) o |= (id[i] & 0xfu) << (4 * i);
-                    }
-                    srt[l] = o;
-                }
-                if (nodeNew || nd[l] != dig[l]) {
-                    int c = nd[l] >> 1, dir = nd[l] & 1;
-                    unsigned rid = (srt[l] >> (4 * c)) & 0xfu;
-                    const double* rb = lds + 4 * rid;
-                    double rsx = rb[0], rsy = rb[1], rex = rb[2], rey = rb[3];
-                    double len = sqrt(pp_sq_len(rsx, rsy, rex, rey));
-                    double dd = dir == 0 ? pp_dist(px[l], py[l], rsx, rsy) : pp_dist(px[l], py[l], rex, rey);
-                    sf[l + 1] = fmax(sf[l] + len - twoW + dd, 0);
-                    px[l + 1] = dir == 0 ? rex : rsx;
-                    py[l + 1] = dir == 0 ? rey : rsy;
-                    // remove position c from the branching order
-                    unsigned lowmask = (c == 0) ? 0u : ((1u << (4 * c)) - 1u);
-                    unsigned s = srt[l];
-                    ord[l + 1] = (s & lowmask) | ((s >> 4) & ~lowmask);
-                    changedAbove = true;
-                    dig[l] = nd[l];
+            for (int j = i; j >= 1; j--) {
+                if (key[j] > key[j - 1]) {
+                    double tk = key[j]; key[j] = key[j - 1]; key[j - 1] = tk;
+                    unsigned ti = id[j]; id[j] = id[j - 1]; id[j - 1] = ti;
                 }
             }
         }
-        // sf[n] with n wave-uniform: select statically
-        double v = sf[0];
+    }
+    unsigned o = 0;
 #pragma unroll
-        for (int l = 1; l <= PP_TSP_MAX; l++) if (l == n) v = sf[l];
-        best = fmin(best, v);
+    for (int i = 0; i < PP_TSP_MAX; i++) o |= (id[i] & 0xfu) << (4 * i);
+    return o;
+}
+
+// take branch `digit` (ribbon position digit>>1 of `srt`, direction digit&1) from node `a`
+__device__ __forceinline__ PPTspNode pp_tsp_child(const double* lds, const PPTspNode& a, unsigned srt, int digit, double twoW) {
+    const int c = digit >> 1, dir = digit & 1;
+    const unsigned rid = (srt >> (4 * c)) & 0xfu;
+    const double* rb = lds + PP_RIB_LDS * rid;
+    const double rsx = rb[0], rsy = rb[1], rex = rb[2], rey = rb[3], len = rb[4];
+    const double dd = dir == 0 ? pp_dist(a.px, a.py, rsx, rsy) : pp_dist(a.px, a.py, rex, rey);
+    PPTspNode b;
+    b.sf = fmax(a.sf + len - twoW + dd, 0);
+    b.px = dir == 0 ? rex : rsx;
+    b.py = dir == 0 ? rey : rsy;
+    const unsigned lowmask = (c == 0) ? 0u : ((1u << (4 * c)) - 1u);
+    b.ord = (srt & lowmask) | ((srt >> 4) & ~lowmask);
+    return b;
+}
+
+__device__ inline double pp_h_tsp_point(const double* lds, int n, double w, int K, bool sortK, double x0, double y0) {
+    if (n == 0) return 0;
+    if (K <= 0) return PP_DBL_MAX;   // the reference's loop body never runs and it returns DBL_MAX
+    const int lane = pp_lane();
+    const double twoW = 2 * w;
+    // prefix depth Ls: deep enough for >= 64 prefixes when the tree has them, and never leaving more than
+    // two suffix levels (those are enumerated by wave-uniform loops below).  All of this is wave-uniform.
+    int Ls = 0;
+    unsigned NP = 1;
+    for (int l = 0; l < n; l++) {
+        const int rem = n - l;
+        if (NP >= 64u && l >= n - 2) break;
+        NP *= (unsigned)(2 * (rem < K ? rem : K));
+        Ls = l + 1;
+    }
+    const int nsuf = n - Ls;         // 0, 1 or 2
+    double best = PP_DBL_MAX;
+    for (unsigned pbase = 0; pbase < NP; pbase += 64u) {
+        const unsigned pid = pbase + (unsigned)lane;
+        const bool act = pid < NP;
+        unsigned rest = act ? pid : 0u;
+        unsigned stride = NP;
+        PPTspNode a;
+        a.px = x0; a.py = y0; a.sf = 0; a.ord = 0x76543210u;
+        for (int l = 0; l < Ls; l++) {                      // this lane's prefix, level 0 = most significant digit
+            const int rem = n - l;
+            const unsigned b = (unsigned)(2 * (rem < K ? rem : K));
+            stride /= b;
+            const unsigned dg = rest / stride;
+            rest -= dg * stride;
+            const unsigned srt = sortK ? pp_tsp_sort(lds, a.ord, rem, a.px, a.py) : a.ord;
+            a = pp_tsp_child(lds, a, srt, (int)dg, twoW);
+        }
+        double v = PP_DBL_MAX;
+        if (nsuf == 0) {
+            v = a.sf;
+        } else {
+            const int remA = n - Ls;
+            const int bA = 2 * (remA < K ? remA : K);
+            const unsigned srtA = sortK ? pp_tsp_sort(lds, a.ord, remA, a.px, a.py) : a.ord;
+            for (int uA = 0; uA < bA; uA++) {
+                const PPTspNode bnode = pp_tsp_child(lds, a, srtA, uA, twoW);
+                if (nsuf == 1) {
+                    v = fmin(v, bnode.sf);
+                } else {
+                    const int remB = remA - 1;
+                    const int bB = 2 * (remB < K ? remB : K);
+                    const unsigned srtB = sortK ? pp_tsp_sort(lds, bnode.ord, remB, bnode.px, bnode.py) : bnode.ord;
+                    for (int uB = 0; uB < bB; uB++) {
+                        const PPTspNode leaf = pp_tsp_child(lds, bnode, srtB, uB, twoW);
+                        v = fmin(v, leaf.sf);
+                    }
+                }
+            }
+        }
+        if (act) best = fmin(best, v);
     }
     return pp_wave_min(best);
 }

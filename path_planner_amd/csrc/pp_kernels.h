@@ -133,6 +133,9 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
     bool dubErr = false;
     const double w = p.ribw;
     const double inc_d = p.inc_d;
+    // bounds used by the obstacle culling: how far the vehicle / time advance over one 64-step chunk
+    const double chunkTime = 64.0 * (p.inc_d / p.max_speed);
+    const double chunkSpan = 64.0 * (p.inc_d / p.max_speed) * speed;
 
     if (!throwsRef) {
         for (int base = 0;; base += PP_WAVE) {
@@ -153,9 +156,15 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
                 double yaw;
                 pp_curve_sample(cv, dist, x, y, yaw);
                 heading = pp_heading_from_yaw(yaw);                   // :47
+#ifndef PP_ABL_NO_GRID
                 blk = pp_is_blocked(p.grid, x, y);                    // Edge.cpp:144
-                hits = pp_obstacle_hits(p.obst, p.n_obst, x, y, t);   // :150-151
+#endif
             }
+#ifndef PP_ABL_NO_OBST
+            if (p.n_obst > 0)                                         // :150-151
+                hits = pp_obstacle_hits_chunk(p.obst, p.n_obst, x, y, t, valid, pp_readlane(x, 0), pp_readlane(y, 0), tFirst,
+                                              chunkSpan, chunkTime);
+#endif
             double prevHeading = __shfl_up(heading, 1, PP_WAVE);
             if (lane == 0) prevHeading = carryHeading;
 
@@ -166,6 +175,9 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
 
             // phase B: coverage events among steps [0, limit)
             int lastEv = -1;
+#ifdef PP_ABL_NO_EVENTS
+            nextEvent = 1 << 30;
+#endif
             while (true) {
                 const int j = nextEvent - base;
                 if (j >= limit) break;
@@ -173,11 +185,9 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
                 if (!(tj < endTime)) break;
                 const double xj = pp_readlane(x, j), yj = pp_readlane(y, j);
                 const double hj = pp_readlane(heading, j), phj = pp_readlane(prevHeading, j);
-                const double D = pp_ribbons_min_distance(rib, nrib, w, xj, yj);          // Edge.cpp:158
-                if (cov || phj == hj) {                                                   // :159
-                    nrib = pp_ribbons_cover(rib, nrib, w, xj, yj, lds);                  // :160
-                    if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
-                }
+                double D;                                                                 // Edge.cpp:158-161
+                nrib = pp_ribbons_event(rib, nrib, w, xj, yj, cov || phj == hj, lds, D);
+                if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
                 if (nrib == 0) {                                                          // :162-170
                     if (cct == -1) cct = tj;
                     rdt = (int)tj;
@@ -246,7 +256,8 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
         endHeading = pp_heading_from_yaw(yaw);
         // cover the last little bit (:182-191)
         if (cov || lastHeading == ih) {
-            nrib = pp_ribbons_cover(rib, nrib, w, ix, iy, lds);
+            double Dunused;
+            nrib = pp_ribbons_event(rib, nrib, w, ix, iy, true, lds, Dunused);
             if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
         }
         if (nrib == 0) {
@@ -262,25 +273,8 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
     const double trueCost = tc * p.tpf + penalty;                                 // :199
     const double g = srcG + trueCost;                                             // Vertex::setCurrentCost
 
-    // Vertex::computeApproxToGo (Vertex.cpp:49-64): child ribbons -> LDS, heuristic, / maxSpeed
-    double hdist = 0;
-    if (!throwsRef && nrib > 0) {
-        if (lane < nrib) { lds[lane * 4 + 0] = rib.sx; lds[lane * 4 + 1] = rib.sy; lds[lane * 4 + 2] = rib.ex; lds[lane * 4 + 3] = rib.ey; }
-        pp_wave_lds_fence();
-        if (p.heuristic == PPGPU_H_MAX_DISTANCE) {
-            hdist = pp_h_max_distance(lds, nrib, w, endX, endY);
-        } else if (nrib > PP_TSP_MAX) {
-            flags |= PPGPU_F_RIBBON_OVF;
-        } else if (p.heuristic == PPGPU_H_TSP_POINT_ALL) {
-            hdist = pp_h_tsp_point(lds, nrib, w, PP_TSP_MAX, false, endX, endY);
-        } else if (p.heuristic == PPGPU_H_TSP_POINT_K) {
-            hdist = pp_h_tsp_point(lds, nrib, w, p.tsp_k, true, endX, endY);
-        } else {
-            flags |= PPGPU_F_DUBINS_ERR;   // Dubins-TSP heuristics are not on the device path yet
-        }
-        pp_wave_lds_fence();
-    }
-    const double h = hdist / p.max_speed * p.tpf;
+    // h and f are filled in by pp_k_heuristic from the child ribbons written below
+    const double h = 0;
 
     if (infeasible) flags |= PPGPU_F_INFEASIBLE;
     if (throwsRef) flags |= PPGPU_F_THROWS | PPGPU_F_INFEASIBLE;
@@ -318,12 +312,59 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
         if (throwsRef && lane != 0) v = 0;
         if (lane < 16) reinterpret_cast<double*>(rec)[lane] = v;
     }
-    if (p.child && !throwsRef) {
+    if (!throwsRef) {
+        if (nrib > p.stride && lane == 0) rec->flags = flags | PPGPU_F_RIBBON_OVF;   // after the record store above
         if (lane < nrib && lane < p.stride) {
             double* c = p.child + ((size_t)e * p.stride + lane) * 4;
             c[0] = rib.sx; c[1] = rib.sy; c[2] = rib.ex; c[3] = rib.ey;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Vertex::computeApproxToGo (Vertex.cpp:49-64) for every costed edge: h = heuristic(child pose,
+// child ribbons) / maxSpeed, f = g + h, patched into the edge's record.  Its own kernel so that the
+// sweep kernel's register budget is not set by the TSP enumeration.  One wavefront per edge.
+__global__ __launch_bounds__(256) void pp_k_heuristic(PPParams p) {
+    __shared__ double lds_all[4][PP_WAVE * PP_RIB_LDS];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = pp_lane();
+    const long long e = (long long)blockIdx.x * 4 + wave;
+    if (e >= p.n_edges) return;
+    double* lds = lds_all[wave];
+    ppgpu_edge_result* rec = p.out + e;
+    unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)rec->flags);
+    if (flags & PPGPU_F_THROWS) return;
+    int nrib = (int)((__builtin_amdgcn_readfirstlane((int)rec->info) >> 8) & 0xff);
+    const double endX = rec->end_x, endY = rec->end_y, g = rec->g;
+    double hdist = 0;
+    if (nrib > 0) {
+        if (nrib > p.stride) {
+            nrib = 0;   // the list was truncated (already flagged): no meaningful heuristic
+        } else {
+            if (lane < nrib) {
+                const double* c = p.child + ((size_t)e * p.stride + lane) * 4;
+                const double sx = c[0], sy = c[1], ex = c[2], ey = c[3];
+                lds[lane * PP_RIB_LDS + 0] = sx; lds[lane * PP_RIB_LDS + 1] = sy;
+                lds[lane * PP_RIB_LDS + 2] = ex; lds[lane * PP_RIB_LDS + 3] = ey;
+                lds[lane * PP_RIB_LDS + 4] = sqrt(pp_sq_len(sx, sy, ex, ey));    // Ribbon::length()
+            }
+            pp_wave_lds_fence();
+            if (p.heuristic == PPGPU_H_MAX_DISTANCE) {
+                hdist = pp_h_max_distance(lds, nrib, p.ribw, endX, endY);
+            } else if (nrib > PP_TSP_MAX) {
+                flags |= PPGPU_F_RIBBON_OVF;
+            } else if (p.heuristic == PPGPU_H_TSP_POINT_ALL) {
+                hdist = pp_h_tsp_point(lds, nrib, p.ribw, PP_TSP_MAX, false, endX, endY);
+            } else if (p.heuristic == PPGPU_H_TSP_POINT_K) {
+                hdist = pp_h_tsp_point(lds, nrib, p.ribw, p.tsp_k, true, endX, endY);
+            } else {
+                flags |= PPGPU_F_DUBINS_ERR;   // Dubins-TSP heuristics are rejected by ppgpu_set_config
+            }
+        }
+    }
+    const double h = hdist / p.max_speed * p.tpf;
+    if (lane == 0) { rec->h = h; rec->f = g + h; rec->flags = flags; }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -77,7 +77,8 @@ struct ppgpu_ctx {
     // scratch for host-convenience entry points and reductions
     DevBuf<unsigned long long> tmp_edges, partial;
     DevBuf<ppgpu_edge_result> tmp_results;
-    DevBuf<double> tmp_child, tmp_lengths, tmp_len_out;
+    DevBuf<double> tmp_child, tmp_lengths, tmp_len_out, int_child;
+    int max_vertex_ribbons = 0;
     DevBuf<int> tmp_idx;
     DevBuf<unsigned long long> gather;
 };
@@ -119,7 +120,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->sx.release(); c->sy.release(); c->sh.release(); c->samp_ribbons.release();
     c->s_bytes.release(); c->s_u64.release(); c->s_u32a.release(); c->s_u32b.release(); c->s_cand.release();
     c->tmp_edges.release(); c->partial.release(); c->tmp_results.release(); c->tmp_child.release();
-    c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release();
+    c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PPGPU_OK;
@@ -193,6 +194,8 @@ int ppgpu_set_obstacles(ppgpu_ctx* c, int32_t model, int32_t n, const double* o7
         h[i].Speed = o[3]; h[i].Time = o[4];
         h[i].halfW = (o[5] + 2) / 2;
         h[i].halfL = (o[6] + 2) / 2;
+        h[i].reach = std::sqrt(h[i].halfW * h[i].halfW + h[i].halfL * h[i].halfL) * (1.0 + 1e-12);
+        h[i].pad = 0;
     }
     int rc = c->obst.reserve((size_t)n, false, c->stream);
     if (rc) return rc;
@@ -225,6 +228,8 @@ int ppgpu_set_vertices(ppgpu_ctx* c, int32_t n, const ppgpu_vertex* hv, int32_t 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));  // the host arrays may go away after return
     c->nverts = n; c->nribbons = n_ribbons;
+    c->max_vertex_ribbons = 0;
+    for (int i = 0; i < n; i++) if (hv[i].ribbon_count > c->max_vertex_ribbons) c->max_vertex_ribbons = hv[i].ribbon_count;
     return PPGPU_OK;
 }
 
@@ -464,7 +469,17 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     if (p.n_edges <= 0) return PPGPU_OK;
     long long blocks = (p.n_edges + 3) / 4;
     if (blocks > 0x7fffffffll) return fail(PPGPU_ECAPACITY, "cost_edges: too many edges for one launch");
+    if (!p.child) {
+        // the heuristic kernel reads the child ribbon lists: keep them in a scratch the caller never sees
+        int stride = c->max_vertex_ribbons + 8;
+        if (stride > PP_WAVE) stride = PP_WAVE;
+        int rc = c->int_child.reserve((size_t)p.n_edges * stride * 4, false, c->stream);
+        if (rc) return rc;
+        p.child = c->int_child.p;
+        p.stride = stride;
+    }
     hipLaunchKernelGGL(pp_k_cost_edges, dim3((unsigned)blocks), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(pp_k_heuristic, dim3((unsigned)blocks), dim3(256), 0, c->stream, p);
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;
 }
