@@ -39,7 +39,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from path_planner_amd import api, workloads
+    from path_planner_amd import api, sharding, workloads
     from path_planner_amd.types import RESULT_DTYPE, F_INFEASIBLE
 
     rank = int(os.environ.get("RANK", "0"))
@@ -70,16 +70,17 @@ def main():
 
     def step(timed):
         ctx.sampler_init(w.bounds6, w.seed, w.ribbons4)
-        if rank:
-            ctx.sampler_skip(rank * B)        # this rank's shard of the iteration's batch
-        n = ctx.sampler_add(B)
+        lo, hi = sharding.shard_attempts(B * world, rank, world)   # this rank's slice of the iteration's batch
+        if lo:
+            ctx.sampler_skip(lo)
+        n = ctx.sampler_add(hi - lo)
         ne = 4 * n
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
         ev0.record(stream)
         ctx.cost_edges_dense(0, 1, 0, n, 0xF, d_res.data_ptr())
         ev1.record(stream)
-        ctx.best_edge(ne, d_res.data_ptr(), d_key2.data_ptr(), goal_only=False, base=rank * max_edges)
+        ctx.best_edge(ne, d_res.data_ptr(), d_key2.data_ptr(), goal_only=False, base=sharding.edge_index_base(rank, max_edges))
         if world > 1:
             dist.all_gather_into_tensor(d_gather, d_key2)          # one collective: 16 B per rank over xGMI
             ctx.key_min(world, d_gather.data_ptr(), d_key2.data_ptr())

@@ -479,6 +479,41 @@ void ppo_edge_event_stats(void* w, const ppgpu_vertex* verts, const double* pool
     }
 }
 
+// SamplingBasedPlanner::expand on a root vertex, the way the reference's ExpandTest1Ribbons drives it
+// (test_planner.cpp:1061-1082): a ribbon-less StateGenerator whose first `gen_skip` states are consumed
+// elsewhere, addSamples(generator, n_samples), expand(root), then pop the whole queue.
+// out_f receives the popped f values in pop order; returns how many were popped (-1 if something threw).
+int ppo_expand_once(void* w, int n_ribbons, const double* ribbons4, const double* root5, const double* b6, uint64_t seed,
+                    long gen_skip, int n_samples, double* out_f, int cap, uint64_t* generated, uint64_t* expanded,
+                    uint64_t* kept_samples) {
+    World* W = (World*)w;
+    AStarPlanner pl;
+    pl.cfg = make_config(*W);
+    pl.startStateTime = pl.cfg.startStateTime;
+    StateGenerator g(b6[0], b6[1], b6[2], b6[3], b6[4], b6[5], seed);
+    for (long i = 0; i < gen_skip; i++) g.generate();
+    RibbonManager rm = make_rm(*W, ribbons4, n_ribbons, -1);
+    State root(root5[0], root5[1], root5[2], root5[3], root5[4]);
+    pl.arena.push_back(makeRoot(root, rm));
+    computeApproxToGo(pl.arena[0], pl.cfg);
+    pl.addSamples(g, n_samples);
+    int n = 0;
+    try {
+        pl.expand(0);
+        int v;
+        while ((v = pl.popVertexQueue()) >= 0) {
+            if (n < cap) out_f[n] = pl.arena[v].f();
+            n++;
+        }
+    } catch (...) {
+        return -1;
+    }
+    if (generated) *generated = pl.stats.Generated;
+    if (expanded) *expanded = pl.stats.Expanded;
+    if (kept_samples) *kept_samples = pl.samples.size();
+    return n;
+}
+
 int ppo_hardware_threads() { return (int)std::thread::hardware_concurrency(); }
 
 }  // extern "C"

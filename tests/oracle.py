@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "libpp_oracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libpp_ref.so")
 
+C_ = C
+
 vp, dbl, i32, i64, u64 = C.c_void_p, C.c_double, C.c_int, C.c_long, C.c_uint64
 
 
@@ -84,6 +86,8 @@ for _n, _r, _a in [
     ("ppo_dubins_lengths", i32, [vp, vp, i32, i32, i64, vp, vp, vp, vp]),
     ("ppo_plan", i32, [vp, i32, vp, dbl, vp, i32, i32, i32, vp, dbl, dbl, dbl, C.POINTER(PlanStats), vp, i32, vp, i32, vp, i64,
                         C.POINTER(i64)]),
+    ("ppo_expand_once", i32, [vp, i32, vp, vp, vp, u64, i64, i32, vp, i32, vp, vp, vp]),
+    ("ppo_edge_event_stats", None, [vp, vp, vp, vp, vp, vp, i64, vp, vp]),
     ("ppo_hardware_threads", i32, []),
 ]:
     _sig(O, _n, _r, _a)
