@@ -726,6 +726,11 @@ Vertex connectWrapper(const Vertex& start, int startIndex, const DubinsWrapper& 
 }
 
 double computeApproxToGo(Vertex& v, const Config& cfg) {  // Vertex.cpp:49-64 (passes heading as "yaw")
+    if (cfg.tspRibbonLimit > 0 && v.ribbons.heuristic != MaxDistance && (int)v.ribbons.ribbons.size() > cfg.tspRibbonLimit) {
+        v.heuristicSkipped = true;
+        v.approxToGo = 0;
+        return 0;
+    }
     double max = v.ribbons.approximateDistanceUntilDone(v.state.x, v.state.y, v.state.heading);
     v.approxToGo = max / cfg.maxSpeed * cfg.timePenaltyFactor;
     return v.approxToGo;

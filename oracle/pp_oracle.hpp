@@ -151,6 +151,9 @@ struct Config {
     const GridMap* map = nullptr;
     const Obstacles* obstacles = nullptr;
     std::function<double()> now;
+    // Checker-only knob mirroring the DEVICE contract (include/ppgpu.h, PPGPU_F_RIBBON_OVF): with a TSP heuristic
+    // and more ribbons than this, h is reported as 0 instead of enumerating 2^n n! tours.  0 = no limit (reference).
+    int tspRibbonLimit = 0;
     double slowSpeed() const { return slowSpeedRaw <= 0 ? maxSpeed : slowSpeedRaw; }  // PlannerConfig.h:168-171
 };
 
@@ -170,6 +173,7 @@ struct Vertex {
     bool threw = false;              // computeTrueCost would have thrown
     double edgeApproxCost = -1, edgeTrueCost = -1, collisionPenalty = 0;
     int steps = 0;                   // sweep iterations executed (diagnostic)
+    bool heuristicSkipped = false;   // tspRibbonLimit applied
     int events = 0, mutations = 0;   // coverage events / events that changed the ribbon list (diagnostic)
     double f() const { return currentCost + approxToGo; }
     int depth(const std::vector<Vertex>& arena) const;

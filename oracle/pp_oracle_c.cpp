@@ -17,6 +17,7 @@ struct World {
     Obstacles obstacles;
     ppgpu_config pc{};
     bool have_cfg = false;
+    int tsp_limit = 8;   // PP_TSP_MAX of the device path; ppo_world_set_tsp_limit(0) restores the unbounded reference
 };
 
 Config make_config(const World& w) {
@@ -35,6 +36,7 @@ Config make_config(const World& w) {
     c.timePenaltyFactor = p.time_penalty_factor;
     c.map = &w.map;
     c.obstacles = &w.obstacles;
+    c.tspRibbonLimit = w.tsp_limit;
     RibbonManager::RibbonWidth = p.ribbon_width;
     return c;
 }
@@ -222,6 +224,7 @@ void ppo_ribbon_end_states(const double* r4, double* start5, double* end5) {
 void* ppo_world_create() { return new World(); }
 void ppo_world_destroy(void* w) { delete (World*)w; }
 void ppo_world_set_config(void* w, const ppgpu_config* c) { ((World*)w)->pc = *c; ((World*)w)->have_cfg = true; RibbonManager::RibbonWidth = c->ribbon_width; }
+void ppo_world_set_tsp_limit(void* w, int limit) { ((World*)w)->tsp_limit = limit; }
 void ppo_world_set_grid(void* w, const uint8_t* cells, int rows, int cols, double res) {
     World* W = (World*)w;
     if (rows == 0) { W->map = GridMap(); return; }
@@ -333,8 +336,12 @@ static void cost_one(const World& W, const Config& cfg, const ppgpu_vertex* vert
         out->g = end.currentCost; out->h = end.approxToGo; out->f = end.currentCost + end.approxToGo;
         out->coverage_completed_time = end.ribbons.coverageCompletedTime;
         out->param[0] = end.wrapper.path.param[0]; out->param[1] = end.wrapper.path.param[1]; out->param[2] = end.wrapper.path.param[2];
+        if (end.heuristicSkipped) flags |= PPGPU_F_RIBBON_OVF;
         if (child) {
-            if (nr > stride) flags |= PPGPU_F_RIBBON_OVF;
+            if (nr > stride) {   // the device contract: a truncated ribbon list carries no heuristic (h = 0, f = g)
+                flags |= PPGPU_F_RIBBON_OVF;
+                out->h = 0; out->f = out->g;
+            }
             for (int i = 0; i < nr && i < stride; i++) {
                 child[4 * i] = end.ribbons.ribbons[i].sx; child[4 * i + 1] = end.ribbons.ribbons[i].sy;
                 child[4 * i + 2] = end.ribbons.ribbons[i].ex; child[4 * i + 3] = end.ribbons.ribbons[i].ey;

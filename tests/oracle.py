@@ -72,6 +72,7 @@ for _n, _r, _a in [
     ("ppo_world_create", vp, []),
     ("ppo_world_destroy", None, [vp]),
     ("ppo_world_set_config", None, [vp, C.POINTER(PpgpuConfig)]),
+    ("ppo_world_set_tsp_limit", None, [vp, i32]),
     ("ppo_world_set_grid", None, [vp, vp, i32, i32, dbl]),
     ("ppo_world_load_grid_text", i32, [vp, C.c_char_p, C.POINTER(i32), C.POINTER(dbl)]),
     ("ppo_world_get_cells", None, [vp, vp]),

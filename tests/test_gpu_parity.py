@@ -55,3 +55,255 @@ def test_sampler_and_dense_costing_match_oracle(torch_cuda, cfgname, n_samples):
     rep = compare_results(gpu, cpu, gchild, cchild)
     print(cfgname, rep)
     assert rep["ok"], rep
+
+
+# ----------------------------------------------------------------------------------------------
+def _children_as_vertices(w, res, child, pick, stride=8):
+    """Turn costed edges into open vertices (what the host planner does with pushed children)."""
+    from path_planner_amd.types import VERTEX_DTYPE
+    v = np.zeros(len(pick) + 1, dtype=VERTEX_DTYPE)
+    pool = [np.asarray(w.ribbons4, dtype=np.float64).reshape(-1, 4)]
+    v[0] = w.root()[0]
+    off = len(pool[0])
+    for k, e in enumerate(pick):
+        r = res[e]
+        nr = int((r["info"] >> 8) & 0xFF)
+        v[k + 1] = (r["end_x"], r["end_y"], r["end_heading"], r["end_speed"], r["end_time"], r["g"],
+                    r["coverage_completed_time"], off, nr)
+        pool.append(child[e, :nr])
+        off += nr
+    return v, np.concatenate(pool)
+
+
+def test_children_as_sources_list_mode_and_best_edge(torch_cuda):
+    """Second-generation edges: sources are children of the root (their own time grids, ribbon lists and
+    coverageCompletedTime), edges given as an explicit list, incumbent min-reduce checked against numpy."""
+    from path_planner_amd import api, workloads, sharding
+    from path_planner_amd.types import RESULT_DTYPE, F_INFEASIBLE, F_GOAL, edge_pack
+    from parity import compare_results
+    import oracle as orc
+    torch = torch_cuda
+    w = workloads.config3(n_samples=512)
+    ctx, world, n, cs = _setup(w, 512)
+    gpu, gchild = _dense(torch, ctx, 1, n, 0xF)
+    feas = np.nonzero(((gpu["flags"] & F_INFEASIBLE) == 0) & ((gpu["flags"] & F_GOAL) == 0))[0]
+    pick = feas[:: max(1, len(feas) // 40)][:40]
+    verts, pool = _children_as_vertices(w, gpu, gchild, pick)
+    ctx.set_vertices(verts, pool)
+    rng = np.random.default_rng(5)
+    ne = 3000
+    vi = rng.integers(0, len(verts), ne)
+    ti = rng.integers(0, n, ne)
+    cb = rng.integers(0, 4, ne)
+    # the reference never builds an edge shorter than the collision-check increment (SamplingBasedPlanner.cpp:68,111);
+    # such degenerate Dubins problems (here: a child and the very sample it was built from) are outside the contract
+    far = np.hypot(verts["x"][vi] - cs[ti, 0], verts["y"][vi] - cs[ti, 1]) > w.cfg.collision_checking_increment
+    assert far.sum() > 2900 and (~far).sum() > 0
+    vi, ti, cb = vi[far], ti[far], cb[far]
+    ne = len(vi)
+    edges = edge_pack(vi, ti, cb)
+    d_e = torch.from_numpy(edges.view(np.int64)).to("cuda:0")
+    d_res = torch.zeros(ne * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
+    d_child = torch.zeros(ne * 10 * 4, dtype=torch.float64, device="cuda:0")
+    ctx.cost_edges_list(ne, d_e.data_ptr(), d_res.data_ptr(), d_child.data_ptr(), 10)
+    d_key = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+    ctx.best_edge(ne, d_res.data_ptr(), d_key.data_ptr(), goal_only=False, base=7000)
+    d_keyg = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+    ctx.best_edge(ne, d_res.data_ptr(), d_keyg.data_ptr(), goal_only=True, base=0)
+    ctx.synchronize()
+    g2 = d_res.cpu().numpy().view(RESULT_DTYPE)
+    c2, cc2 = world.cost_edges(verts, pool, cs[:, 0], cs[:, 1], cs[:, 2], edges, stride=10)
+    rep = compare_results(g2, c2, d_child.cpu().numpy().reshape(ne, 10, 4), cc2)
+    print(rep)
+    bad = np.nonzero((g2["flags"] != c2["flags"]) | (g2["info"] != c2["info"]))[0]
+    for b in bad[:5]:
+        print("mismatch edge", b, "vertex", vi[b], "target", ti[b], "cfg", cb[b], "euclid",
+              float(np.hypot(verts["x"][vi[b]] - cs[ti[b], 0], verts["y"][vi[b]] - cs[ti[b], 1])), g2[b], c2[b])
+    assert rep["ok"], rep
+    assert rep["n_feasible"] > 200
+    key = d_key.cpu().numpy().view(np.uint64)
+    exp = sharding.local_best_key(g2["f"], (g2["flags"] & F_INFEASIBLE) == 0, base=7000)
+    assert key.tolist() == exp.tolist()
+    keyg = d_keyg.cpu().numpy().view(np.uint64)
+    expg = sharding.local_best_key(g2["f"], ((g2["flags"] & F_INFEASIBLE) == 0) & ((g2["flags"] & F_GOAL) != 0))
+    assert keyg.tolist() == expg.tolist()
+    # the host-convenience entry point gives the same records
+    h_res, h_child = ctx.cost_edges_host(edges[:64], stride=10)
+    assert np.array_equal(h_res.view(np.uint8), g2[:64].view(np.uint8))
+
+
+def test_dubins_lengths_and_nearest_selection(torch_cuda):
+    """Edge::computeApproxCost lengths for the k-nearest scan and the selection itself
+    (SamplingBasedPlanner.cpp:85-133): equal to 'k smallest Dubins lengths, ties by sample index'."""
+    from path_planner_amd import workloads
+    from path_planner_amd.types import F_INFEASIBLE
+    torch = torch_cuda
+    w = workloads.config2(n_samples=2048)
+    ctx, world, n, cs = _setup(w, 2048)
+    gpu, gchild = _dense(torch, ctx, 1, 64, 0x1)
+    pick = np.nonzero((gpu["flags"] & F_INFEASIBLE) == 0)[0][:5]
+    verts, pool = _children_as_vertices(w, gpu, gchild, pick)
+    ctx.set_vertices(verts, pool)
+    nv = len(verts)
+    d_len = torch.zeros(nv * n * 2, dtype=torch.float64, device="cuda:0")
+    ctx.dubins_lengths(0, nv, d_len.data_ptr())
+    ctx.synchronize()
+    L = d_len.cpu().numpy().reshape(nv, n, 2)
+    Lc = world.dubins_lengths(verts, 0, nv, cs[:, 0], cs[:, 1], cs[:, 2])
+    assert np.array_equal(L < 0, Lc < 0)
+    rel = np.abs(L - Lc) / np.maximum(np.abs(Lc), 1.0)
+    assert rel.max() < 1e-12, rel.max()
+    k = 9
+    idx, ln = ctx.select_nearest(0, nv, k)
+    for v in range(nv):
+        for r in range(2):
+            col = L[v, :, r]
+            cand = np.nonzero(col >= 0)[0]
+            order = cand[np.lexsort((cand, col[cand]))][:k]
+            assert idx[v, r].tolist() == order.tolist()
+            assert np.array_equal(ln[v, r], col[order])
+
+
+@pytest.mark.parametrize("case", ["done_at_start", "colocated", "no_grid_no_obst", "many_ribbons_maxdist", "tsp_all_four",
+                                  "equal_speeds", "short_horizon", "wide_ribbons"])
+def test_edge_cases_match_oracle(torch_cuda, case):
+    """Empty ribbon set, co-located target (the reference throws), base Map and base obstacle manager,
+    long ribbon lists, the other heuristics, degenerate configuration values."""
+    from path_planner_amd import api, workloads
+    from path_planner_amd.types import (RESULT_DTYPE, F_THROWS, F_INFEASIBLE, H_MAX_DISTANCE, H_TSP_POINT_ALL, H_TSP_POINT_K,
+                                        edge_pack, make_config)
+    from path_planner_amd.workloads import root_vertex
+    from parity import compare_results
+    import oracle as orc
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    kw = dict(start_state_time=3.0, heuristic=H_TSP_POINT_K, tsp_k=2)
+    grid, res, obst = np.zeros((300, 300), dtype=np.uint8), 0.5, workloads.obstacles(4, 9, 150.0, time=3.0, keep_free=(75, 75, 25))
+    grid[40:60, 100:180] = 1
+    grid[200:230, 60:90] = 1
+    rib = [[60, 90, 100, 90], [60, 100, 100, 100], [60, 110, 100, 112]]
+    if case == "done_at_start":
+        rib = []
+    elif case == "no_grid_no_obst":
+        grid, obst = None, None
+    elif case == "many_ribbons_maxdist":
+        kw["heuristic"] = H_MAX_DISTANCE
+        rib = [[40 + 4 * i, 85, 40 + 4 * i, 125] for i in range(12)]
+    elif case == "tsp_all_four":
+        kw["heuristic"] = H_TSP_POINT_ALL
+        rib = [[60, 86 + 6 * i, 100 - 3 * i, 86 + 6 * i] for i in range(6)]
+    elif case == "equal_speeds":
+        kw.update(slow_speed=-1.0, coverage_turning_radius=8.0)
+    elif case == "short_horizon":
+        kw.update(time_horizon=6.0, time_minimum=1.0, collision_checking_increment=0.11)
+    elif case == "wide_ribbons":
+        kw.update(ribbon_width=4.0)
+    cfg = make_config(**kw)
+    orc.O.ppo_set_ribbon_width(cfg.ribbon_width)
+    rib = np.asarray(rib, dtype=np.float64).reshape(-1, 4)
+    cct = 3.0 if case == "done_at_start" else -1.0           # AStarPlanner.cpp:19 sets it when nothing is left
+    root = root_vertex(75.0, 75.0, 0.4, 2.5, 3.0, rib, cct=cct)
+    n = 300
+    sx, sy, sh = rng.uniform(20, 130, n), rng.uniform(20, 130, n), rng.uniform(0, 2 * np.pi, n)
+    sx[0], sy[0], sh[0] = 75.0, 75.0, 0.4                    # co-located with the root: reference throws
+    # (targets closer than the collision-check increment are never built by the reference, SamplingBasedPlanner.cpp:68,111:
+    #  their Dubins problem is degenerate and decided by the last bit of the host libm, so they are not part of the contract)
+    sx[2], sy[2], sh[2] = 80.0, 90.0, np.pi / 2              # ends on a ribbon, heading along it
+    ctx = api.Context(0)
+    ctx.set_config(cfg)
+    ctx.set_grid(grid, res)
+    ctx.set_obstacles(obst)
+    ctx.set_vertices(root, rib)
+    ctx.set_samples(sx, sy, sh)
+    # stride 20 on purpose: with 12 ribbons some children exceed it and must come back flagged PPGPU_F_RIBBON_OVF
+    gpu, gchild = _dense(torch, ctx, 1, n, 0xF, stride=20)
+    world = orc.World(cfg, grid, res, obst)
+    e = edge_pack(np.zeros(4 * n, dtype=np.uint64), np.repeat(np.arange(n), 4), np.tile(np.arange(4), n))
+    cpu, cchild = world.cost_edges(root, rib, sx, sy, sh, e, stride=20)
+    if case == "many_ribbons_maxdist":
+        from path_planner_amd.types import F_RIBBON_OVF
+        assert np.count_nonzero(gpu["flags"] & F_RIBBON_OVF) > 0
+    rep = compare_results(gpu, cpu, gchild, cchild)
+    print(case, rep)
+    badh = np.nonzero(np.abs(gpu["h"] - cpu["h"]) > 1e-6 * np.maximum(1.0, np.abs(cpu["h"])))[0]
+    for b in badh[:6]:
+        print("h mismatch edge", b, "flags", gpu["flags"][b], cpu["flags"][b], "nrib", (gpu["info"][b] >> 8) & 255, "h", gpu["h"][b], cpu["h"][b],
+              "g", gpu["g"][b], cpu["g"][b])
+    assert rep["ok"], rep
+    assert np.all((gpu["flags"][:4] & F_THROWS) != 0)        # the co-located target, all four configurations
+    assert np.count_nonzero(gpu["flags"] & F_THROWS) == 4
+    if case == "done_at_start":
+        ok = (gpu["flags"] & F_INFEASIBLE) == 0
+        assert np.all(gpu["true_cost"][ok] == gpu["collision_penalty"][ok])   # time costs nothing once coverage is done
+    orc.O.ppo_set_ribbon_width(1.5)
+
+
+def test_sampler_continuation_skip_and_ribbonless(torch_cuda):
+    """addSamples(generator, n) twice continues one stream (AStarPlanner.cpp:101-102); a skipped prefix lands on the
+    same stream position; the ribbon-less constructor consumes 4 draws per state."""
+    from path_planner_amd import api, workloads
+    import oracle as orc
+    w = workloads.config2()
+    ctx = api.Context(0)
+    ctx.set_config(w.cfg)
+    ctx.set_grid(w.grid, w.res)
+    world = orc.World(w.cfg, w.grid, w.res, None)
+    ctx.sampler_init(w.bounds6, 12345, w.ribbons4)
+    n1 = ctx.sampler_add(1000)
+    n2 = ctx.sampler_add(3000)
+    n3 = ctx.sampler_add(7)
+    cs = world.add_samples(w.bounds6, 12345, w.ribbons4, 0, 4007)
+    assert n3 == len(cs) and n1 == len(world.add_samples(w.bounds6, 12345, w.ribbons4, 0, 1000))
+    assert np.array_equal(ctx.get_samples()[:, :3], cs[:, :3])
+    ctx.sampler_init(w.bounds6, 12345, w.ribbons4)
+    ctx.sampler_skip(2500)
+    m = ctx.sampler_add(1507)
+    assert np.array_equal(ctx.get_samples()[:, :3], world.add_samples(w.bounds6, 12345, w.ribbons4, 2500, 1507)[:, :3])
+    ctx.sampler_init(w.bounds6, 99, None)
+    m = ctx.sampler_add(5000)
+    c2 = world.add_samples(w.bounds6, 99, None, 0, 5000)
+    assert m == len(c2) and np.array_equal(ctx.get_samples()[:, :3], c2[:, :3])
+    # seed 0 and seeds >= 2^31-1 follow linear_congruential_engine::seed
+    for seed in (0, 2147483647, 2147483648 + 5, 2**40 + 3):
+        ctx.sampler_init(w.bounds6, seed, w.ribbons4)
+        ctx.sampler_add(300)
+        assert np.array_equal(ctx.get_samples()[:, :3], world.add_samples(w.bounds6, seed, w.ribbons4, 0, 300)[:, :3])
+
+
+def test_full_size_properties_config3(torch_cuda):
+    """BASELINE.json's full size (65 536 attempts, 2048^2 grid, 16 obstacles): properties that need no oracle, plus
+    an oracle spot check of a strided subset."""
+    from path_planner_amd import api, workloads
+    from path_planner_amd.types import RESULT_DTYPE, F_INFEASIBLE, F_THROWS, F_GOAL, F_DONE, edge_pack
+    from parity import compare_results
+    import oracle as orc
+    torch = torch_cuda
+    w = workloads.config3()
+    ctx, world, n, cs = _setup(w, w.n_samples)
+    assert np.array_equal(ctx.get_samples()[:, :3], cs[:, :3])
+    assert not world.is_blocked(cs[:, 0], cs[:, 1]).any()                      # every kept sample is on a free cell
+    gpu, gchild = _dense(torch, ctx, 1, n, 0xF)
+    gpu2, _ = _dense(torch, ctx, 1, n, 0xF)
+    assert np.array_equal(gpu.view(np.uint8), gpu2.view(np.uint8))             # run-to-run identical (no atomics, no races)
+    fl = gpu["flags"]
+    assert not (fl & F_THROWS).any()
+    ok = (fl & F_INFEASIBLE) == 0
+    assert 0.2 < ok.mean() < 0.9
+    assert np.array_equal(gpu["f"][ok], gpu["g"][ok] + gpu["h"][ok])
+    assert np.all(gpu["end_time"] <= w.cfg.time_horizon + w.cfg.start_state_time + 1e-12 + 1e-15)
+    assert np.all((gpu["info"] >> 16) <= 1501)
+    assert np.all(gpu["true_cost"][ok] >= 0) and np.all(gpu["h"][ok] >= 0)
+    pen = gpu["collision_penalty"][ok]
+    assert np.all(pen == np.round(pen / 600.0) * 600.0)                        # integer hit counts times 600
+    goal = (fl & F_GOAL) != 0
+    assert np.all(gpu["end_time"][goal & ok] >= w.cfg.start_state_time + w.cfg.time_horizon) or (fl[goal] & F_DONE).any()
+    # a reversed-order list of the same edges gives the same records (edge independence)
+    ne = len(gpu)
+    sub = np.arange(0, ne, 97)
+    e = edge_pack(np.zeros(len(sub), dtype=np.uint64), sub // 4, sub % 4)[::-1].copy()
+    h_res = ctx.cost_edges_host(e)
+    assert np.array_equal(h_res.view(np.uint8), gpu[sub][::-1].copy().view(np.uint8))
+    cpu = world.cost_edges(w.root(), w.ribbons4, cs[:, 0], cs[:, 1], cs[:, 2], e[::-1].copy())
+    rep = compare_results(gpu[sub], cpu)
+    print(rep)
+    assert rep["ok"], rep
