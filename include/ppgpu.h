@@ -133,6 +133,22 @@ static inline uint64_t ppgpu_edge_pack(uint32_t vertex, uint32_t target, uint32_
     return ((uint64_t)(cfg & 0xffu) << 56) | ((uint64_t)(vertex & 0xffffffu) << 32) | (uint64_t)target;
 }
 
+/* An edge whose curve already exists: Vertex::connect(start, DubinsWrapper, coverageAllowed)
+ * (Vertex.cpp:28-36) — how AStarPlanner::plan re-costs the previous plan (AStarPlanner.cpp:46-59).
+ * Fields are DubinsWrapper's (DubinsWrapper.h:118-120) as serialised by NodeBase.h:201-220. */
+typedef struct ppgpu_wrapper_edge {
+    int32_t vertex;            /* open vertex the edge starts from                        */
+    int32_t coverage_allowed;  /* p.getRho() == config.coverageTurningRadius()            */
+    double qi[3];              /* DubinsPath::qi (x, y, yaw)                              */
+    double param[3];           /* DubinsPath::param                                       */
+    double rho;                /* DubinsPath::rho                                         */
+    int32_t type;              /* DubinsPathType                                          */
+    int32_t reserved;
+    double speed;              /* DubinsWrapper::getSpeed()                               */
+    double start_time;         /* start time of the curve (m_StartTime)                   */
+    double end_time;           /* getEndTime(), possibly truncated by updateEndTime()     */
+} ppgpu_wrapper_edge;
+
 /* ------------------------------------------------------------------ lifecycle */
 
 /* Process-level handle: device context, stream, persistent buffers.  The reference
@@ -187,6 +203,13 @@ int ppgpu_sampler_skip(ppgpu_ctx* ctx, int64_t n_attempts);
 
 /* Replace the sample (target-state) store with caller data; x/y/heading arrays of n. */
 int ppgpu_set_samples(ppgpu_ctx* ctx, int64_t n, const double* h_x, const double* h_y, const double* h_heading);
+/* Explicit target states that are not samples — the nearest ribbon endpoint of the vertex being expanded
+ * (SamplingBasedPlanner.cpp:66-79), Brown-path seeds (AStarPlanner.cpp:150-162).  They are stored BEHIND the samples
+ * (indices *first_index .. *first_index + n - 1 for edge descriptors), are not seen by ppgpu_dubins_lengths /
+ * ppgpu_select_nearest, and are dropped by the next ppgpu_sampler_add / ppgpu_set_samples / ppgpu_set_extra_targets. */
+int ppgpu_set_extra_targets(ppgpu_ctx* ctx, int32_t n, const double* h_x, const double* h_y, const double* h_heading,
+                            int64_t* first_index);
+
 /* Copy samples [first, first+n) out as States {x,y,heading,speed,time} (5 doubles each). */
 int ppgpu_get_samples(ppgpu_ctx* ctx, int64_t first, int64_t n, double* h_states5);
 int64_t ppgpu_num_samples(ppgpu_ctx* ctx);
@@ -228,6 +251,13 @@ int ppgpu_cost_edges_list(ppgpu_ctx* ctx, int64_t n, const uint64_t* d_edges,
 int ppgpu_cost_edges_host(ppgpu_ctx* ctx, int64_t n, const uint64_t* h_edges,
                           ppgpu_edge_result* h_results,
                           double* h_child_ribbons, int32_t ribbon_stride);
+
+/* Wrapper edges (previous-plan re-costing): host descriptors in, host results out, synchronous.
+ * The caller must route a wrapper whose rho differs from the radius its coverage flag implies
+ * through ppgpu_cost_edges_* instead (Edge.cpp:78-80 re-solves the curve in that case). */
+int ppgpu_cost_wrapper_edges_host(ppgpu_ctx* ctx, int64_t n, const ppgpu_wrapper_edge* h_edges,
+                                  ppgpu_edge_result* h_results,
+                                  double* h_child_ribbons, int32_t ribbon_stride);
 
 /* Number of edges a dense launch with these arguments produces. */
 int64_t ppgpu_dense_edge_count(int32_t nv, int64_t ns, uint32_t cfg_mask);

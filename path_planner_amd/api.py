@@ -38,6 +38,7 @@ def _load():
         "ppgpu_sampler_add": (C.c_int, [vp, i64, C.POINTER(i64)]),
         "ppgpu_sampler_skip": (C.c_int, [vp, i64]),
         "ppgpu_set_samples": (C.c_int, [vp, i64, vp, vp, vp]),
+        "ppgpu_set_extra_targets": (C.c_int, [vp, i32, vp, vp, vp, C.POINTER(i64)]),
         "ppgpu_get_samples": (C.c_int, [vp, i64, i64, vp]),
         "ppgpu_num_samples": (i64, [vp]),
         "ppgpu_dubins_lengths": (C.c_int, [vp, i32, i32, vp]),
@@ -45,6 +46,7 @@ def _load():
         "ppgpu_cost_edges_dense": (C.c_int, [vp, i32, i32, i64, i64, u32, vp, vp, i32]),
         "ppgpu_cost_edges_list": (C.c_int, [vp, i64, vp, vp, vp, i32]),
         "ppgpu_cost_edges_host": (C.c_int, [vp, i64, vp, vp, vp, i32]),
+        "ppgpu_cost_wrapper_edges_host": (C.c_int, [vp, i64, vp, vp, vp, i32]),
         "ppgpu_dense_edge_count": (i64, [i32, i64, u32]),
         "ppgpu_best_edge": (C.c_int, [vp, i64, vp, i32, u64, vp]),
         "ppgpu_key_min": (C.c_int, [vp, i32, vp, vp]),

@@ -15,8 +15,10 @@ struct PPParams {
     const ppgpu_vertex* verts; const double* ribbons; const double* tgrid; int ng; int nverts;
     // targets
     const double* sx; const double* sy; const double* sh; long long n_samples;
-    // edges: explicit list, or dense enumeration when edges == nullptr
+    // edges: explicit list, or dense enumeration when edges == nullptr; wedges: edges whose curve is given
+    // (Vertex::connect(start, DubinsWrapper, coverageAllowed), Vertex.cpp:28-36) instead of solved
     const unsigned long long* edges; long long n_edges;
+    const ppgpu_wrapper_edge* wedges;
     int v0, nv; long long s0, ns; unsigned cfg_mask; int per;
     // outputs
     ppgpu_edge_result* out; double* child; int stride;
@@ -62,7 +64,11 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
 
     // ---- which edge
     unsigned vi, target, cbits;
-    if (p.edges) {
+    if (p.wedges) {
+        vi = (unsigned)p.wedges[e].vertex;
+        target = 0;
+        cbits = p.wedges[e].coverage_allowed ? PPGPU_EDGE_COVERAGE : 0u;
+    } else if (p.edges) {
         unsigned long long d = p.edges[e];
         target = (unsigned)(d & 0xffffffffull);
         vi = (unsigned)((d >> 32) & 0xffffffull);
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
 
     unsigned flags = 0;
     ppgpu_edge_result* rec = p.out + e;
-    if (vi >= (unsigned)p.nverts || (long long)target >= p.n_samples) {
+    if (vi >= (unsigned)p.nverts || (!p.wedges && (long long)target >= p.n_samples)) {
         // malformed descriptor: fail loudly in the record, touch nothing else
         if (lane == 0) { rec->flags = PPGPU_F_INFEASIBLE | PPGPU_F_THROWS | PPGPU_F_DUBINS_ERR; rec->info = 0; }
         return;
@@ -94,9 +100,10 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
     double cct = V->coverage_completed_time;
     int nrib = V->ribbon_count;
     const bool cov = (cbits & PPGPU_EDGE_COVERAGE) != 0;
-    const double rho = cov ? p.rho_cov : p.rho;                       // Edge.cpp:73-76
-    const double speed = (cbits & PPGPU_EDGE_SLOW) ? p.slow_speed : p.max_speed;
-    const double tgtX = p.sx[target], tgtY = p.sy[target], tgtH = p.sh[target];
+    double rho = cov ? p.rho_cov : p.rho;                             // Edge.cpp:73-76
+    double speed = (cbits & PPGPU_EDGE_SLOW) ? p.slow_speed : p.max_speed;
+    double tgtX = 0, tgtY = 0, tgtH = 0;
+    if (!p.wedges) { tgtX = p.sx[target]; tgtY = p.sy[target]; tgtH = p.sh[target]; }
 
     // this vertex's ribbons, one per lane (Vertex::connect copies the parent's RibbonManager, Vertex.cpp:24)
     PPRibbon rib = {0, 0, 0, 0};
@@ -108,13 +115,27 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
     const bool startedDone = (nrib == 0);                             // Edge.cpp:93
 
     // ---- phase 0: the curve (Edge::computeApproxCost -> DubinsWrapper::set)
-    const bool colocated = (srcX == tgtX) && (srcY == tgtY) && (srcH == tgtH);   // State::isCoLocated
+    bool colocated = false;
     PPDubins dub;
-    pp_dubins_shortest(srcX, srcY, pp_yaw(srcH), tgtX, tgtY, pp_yaw(tgtH), rho, dub);
     PPCurve cv;
-    pp_curve_init(cv, srcX, srcY, pp_yaw(srcH), rho, dub);
-    const double approx = cv.length / speed * 1.0;                    // Edge.cpp:17
-    const double wEnd = srcT + cv.length / speed;                     // DubinsWrapper::setEndTime
+    double approx, wEnd, wStart;
+    if (p.wedges) {
+        // the wrapper comes with the edge: DubinsWrapper::fill semantics, start time of ITS curve, possibly truncated end
+        const ppgpu_wrapper_edge* W = p.wedges + e;
+        dub.p0 = W->param[0]; dub.p1 = W->param[1]; dub.p2 = W->param[2]; dub.type = W->type;
+        if (dub.type < 0 || dub.type > 5) dub.type = -1;
+        rho = W->rho; speed = W->speed;
+        pp_curve_init(cv, W->qi[0], W->qi[1], W->qi[2], rho, dub);
+        wStart = W->start_time; wEnd = W->end_time;
+        approx = (wEnd - srcT) * 1.0;                                 // Edge::setEnd(wrapper), Edge.cpp:208-216
+    } else {
+        colocated = (srcX == tgtX) && (srcY == tgtY) && (srcH == tgtH);              // State::isCoLocated
+        pp_dubins_shortest(srcX, srcY, pp_yaw(srcH), tgtX, tgtY, pp_yaw(tgtH), rho, dub);
+        pp_curve_init(cv, srcX, srcY, pp_yaw(srcH), rho, dub);
+        approx = cv.length / speed * 1.0;                             // Edge.cpp:17
+        wStart = srcT;
+        wEnd = srcT + cv.length / speed;                              // DubinsWrapper::setEndTime
+    }
     double endTime = fmin(p.horizon + 1e-12 + p.sst, wEnd);           // Edge.cpp:90
     bool infeasible = (srcT >= endTime);                              // :102-110
     bool throwsRef = colocated || (dub.type < 0);
@@ -150,7 +171,7 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
             bool blk = false;
             int hits = 0;
             if (valid) {
-                double dist = (t - srcT) * speed;                     // DubinsWrapper.cpp:36
+                double dist = (t - wStart) * speed;                   // DubinsWrapper.cpp:36
                 if (dist < 0 || dist > cv.length) dist = dist - 1e-5; // EDUBPARAM retry, :39-42
                 if (dist < 0 || dist > cv.length) { dubErr = true; dist = fmin(fmax(dist, 0.0), cv.length); }
                 double yaw;
@@ -245,10 +266,10 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
 
     // ---- phase C
     // end()->state().time() = endTime; wrapper.sample(end state)  (Edge.cpp:177-178)
-    if (!throwsRef && !(srcT <= endTime && wEnd >= endTime)) throwsRef = true;   // DubinsWrapper::containsTime
+    if (!throwsRef && !(wStart <= endTime && wEnd >= endTime)) throwsRef = true;  // DubinsWrapper::containsTime
     double endX = 0, endY = 0, endHeading = 0;
     if (!throwsRef) {
-        double dist = (endTime - srcT) * speed;
+        double dist = (endTime - wStart) * speed;
         if (dist < 0 || dist > cv.length) dist = dist - 1e-5;
         if (dist < 0 || dist > cv.length) { flags |= PPGPU_F_DUBINS_ERR; dist = fmin(fmax(dist, 0.0), cv.length); }
         double yaw;

@@ -67,6 +67,7 @@ struct ppgpu_ctx {
     // sample (target state) store, SoA
     DevBuf<double> sx, sy, sh;
     long long n_samples = 0;
+    long long n_extra = 0;              // explicit target states appended behind the samples (ppgpu_set_extra_targets)
     // sampler (StateGenerator) state
     PPSamplerState sampler{};
     DevBuf<double> samp_ribbons;
@@ -76,6 +77,7 @@ struct ppgpu_ctx {
     DevBuf<double> s_cand;              // candidate states before the map filter
     // scratch for host-convenience entry points and reductions
     DevBuf<unsigned long long> tmp_edges, partial;
+    DevBuf<ppgpu_wrapper_edge> tmp_wedges;
     DevBuf<ppgpu_edge_result> tmp_results;
     DevBuf<double> tmp_child, tmp_lengths, tmp_len_out, int_child;
     int max_vertex_ribbons = 0;
@@ -119,7 +121,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->grid.release(); c->obst.release(); c->verts.release(); c->ribbons.release(); c->tgrid.release();
     c->sx.release(); c->sy.release(); c->sh.release(); c->samp_ribbons.release();
     c->s_bytes.release(); c->s_u64.release(); c->s_u32a.release(); c->s_u32b.release(); c->s_cand.release();
-    c->tmp_edges.release(); c->partial.release(); c->tmp_results.release(); c->tmp_child.release();
+    c->tmp_edges.release(); c->tmp_wedges.release(); c->partial.release(); c->tmp_results.release(); c->tmp_child.release();
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -251,6 +253,27 @@ int ppgpu_set_samples(ppgpu_ctx* c, int64_t n, const double* hx, const double* h
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     c->n_samples = n;
+    c->n_extra = 0;
+    return PPGPU_OK;
+}
+
+int ppgpu_set_extra_targets(ppgpu_ctx* c, int32_t n, const double* hx, const double* hy, const double* hh, int64_t* first_index) {
+    if (!c) return fail(PPGPU_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (n < 0 || (n > 0 && (!hx || !hy || !hh))) return fail(PPGPU_EINVAL, "extra_targets: bad arguments");
+    int rc;
+    size_t need = (size_t)(c->n_samples + n > 0 ? c->n_samples + n : 1);
+    if ((rc = c->sx.reserve(need, true, c->stream)) || (rc = c->sy.reserve(need, true, c->stream)) ||
+        (rc = c->sh.reserve(need, true, c->stream)))
+        return rc;
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(c->sx.p + c->n_samples, hx, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->sy.p + c->n_samples, hy, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->sh.p + c->n_samples, hh, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    c->n_extra = n;
+    if (first_index) *first_index = c->n_samples;
     return PPGPU_OK;
 }
 
@@ -299,6 +322,7 @@ int ppgpu_sampler_init(ppgpu_ctx* c, const double* b6, uint64_t seed, int32_t n_
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     c->n_samples = 0;
+    c->n_extra = 0;
     return PPGPU_OK;
 }
 
@@ -399,6 +423,7 @@ int ppgpu_sampler_add(ppgpu_ctx* c, int64_t n_attempts, int64_t* n_total_out) {
     if (s.on_ribbons && h2[1] == 0) return fail(PPGPU_EHIP, "sampler: chain scan did not reach the end of the batch");
     s.pos = s.on_ribbons ? (s.pos + h2[1]) : (s.pos + 4ull * (unsigned long long)n);   // slots consumed so far
     c->n_samples += (long long)h2[0];
+    c->n_extra = 0;                        // the appended samples overwrote any explicit targets
     if (n_total_out) *n_total_out = c->n_samples;
     return PPGPU_OK;
 }
@@ -416,14 +441,14 @@ static void fill_params(ppgpu_ctx* c, PPParams& p) {
     p.grid = PPGrid{c->grid.p, c->rows, c->cols, c->wpr, c->res};
     p.obst = c->obst.p; p.n_obst = c->n_obst;
     p.verts = c->verts.p; p.ribbons = c->ribbons.p; p.tgrid = c->tgrid.p; p.ng = c->ng; p.nverts = c->nverts;
-    p.sx = c->sx.p; p.sy = c->sy.p; p.sh = c->sh.p; p.n_samples = c->n_samples;
+    p.sx = c->sx.p; p.sy = c->sy.p; p.sh = c->sh.p; p.n_samples = c->n_samples + c->n_extra;
 }
 
 static int require_world(ppgpu_ctx* c) {
     int rc = require_cfg(c);
     if (rc) return rc;
     if (c->nverts <= 0) return fail(PPGPU_ESTATE, "ppgpu_set_vertices must be called (after ppgpu_set_config)");
-    if (c->n_samples <= 0) return fail(PPGPU_ESTATE, "no samples: call ppgpu_sampler_add or ppgpu_set_samples");
+    if (c->n_samples + c->n_extra <= 0) return fail(PPGPU_ESTATE, "no targets: call ppgpu_sampler_add, ppgpu_set_samples or ppgpu_set_extra_targets");
     return PPGPU_OK;
 }
 
@@ -434,6 +459,7 @@ int ppgpu_dubins_lengths(ppgpu_ctx* c, int32_t v0, int32_t nv, double* d_lengths
     if (v0 < 0 || nv <= 0 || v0 + nv > c->nverts || !d_lengths) return fail(PPGPU_EINVAL, "dubins_lengths: vertex range");
     if (nv > 65535) return fail(PPGPU_ECAPACITY, "dubins_lengths: at most 65535 vertices per call");
     const long long ns = c->n_samples;
+    if (ns <= 0) return fail(PPGPU_ESTATE, "dubins_lengths: the sample store is empty");
     hipLaunchKernelGGL(pp_k_dubins_lengths, dim3((unsigned)((ns + 255) / 256), (unsigned)nv), dim3(256), 0, c->stream, c->verts.p,
                        v0, c->sx.p, c->sy.p, c->sh.p, ns, c->cfg.turning_radius, c->cfg.coverage_turning_radius,
                        c->cfg.collision_checking_increment, d_lengths);
@@ -496,7 +522,7 @@ int ppgpu_cost_edges_dense(ppgpu_ctx* c, int32_t v0, int32_t nv, int64_t s0, int
     if (d_child && stride <= 0) return fail(PPGPU_EINVAL, "cost_edges_dense: ribbon_stride must be positive");
     PPParams p;
     fill_params(c, p);
-    p.edges = nullptr;
+    p.edges = nullptr; p.wedges = nullptr;
     p.v0 = v0; p.nv = nv; p.s0 = s0; p.ns = ns; p.cfg_mask = cfg_mask; p.per = __builtin_popcount(cfg_mask);
     p.n_edges = (long long)nv * ns * p.per;
     p.out = d_results; p.child = d_child; p.stride = stride;
@@ -512,7 +538,7 @@ int ppgpu_cost_edges_list(ppgpu_ctx* c, int64_t n, const uint64_t* d_edges, ppgp
     if (d_child && stride <= 0) return fail(PPGPU_EINVAL, "cost_edges_list: ribbon_stride must be positive");
     PPParams p;
     fill_params(c, p);
-    p.edges = (const unsigned long long*)d_edges;
+    p.edges = (const unsigned long long*)d_edges; p.wedges = nullptr;
     p.v0 = 0; p.nv = 0; p.s0 = 0; p.ns = 1; p.cfg_mask = 0; p.per = 1;
     p.n_edges = n;
     p.out = d_results; p.child = d_child; p.stride = stride;
@@ -534,6 +560,38 @@ int ppgpu_cost_edges_host(ppgpu_ctx* c, int64_t n, const uint64_t* h_edges, ppgp
     if (h_child) HIP_TRY(hipMemsetAsync(c->tmp_child.p, 0, (size_t)n * stride * 4 * sizeof(double), c->stream));
     if ((rc = ppgpu_cost_edges_list(c, n, (const uint64_t*)c->tmp_edges.p, c->tmp_results.p, h_child ? c->tmp_child.p : nullptr, stride)))
         return rc;
+    HIP_TRY(hipMemcpyAsync(h_results, c->tmp_results.p, (size_t)n * sizeof(ppgpu_edge_result), hipMemcpyDeviceToHost, c->stream));
+    if (h_child)
+        HIP_TRY(hipMemcpyAsync(h_child, c->tmp_child.p, (size_t)n * stride * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PPGPU_OK;
+}
+
+int ppgpu_cost_wrapper_edges_host(ppgpu_ctx* c, int64_t n, const ppgpu_wrapper_edge* h_edges, ppgpu_edge_result* h_results,
+                                  double* h_child, int32_t stride) {
+    int rc = require_cfg(c);
+    if (rc) return rc;
+    if (c->nverts <= 0) return fail(PPGPU_ESTATE, "ppgpu_set_vertices must be called (after ppgpu_set_config)");
+    HIP_TRY(hipSetDevice(c->device));
+    if (n < 0 || (n > 0 && (!h_edges || !h_results))) return fail(PPGPU_EINVAL, "cost_wrapper_edges_host: bad arguments");
+    if (n == 0) return PPGPU_OK;
+    if (h_child && stride <= 0) return fail(PPGPU_EINVAL, "cost_wrapper_edges_host: ribbon_stride must be positive");
+    for (int64_t i = 0; i < n; i++) {
+        if (!(h_edges[i].rho > 0) || !(h_edges[i].speed > 0)) return fail(PPGPU_EINVAL, "cost_wrapper_edges_host: rho and speed must be positive");
+        if (h_edges[i].vertex < 0 || h_edges[i].vertex >= c->nverts) return fail(PPGPU_EINVAL, "cost_wrapper_edges_host: vertex out of range");
+    }
+    if ((rc = c->tmp_wedges.reserve((size_t)n, false, c->stream))) return rc;
+    if ((rc = c->tmp_results.reserve((size_t)n, false, c->stream))) return rc;
+    if (h_child && (rc = c->tmp_child.reserve((size_t)n * stride * 4, false, c->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->tmp_wedges.p, h_edges, (size_t)n * sizeof(ppgpu_wrapper_edge), hipMemcpyHostToDevice, c->stream));
+    if (h_child) HIP_TRY(hipMemsetAsync(c->tmp_child.p, 0, (size_t)n * stride * 4 * sizeof(double), c->stream));
+    PPParams p;
+    fill_params(c, p);
+    p.edges = nullptr; p.wedges = c->tmp_wedges.p;
+    p.v0 = 0; p.nv = 0; p.s0 = 0; p.ns = 1; p.cfg_mask = 0; p.per = 1;
+    p.n_edges = n;
+    p.out = c->tmp_results.p; p.child = h_child ? c->tmp_child.p : nullptr; p.stride = stride;
+    if ((rc = launch_cost(c, p))) return rc;
     HIP_TRY(hipMemcpyAsync(h_results, c->tmp_results.p, (size_t)n * sizeof(ppgpu_edge_result), hipMemcpyDeviceToHost, c->stream));
     if (h_child)
         HIP_TRY(hipMemcpyAsync(h_child, c->tmp_child.p, (size_t)n * stride * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));

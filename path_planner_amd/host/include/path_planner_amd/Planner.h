@@ -1,0 +1,106 @@
+// Planner / GpuAStarPlanner — the drop-in seam.
+//
+// Planner mirrors /root/reference/path_planner/src/planner/Planner.h:17-80 (same Stats fields, same plan() signature);
+// GpuAStarPlanner is AStarPlanner (AStarPlanner.cpp:12-148) + SamplingBasedPlanner::expand (SamplingBasedPlanner.cpp:52-151)
+// with every sample drawn, every Dubins length computed and every edge costed on the device through include/ppgpu.h.
+// The A* control flow, the open list and the clock polling stay on the host in the reference's order, so that with the same
+// injected clock and seed the same vertices are expanded in the same order.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "DubinsWrapper.h"
+#include "RibbonManager.h"
+#include "World.h"
+
+struct ppgpu_ctx;
+
+namespace ppamd {
+
+class Planner {
+public:
+    struct Stats {
+        unsigned long Samples = 0;
+        unsigned long Generated = 0;
+        unsigned long Expanded = 0;
+        unsigned long Iterations = 0;
+        double PlanFValue = 0;
+        double PlanCollisionPenalty = 0;
+        double PlanTimePenalty = 0;
+        double PlanHValue = 0;
+        unsigned long PlanDepth = 0;
+        DubinsPlan Plan;
+        // extra, for parity checks against the CPU oracle
+        long FirstGoalIteration = -1;
+        unsigned long EdgesCosted = 0;
+    };
+    Planner();
+    virtual ~Planner() = default;
+    virtual Stats plan(const RibbonManager& ribbonManager, const State& start, PlannerConfig config,
+                       const DubinsPlan& previousPlan, double timeRemaining);
+    void setConfig(PlannerConfig config) { m_Config = std::move(config); }
+
+protected:
+    double now() const { return m_Config.now(); }
+    PlannerConfig m_Config;
+    Stats m_Stats;
+};
+
+// Process-level device handle: stream, persistent buffers (the reference builds a new planner every cycle,
+// executive.cpp:85-90, so nothing device-side may live in the planner object).  Throws std::runtime_error.
+class GpuContext {
+public:
+    explicit GpuContext(int device = 0);
+    ~GpuContext();
+    GpuContext(const GpuContext&) = delete;
+    GpuContext& operator=(const GpuContext&) = delete;
+    ppgpu_ctx* handle() const { return m_Handle; }
+    static std::shared_ptr<GpuContext> shared(int device = 0);   // one per device per process
+
+private:
+    ppgpu_ctx* m_Handle = nullptr;
+};
+
+class GpuAStarPlanner : public Planner {
+public:
+    explicit GpuAStarPlanner(std::shared_ptr<GpuContext> ctx = GpuContext::shared()) : m_Ctx(std::move(ctx)) {}
+    Stats plan(const RibbonManager& ribbonManager, const State& start, PlannerConfig config, const DubinsPlan& previousPlan,
+               double timeRemaining) override;
+
+    // one search-tree node: what Vertex + its parent Edge hold in the reference (Vertex.h:180-187, Edge.h:133-143)
+    struct Node {
+        State state;
+        int parent = -1;
+        RibbonManager ribbons;
+        double g = -1, h = -1;
+        bool coverageAllowed = false;
+        bool infeasible = false;
+        double collisionPenalty = 0;
+        DubinsWrapper wrapper;     // parent edge's curve
+        double f() const { return g + h; }
+    };
+
+private:
+    std::shared_ptr<GpuContext> m_Ctx;
+    std::vector<Node> m_Nodes;
+    std::vector<int> m_Queue;      // binary heap of node indices, min f (AStarPlanner.cpp:6-10)
+    int m_Best = -1;
+    double m_StartStateTime = 0;
+    RibbonManager m_RibbonManager;
+    long m_NumSamples = 0;
+
+    void uploadWorld(const State& start);
+    void pushVertexQueue(int v);
+    int popVertexQueue();
+    bool goalCondition(const Node& v) const;
+    void expand(int source);
+    int aStar(double endTime);
+    void addSamples(long n);
+    int depth(int v) const;
+    DubinsPlan tracePlan(int v);
+    void check(int rc, const char* what) const;
+    int costStateEdges(int source, const std::vector<State>& targets, const std::vector<unsigned>& cfgBits,
+                       const std::vector<long>& sampleIndex);
+};
+
+}  // namespace ppamd

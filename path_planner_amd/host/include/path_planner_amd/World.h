@@ -1,0 +1,141 @@
+// Map / GridWorldMap / DynamicObstaclesManager / BinaryDynamicObstaclesManager / PlannerConfig — host mirrors of
+//   /root/reference/path_planner/src/common/map/{Map,GridWorldMap}.{h,cpp}
+//   /root/reference/path_planner/src/common/dynamic_obstacles/{DynamicObstaclesManager,BinaryDynamicObstaclesManager}.{h,cpp}
+//   /root/reference/path_planner/src/planner/PlannerConfig.h
+// The planner uploads snapshots of them to the device at the start of every plan() call.
+#pragma once
+#include <cfloat>
+#include <cstdint>
+#include <functional>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "State.h"
+
+namespace ppamd {
+
+class Map {
+public:
+    typedef std::shared_ptr<Map> SharedPtr;
+    virtual ~Map() = default;
+    virtual bool isBlocked(double x, double y) const { return false; }        // Map.cpp:4-6
+    virtual const double* extremes() const { return m_Extremes; }             // Map.cpp:8-10
+    virtual double resolution() const { return 0; }                           // Map.cpp:12-14
+    // Occupancy as a byte grid for the device (row 0 = y in [0,res)).  The base map has none (rows = 0).
+    // Any subclass that only implements isBlocked/extremes/resolution is rasterised cell centre by cell centre.
+    virtual void rasterize(std::vector<uint8_t>& cells, int& rows, int& cols, double& res) const;
+
+private:
+    double m_Extremes[4] = {-DBL_MAX, DBL_MAX, -DBL_MAX, DBL_MAX};
+};
+
+class GridWorldMap : public Map {
+public:
+    explicit GridWorldMap(const std::string& path);                           // GridWorldMap.cpp:10-82
+    static std::shared_ptr<GridWorldMap> fromText(const std::string& text);
+    bool isBlocked(double x, double y) const override;                        // :84-93
+    const double* extremes() const override { return m_Extremes; }
+    double resolution() const override { return m_Resolution; }
+    void rasterize(std::vector<uint8_t>& cells, int& rows, int& cols, double& res) const override;
+
+private:
+    GridWorldMap() = default;
+    void load(std::istream& in);
+    std::vector<std::vector<bool>> m_Blocked;
+    double m_Resolution = 0;
+    double m_Extremes[4] = {0, 0, 0, 0};
+};
+
+class DynamicObstaclesManager {
+public:
+    typedef std::shared_ptr<DynamicObstaclesManager> SharedPtr;
+    virtual ~DynamicObstaclesManager() = default;
+    virtual double collisionExists(double x, double y, double time, bool strict) const { return 0; }
+    double collisionExists(const State& s, bool strict) const { return collisionExists(s.x(), s.y(), s.time(), strict); }
+    // device snapshot: model id (PPGPU_OBST_*) and rows of {x, y, heading, speed, time, width, length}
+    virtual int deviceModel() const { return 0; }
+    virtual void deviceRows(std::vector<double>& rows7) const { rows7.clear(); }
+};
+
+class BinaryDynamicObstaclesManager : public DynamicObstaclesManager {
+public:
+    typedef std::shared_ptr<BinaryDynamicObstaclesManager> SharedPtr;
+    struct Obstacle {
+        double X, Y, Yaw, Speed, Time, Width, Length, Heading;
+        Obstacle(double x, double y, double heading, double speed, double time, double width, double length)
+            : X(x), Y(y), Yaw(M_PI_2 - heading), Speed(speed), Time(time), Width(width), Length(length), Heading(heading) {}
+        void project(double desiredTime) {
+            double dt = desiredTime - Time;
+            double dx = Speed * dt * std::cos(Yaw);
+            double dy = Speed * dt * std::sin(Yaw);
+            X += dx; Y += dy;
+        }
+    };
+    void update(uint32_t mmsi, double x, double y, double heading, double speed, double time, double width, double length);
+    void forget(uint32_t mmsi) { m_Obstacles.erase(mmsi); }
+    void addIgnore(uint32_t mmsi) { m_Ignored.emplace(mmsi); }
+    void removeIgnore(uint32_t mmsi) { m_Ignored.erase(mmsi); }
+    double collisionExists(double x, double y, double time, bool strict) const override;   // .cpp:4-22
+    const std::unordered_map<uint32_t, Obstacle>& get() const { return m_Obstacles; }
+    int deviceModel() const override { return 1; }
+    void deviceRows(std::vector<double>& rows7) const override;
+
+private:
+    std::unordered_map<uint32_t, Obstacle> m_Obstacles;
+    std::unordered_set<uint32_t> m_Ignored;
+};
+
+class PlannerConfig {
+public:
+    explicit PlannerConfig(std::ostream* output) : m_Output(output) {}
+    int branchingFactor() const { return m_BranchingFactor; }
+    void setBranchingFactor(int b) { m_BranchingFactor = b; }
+    double maxSpeed() const { return m_MaxSpeed; }
+    void setMaxSpeed(double s) { m_MaxSpeed = s; }
+    double turningRadius() const { return m_TurningRadius; }
+    void setTurningRadius(double r) { m_TurningRadius = r; }
+    double coverageTurningRadius() const { return m_CoverageTurningRadius; }
+    void setCoverageTurningRadius(double r) { m_CoverageTurningRadius = r; }
+    const Map::SharedPtr& map() const { return m_Map; }
+    void setMap(const Map::SharedPtr& m) { m_Map = m; }
+    const DynamicObstaclesManager& obstaclesManager() const { return *m_ObstaclesManager; }
+    void setObstaclesManager(DynamicObstaclesManager::SharedPtr m) { m_ObstaclesManager = std::move(m); }
+    std::ostream* output() const { return m_Output; }
+    void setNowFunction(const std::function<double()>& f) { m_NowFunction = f; }
+    double now() const { return m_NowFunction(); }
+    double startStateTime() const { return m_StartStateTime; }
+    void setStartStateTime(double t) { m_StartStateTime = t; }
+    double timeHorizon() const { return m_TimeHorizon; }
+    void setTimeHorizon(double t) { m_TimeHorizon = t; }
+    bool useBrownPaths() const { return m_UseBrownPaths; }
+    void setUseBrownPaths(bool b) { m_UseBrownPaths = b; }
+    int initialSamples() const { return m_InitialSamples; }
+    void setInitialSamples(int n) { m_InitialSamples = n; }
+    double collisionCheckingIncrement() const { return m_CollisionCheckingIncrement; }
+    void setCollisionCheckingIncrement(double d) { m_CollisionCheckingIncrement = d; }
+    double timeMinimum() const { return m_TimeMinimum; }
+    void setTimeMinimum(double t) { m_TimeMinimum = t; }
+    double slowSpeed() const { return m_SlowSpeed <= 0 ? m_MaxSpeed : m_SlowSpeed; }
+    void setSlowSpeed(double s) { m_SlowSpeed = s; }
+    // the reference's visualisation stream is not available on the device path
+    bool visualizations() const { return false; }
+
+private:
+    int m_BranchingFactor = 9;
+    double m_MaxSpeed = 2.5, m_SlowSpeed = 0.5, m_TurningRadius = 8, m_CoverageTurningRadius = 16;
+    double m_TimeHorizon = 30, m_TimeMinimum = 5;
+    double m_CollisionCheckingIncrement = 0.05;
+    int m_InitialSamples = 100;
+    bool m_UseBrownPaths = false;
+    Map::SharedPtr m_Map;
+    DynamicObstaclesManager::SharedPtr m_ObstaclesManager = std::make_shared<DynamicObstaclesManager>();
+    std::ostream* m_Output;
+    std::function<double()> m_NowFunction;
+    double m_StartStateTime = 0;
+};
+
+}  // namespace ppamd

@@ -1,0 +1,446 @@
+// planner.cpp — Planner / GpuContext / GpuAStarPlanner (see include/path_planner_amd/Planner.h).
+//
+// Control flow follows /root/reference/path_planner/src/planner/AStarPlanner.cpp:12-148 and
+// SamplingBasedPlanner.cpp:7-27,42-151 line by line, including where the clock is polled; the data-parallel work
+// (sampling, Dubins lengths to every sample, k-nearest selection, edge costing with coverage/heuristic) is done by the
+// device library behind include/ppgpu.h.  Any device error becomes std::runtime_error, which Executive::planLoop
+// catches like any other planner exception (executive.cpp:191-195).
+#include "path_planner_amd/Planner.h"
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+#include "../../../include/ppgpu.h"
+
+namespace ppamd {
+
+static const double kTimePenaltyFactor = 1;       // Edge::timePenaltyFactor() (Edge.h:152)
+static const double kCollisionPenaltyFactor = 600;  // Edge::collisionPenaltyFactor() (Edge.h:151)
+static const int kRibbonStride = 64;              // child ribbon capacity per edge = the device's per-vertex limit
+
+Planner::Planner() : m_Config(PlannerConfig(&std::cerr)) {}
+
+Planner::Stats Planner::plan(const RibbonManager&, const State&, PlannerConfig config, const DubinsPlan&, double) {
+    m_Config = std::move(config);
+    throw std::runtime_error("Ribbon point-to-point planner is not yet implemented");   // Planner.cpp:41-45
+}
+
+// ------------------------------------------------------------------------------------------------ GpuContext
+GpuContext::GpuContext(int device) {
+    if (ppgpu_create(device, &m_Handle) != PPGPU_OK) throw std::runtime_error(std::string("ppgpu_create: ") + ppgpu_last_error());
+}
+GpuContext::~GpuContext() { ppgpu_destroy(m_Handle); }
+
+std::shared_ptr<GpuContext> GpuContext::shared(int device) {
+    static std::mutex mtx;
+    static std::map<int, std::weak_ptr<GpuContext>> cache;
+    std::lock_guard<std::mutex> lock(mtx);
+    auto sp = cache[device].lock();
+    if (!sp) {
+        sp = std::make_shared<GpuContext>(device);
+        cache[device] = sp;
+    }
+    return sp;
+}
+
+// ------------------------------------------------------------------------------------------------ helpers
+void GpuAStarPlanner::check(int rc, const char* what) const {
+    if (rc != PPGPU_OK) throw std::runtime_error(std::string(what) + ": " + ppgpu_last_error());
+}
+
+static void ribbonsToArray(const RibbonManager& rm, std::vector<double>& out) {
+    out.clear();
+    for (const auto& r : rm.get()) out.insert(out.end(), {r.start().first, r.start().second, r.end().first, r.end().second});
+}
+
+static ppgpu_vertex makeVertex(const GpuAStarPlanner::Node& n) {
+    ppgpu_vertex v;
+    v.x = n.state.x(); v.y = n.state.y(); v.heading = n.state.heading(); v.speed = n.state.speed(); v.time = n.state.time();
+    v.g = n.g;
+    v.coverage_completed_time = n.ribbons.coverageCompletedTime();
+    v.ribbon_offset = 0;
+    v.ribbon_count = (int32_t)n.ribbons.get().size();
+    return v;
+}
+
+int GpuAStarPlanner::depth(int v) const {
+    int d = 0;
+    for (int p = m_Nodes[v].parent; p >= 0; p = m_Nodes[p].parent) d++;
+    return d;
+}
+
+// ------------------------------------------------------------------------------------------------ world upload
+void GpuAStarPlanner::uploadWorld(const State& start) {
+    ppgpu_ctx* h = m_Ctx->handle();
+    ppgpu_config c{};
+    c.max_speed = m_Config.maxSpeed();
+    c.slow_speed = m_Config.slowSpeed();
+    c.turning_radius = m_Config.turningRadius();
+    c.coverage_turning_radius = m_Config.coverageTurningRadius();
+    c.time_horizon = m_Config.timeHorizon();
+    c.time_minimum = m_Config.timeMinimum();
+    c.collision_checking_increment = m_Config.collisionCheckingIncrement();
+    c.start_state_time = start.time();
+    c.ribbon_width = Ribbon::RibbonWidth;
+    c.collision_penalty_factor = kCollisionPenaltyFactor;
+    c.time_penalty_factor = kTimePenaltyFactor;
+    c.heuristic_turning_radius = m_RibbonManager.turningRadius();
+    c.heuristic = (int32_t)m_RibbonManager.heuristic();
+    c.tsp_k = m_RibbonManager.k();
+    c.branching_factor = m_Config.branchingFactor();
+    check(ppgpu_set_config(h, &c), "ppgpu_set_config");
+
+    std::vector<uint8_t> cells;
+    int rows = 0, cols = 0;
+    double res = 0;
+    if (m_Config.map()) m_Config.map()->rasterize(cells, rows, cols, res);
+    check(ppgpu_set_grid(h, rows ? cells.data() : nullptr, rows, cols, res), "ppgpu_set_grid");
+
+    std::vector<double> rows7;
+    const DynamicObstaclesManager& om = m_Config.obstaclesManager();
+    om.deviceRows(rows7);
+    check(ppgpu_set_obstacles(h, om.deviceModel(), (int32_t)(rows7.size() / 7), rows7.empty() ? nullptr : rows7.data()),
+          "ppgpu_set_obstacles");
+}
+
+// ------------------------------------------------------------------------------------------------ open list
+void GpuAStarPlanner::pushVertexQueue(int vi) {   // SamplingBasedPlanner.cpp:7-19
+    Node& v = m_Nodes[vi];
+    if (v.parent >= 0 && v.infeasible) return;
+    if (v.h == -1) throw std::runtime_error("Fetching unset approx to go (h)");
+    if (m_Best >= 0 && m_Nodes[m_Best].f() < v.f()) return;
+    if (m_Best >= 0 && m_Nodes[m_Best].f() == v.f() && goalCondition(v)) return;
+    m_Queue.push_back(vi);
+    std::push_heap(m_Queue.begin(), m_Queue.end(), [&](int a, int b) { return m_Nodes[a].f() > m_Nodes[b].f(); });
+    m_Stats.Generated++;
+}
+
+int GpuAStarPlanner::popVertexQueue() {   // :21-27
+    if (m_Queue.empty()) throw std::out_of_range("Trying to pop an empty vertex queue");
+    std::pop_heap(m_Queue.begin(), m_Queue.end(), [&](int a, int b) { return m_Nodes[a].f() > m_Nodes[b].f(); });
+    int r = m_Queue.back();
+    m_Queue.pop_back();
+    return r;
+}
+
+bool GpuAStarPlanner::goalCondition(const Node& v) const {   // :42-50
+    double coverageDoneTime = v.ribbons.coverageCompletedTime() + m_Config.timeMinimum();
+    if (v.ribbons.coverageCompletedTime() == -1 && v.ribbons.done())
+        throw std::runtime_error("Unset coverage completed time but coverage is done");
+    double nonCoverageDoneTime = m_StartStateTime + m_Config.timeHorizon();
+    return v.state.time() >= nonCoverageDoneTime || (v.ribbons.done() && v.state.time() >= coverageDoneTime);
+}
+
+// ------------------------------------------------------------------------------------------------ sampling
+void GpuAStarPlanner::addSamples(long n) {   // SamplingBasedPlanner::addSamples (:157-168)
+    int64_t total = 0;
+    long left = n;
+    while (left > 0) {   // the device sampler takes at most 524288 attempts per call
+        long chunk = std::min<long>(left, 524288);
+        check(ppgpu_sampler_add(m_Ctx->handle(), chunk, &total), "ppgpu_sampler_add");
+        left -= chunk;
+    }
+    if (n > 0) m_NumSamples = (long)total;
+}
+
+// ------------------------------------------------------------------------------------------------ edges
+// Vertex::connect(source, state, radius, coverageAllowed) + Edge::computeTrueCost for a batch of targets, then
+// pushVertexQueue in the given order.  sampleIndex[i] >= 0 uses a stored sample, otherwise targets[i] is uploaded.
+int GpuAStarPlanner::costStateEdges(int source, const std::vector<State>& targets, const std::vector<unsigned>& cfgBits,
+                                    const std::vector<long>& sampleIndex) {
+    const size_t n = cfgBits.size();
+    if (n == 0) return 0;
+    ppgpu_ctx* h = m_Ctx->handle();
+    std::vector<double> ex, ey, eh;
+    std::vector<long> extraSlot(n, -1);
+    for (size_t i = 0; i < n; i++) {
+        if (sampleIndex[i] < 0) {
+            extraSlot[i] = (long)ex.size();
+            ex.push_back(targets[i].x()); ey.push_back(targets[i].y()); eh.push_back(targets[i].heading());
+        }
+    }
+    int64_t first = m_NumSamples;
+    check(ppgpu_set_extra_targets(h, (int32_t)ex.size(), ex.data(), ey.data(), eh.data(), &first), "ppgpu_set_extra_targets");
+    std::vector<uint64_t> edges(n);
+    for (size_t i = 0; i < n; i++) {
+        uint32_t tgt = (uint32_t)(sampleIndex[i] >= 0 ? sampleIndex[i] : first + extraSlot[i]);
+        edges[i] = ppgpu_edge_pack(0, tgt, cfgBits[i]);
+    }
+    std::vector<ppgpu_edge_result> res(n);
+    std::vector<double> child(n * (size_t)kRibbonStride * 4);
+    check(ppgpu_cost_edges_host(h, (int64_t)n, edges.data(), res.data(), child.data(), kRibbonStride), "ppgpu_cost_edges_host");
+    m_Stats.EdgesCosted += n;
+    const Node src = m_Nodes[source];
+    for (size_t i = 0; i < n; i++) {
+        const ppgpu_edge_result& r = res[i];
+        if (r.flags & PPGPU_F_THROWS) throw std::runtime_error("Edge cost evaluation failed: invalid time in sample for Dubins path");
+        if (r.flags & (PPGPU_F_RIBBON_OVF | PPGPU_F_DUBINS_ERR)) throw std::runtime_error("Edge cost evaluation exceeded a device capacity");
+        Node c;
+        c.parent = source;
+        c.state = State(r.end_x, r.end_y, r.end_heading, r.end_speed, r.end_time);
+        c.coverageAllowed = (cfgBits[i] & PPGPU_EDGE_COVERAGE) != 0;
+        c.infeasible = (r.flags & PPGPU_F_INFEASIBLE) != 0;
+        c.collisionPenalty = r.collision_penalty;
+        c.g = r.g;
+        c.h = r.h;
+        c.ribbons = src.ribbons;   // keeps heuristic, K, turning radius
+        c.ribbons.assign(child.data() + i * (size_t)kRibbonStride * 4, (int)((r.info >> 8) & 0xff), r.coverage_completed_time);
+        DubinsPath p;
+        p.qi[0] = src.state.x(); p.qi[1] = src.state.y(); p.qi[2] = src.state.yaw();
+        p.param[0] = r.param[0]; p.param[1] = r.param[1]; p.param[2] = r.param[2];
+        p.rho = c.coverageAllowed ? m_Config.coverageTurningRadius() : m_Config.turningRadius();
+        p.type = (DubinsPathType)(r.info & 0xff);
+        c.wrapper.fill(p, r.end_speed, src.state.time());
+        if (!c.infeasible && r.end_time < c.wrapper.getEndTime()) c.wrapper.updateEndTime(r.end_time);   // Edge.cpp:179
+        m_Nodes.push_back(std::move(c));
+        pushVertexQueue((int)m_Nodes.size() - 1);
+    }
+    return (int)n;
+}
+
+void GpuAStarPlanner::expand(int source) {   // SamplingBasedPlanner::expand (:52-151)
+    ppgpu_ctx* h = m_Ctx->handle();
+    const double speeds[2] = {m_Config.maxSpeed(), m_Config.maxSpeed() == m_Config.slowSpeed() ? -1 : m_Config.slowSpeed()};
+    const double radii[2] = {m_Config.turningRadius(),
+                             m_Config.coverageTurningRadius() == m_Config.turningRadius() ? -1 : m_Config.coverageTurningRadius()};
+    // this vertex becomes the device's open-vertex array (one entry)
+    {
+        ppgpu_vertex v = makeVertex(m_Nodes[source]);
+        std::vector<double> rib;
+        ribbonsToArray(m_Nodes[source].ribbons, rib);
+        check(ppgpu_set_vertices(h, 1, &v, v.ribbon_count, rib.empty() ? nullptr : rib.data()), "ppgpu_set_vertices");
+    }
+    std::vector<State> targets;
+    std::vector<unsigned> cfg;
+    std::vector<long> sidx;
+    // nearest point to cover (:64-81)
+    if (!m_Nodes[source].ribbons.done()) {
+        State s = m_Nodes[source].ribbons.getNearestEndpointAsState(m_Nodes[source].state);
+        if (m_Nodes[source].state.distanceTo(s) > m_Config.collisionCheckingIncrement()) {
+            for (int si = 0; si < 2; si++) {
+                if (speeds[si] <= 0) continue;
+                for (int ri = 0; ri < 2; ri++) {
+                    if (radii[ri] <= 0) continue;
+                    bool coverageAllowed = radii[ri] == m_Config.coverageTurningRadius();
+                    targets.push_back(s);
+                    cfg.push_back((coverageAllowed ? PPGPU_EDGE_COVERAGE : 0u) | (si == 1 ? PPGPU_EDGE_SLOW : 0u));
+                    sidx.push_back(-1);
+                }
+            }
+        }
+    }
+    // k best samples by Dubins length per radius (:85-133), then every winner at every speed (:134-149)
+    const int k = m_Config.branchingFactor();
+    if (m_NumSamples > 0 && k > 0) {
+        std::vector<int32_t> idx(2 * (size_t)k);
+        std::vector<double> len(2 * (size_t)k);
+        check(ppgpu_select_nearest(h, 0, 1, k, idx.data(), len.data()), "ppgpu_select_nearest");
+        for (int ri = 0; ri < 2; ri++) {
+            if (radii[ri] <= 0) continue;
+            bool coverageAllowed = radii[ri] == m_Config.coverageTurningRadius();
+            // slot 1 of the device result is always the coverage radius; with equal radii slot 0 IS the coverage radius
+            const int slot = (ri == 1) ? 1 : 0;
+            for (int j = 0; j < k; j++) {
+                int32_t s = idx[(size_t)slot * k + j];
+                if (s < 0) break;
+                for (int si = 0; si < 2; si++) {
+                    if (speeds[si] <= 0) continue;
+                    targets.emplace_back();
+                    cfg.push_back((coverageAllowed ? PPGPU_EDGE_COVERAGE : 0u) | (si == 1 ? PPGPU_EDGE_SLOW : 0u));
+                    sidx.push_back(s);
+                }
+            }
+        }
+    }
+    costStateEdges(source, targets, cfg, sidx);
+    m_Stats.Expanded++;
+}
+
+int GpuAStarPlanner::aStar(double endTime) {   // AStarPlanner.cpp:134-148
+    int vertex = popVertexQueue();
+    while (now() < endTime) {
+        if (goalCondition(m_Nodes[vertex])) return vertex;
+        expand(vertex);
+        if (m_Queue.empty()) return -1;
+        vertex = popVertexQueue();
+    }
+    return -1;
+}
+
+DubinsPlan GpuAStarPlanner::tracePlan(int v) {   // Planner.cpp:12-32
+    DubinsPlan plan;
+    if (v < 0) return plan;
+    std::vector<int> branch;
+    bool dangerous = false;
+    for (int cur = v; m_Nodes[cur].parent >= 0; cur = m_Nodes[cur].parent) {
+        branch.push_back(cur);
+        if (m_Nodes[cur].collisionPenalty > 0) {
+            dangerous = true;
+            m_Stats.PlanCollisionPenalty += m_Nodes[cur].collisionPenalty;
+        }
+    }
+    plan.setDangerous(dangerous);
+    for (auto it = branch.rbegin(); it != branch.rend(); it++) plan.append(m_Nodes[*it].wrapper);
+    return plan;
+}
+
+// ------------------------------------------------------------------------------------------------ plan()
+Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const State& start, PlannerConfig config,
+                                     const DubinsPlan& previousPlan, double timeRemaining) {   // AStarPlanner.cpp:12-132
+    m_Config = std::move(config);
+    double endTime = timeRemaining + now();
+    m_Config.setStartStateTime(start.time());
+    m_RibbonManager = ribbonManager;
+    m_RibbonManager.changeHeuristicIfTooManyRibbons();
+    if (m_RibbonManager.done()) m_RibbonManager.setCoverageCompletedTime(start.time());
+    m_Stats = Stats();
+    m_StartStateTime = start.time();
+    m_Nodes.clear();
+    m_Queue.clear();
+    m_NumSamples = 0;
+    ppgpu_ctx* h = m_Ctx->handle();
+    uploadWorld(start);
+
+    double minSpeed = m_Config.maxSpeed(), maxSpeed = m_Config.maxSpeed();
+    double magnitude = m_Config.maxSpeed() * m_Config.timeHorizon();
+    const double* mapExtremes = m_Config.map() ? m_Config.map()->extremes() : Map().extremes();
+    double bounds[6];
+    bounds[0] = std::fmax(start.x() - magnitude, mapExtremes[0]);
+    bounds[1] = std::fmin(start.x() + magnitude, mapExtremes[1]);
+    bounds[2] = std::fmax(start.y() - magnitude, mapExtremes[2]);
+    bounds[3] = std::fmin(start.y() + magnitude, mapExtremes[3]);
+    bounds[4] = minSpeed; bounds[5] = maxSpeed;
+    unsigned long seed = (unsigned long)endTime;   // :33
+    {
+        std::vector<double> rib;
+        ribbonsToArray(m_RibbonManager, rib);
+        check(ppgpu_sampler_init(h, bounds, seed, (int32_t)(rib.size() / 4), rib.empty() ? nullptr : rib.data()), "ppgpu_sampler_init");
+    }
+    // root (:35-37)
+    Node root;
+    root.state = start;
+    root.state.speed() = m_Config.maxSpeed();
+    root.g = 0;
+    root.ribbons = m_RibbonManager;
+    root.h = root.ribbons.approximateDistanceUntilDone(root.state.x(), root.state.y(), root.state.heading()) / m_Config.maxSpeed() *
+             kTimePenaltyFactor;   // Vertex::computeApproxToGo (Vertex.cpp:49-64), once per plan, on the host
+    m_Nodes.push_back(root);
+    const int startV = 0;
+    m_Best = -1;
+    std::vector<State> brownPathSamples;
+    if (m_Config.useBrownPaths()) brownPathSamples = m_RibbonManager.findNearStatesOnRibbons(start, m_Config.coverageTurningRadius());
+
+    // collision check old plan (:46-59)
+    int lastPlanEnd = startV;
+    if (!previousPlan.empty()) {
+        for (const auto& p : previousPlan.get()) {
+            if (p.getEndTime() <= start.time()) continue;
+            if (p.getNetTime() == 0) continue;
+            const bool cov = p.getRho() == m_Config.coverageTurningRadius();
+            const double expectRho = cov ? m_Config.coverageTurningRadius() : m_Config.turningRadius();
+            ppgpu_vertex v = makeVertex(m_Nodes[lastPlanEnd]);
+            std::vector<double> rib;
+            ribbonsToArray(m_Nodes[lastPlanEnd].ribbons, rib);
+            check(ppgpu_set_vertices(h, 1, &v, v.ribbon_count, rib.empty() ? nullptr : rib.data()), "ppgpu_set_vertices");
+            const size_t before = m_Nodes.size();
+            if (p.getRho() != expectRho) {
+                // Edge.cpp:78-80: a curve at a radius the configuration no longer has is re-solved to the wrapper's end state
+                State s;
+                s.time() = p.getEndTime();
+                p.sample(s);
+                std::vector<State> t{s};
+                std::vector<unsigned> c{(s.speed() == m_Config.maxSpeed() ? 0u : PPGPU_EDGE_SLOW)};
+                std::vector<long> si{-1};
+                const size_t q = m_Queue.size();
+                const unsigned long gen = m_Stats.Generated;
+                costStateEdges(lastPlanEnd, t, c, si);
+                m_Queue.resize(q);   // connect + computeTrueCost only: the reference does not push here
+                std::make_heap(m_Queue.begin(), m_Queue.end(), [&](int a, int b) { return m_Nodes[a].f() > m_Nodes[b].f(); });
+                m_Stats.Generated = gen;
+            } else {
+                ppgpu_wrapper_edge we{};
+                we.vertex = 0;
+                we.coverage_allowed = cov ? 1 : 0;
+                const DubinsPath& dp = p.unwrap();
+                for (int i = 0; i < 3; i++) { we.qi[i] = dp.qi[i]; we.param[i] = dp.param[i]; }
+                we.rho = dp.rho; we.type = (int32_t)dp.type;
+                we.speed = p.getSpeed(); we.start_time = p.curveStartTime(); we.end_time = p.getEndTime();
+                ppgpu_edge_result r;
+                std::vector<double> child((size_t)kRibbonStride * 4);
+                check(ppgpu_cost_wrapper_edges_host(h, 1, &we, &r, child.data(), kRibbonStride), "ppgpu_cost_wrapper_edges_host");
+                m_Stats.EdgesCosted++;
+                if (r.flags & PPGPU_F_THROWS) throw std::runtime_error("Invalid time in sample for Dubins path (previous plan)");
+                if (r.flags & (PPGPU_F_RIBBON_OVF | PPGPU_F_DUBINS_ERR)) throw std::runtime_error("Edge cost evaluation exceeded a device capacity");
+                Node c;
+                c.parent = lastPlanEnd;
+                c.state = State(r.end_x, r.end_y, r.end_heading, r.end_speed, r.end_time);
+                c.coverageAllowed = cov;
+                c.infeasible = (r.flags & PPGPU_F_INFEASIBLE) != 0;
+                c.collisionPenalty = r.collision_penalty;
+                c.g = r.g; c.h = r.h;
+                c.ribbons = m_Nodes[lastPlanEnd].ribbons;
+                c.ribbons.assign(child.data(), (int)((r.info >> 8) & 0xff), r.coverage_completed_time);
+                c.wrapper = p;
+                if (!c.infeasible && r.end_time < c.wrapper.getEndTime()) c.wrapper.updateEndTime(r.end_time);
+                m_Nodes.push_back(std::move(c));
+            }
+            if (m_Nodes.size() == before) break;
+            lastPlanEnd = (int)m_Nodes.size() - 1;
+            if (m_Nodes[lastPlanEnd].infeasible) {
+                lastPlanEnd = startV;
+                break;
+            }
+            if (goalCondition(m_Nodes[lastPlanEnd])) break;
+        }
+    }
+
+    // big loop (:61-119)
+    while (now() < endTime) {
+        m_Queue.clear();
+        if (m_Best >= 0 && m_Nodes[m_Best].f() <= m_Nodes[startV].f()) {
+            *m_Config.output() << "Found best possible plan, assuming heuristic admissibility" << std::endl;
+            break;
+        }
+        pushVertexQueue(startV);
+        if (lastPlanEnd != startV) pushVertexQueue(lastPlanEnd);
+        // expandToCoverSpecificSamples(startV, brownPathSamples, ..., true) (:150-162)
+        if (!brownPathSamples.empty() && m_Config.coverageTurningRadius() > 0) {
+            ppgpu_vertex v = makeVertex(m_Nodes[startV]);
+            std::vector<double> rib;
+            ribbonsToArray(m_Nodes[startV].ribbons, rib);
+            check(ppgpu_set_vertices(h, 1, &v, v.ribbon_count, rib.empty() ? nullptr : rib.data()), "ppgpu_set_vertices");
+            std::vector<State> t;
+            std::vector<unsigned> c;
+            std::vector<long> si;
+            for (const State& s : brownPathSamples) {
+                t.push_back(s); c.push_back(PPGPU_EDGE_COVERAGE); si.push_back(-1);
+                t.push_back(s); c.push_back(PPGPU_EDGE_COVERAGE | PPGPU_EDGE_SLOW); si.push_back(-1);
+            }
+            costStateEdges(startV, t, c, si);
+        }
+        // first iteration: initialSamples; afterwards double them (:101-102)
+        if (m_NumSamples < m_Config.initialSamples()) addSamples(m_Config.initialSamples());
+        else addSamples(m_NumSamples);
+        int v = aStar(endTime);
+        if (m_Best < 0 || (v >= 0 && m_Nodes[v].f() + 0.0 < m_Nodes[m_Best].f())) m_Best = v;
+        if (v >= 0 && m_Stats.FirstGoalIteration < 0) m_Stats.FirstGoalIteration = (long)m_Stats.Iterations;
+        m_Stats.Iterations++;
+    }
+    m_Stats.Samples = (unsigned long)m_NumSamples;
+    if (m_Best < 0) {
+        *m_Config.output() << "Failed to find a plan" << std::endl;
+    } else {
+        m_Stats.PlanFValue = m_Nodes[m_Best].f();
+        m_Stats.PlanDepth = (unsigned long)depth(m_Best);
+        m_Stats.PlanTimePenalty = (m_Nodes[m_Best].state.time() - m_StartStateTime) * kTimePenaltyFactor;
+        m_Stats.PlanHValue = m_Nodes[m_Best].h;
+        m_Stats.Plan = tracePlan(m_Best);
+    }
+    return m_Stats;
+}
+
+}  // namespace ppamd

@@ -1,0 +1,102 @@
+// plan_cli — drives GpuAStarPlanner::plan() from a small text scenario and prints the Stats as JSON.
+// Used by tests/test_gpu_host_planner.py to compare the C++ host path with the CPU oracle's AStarPlanner::plan
+// under the same injected clock (PlannerConfig::setNowFunction).
+//
+// Scenario lines:  cfg <key> <value> | start x y heading speed time | ribbon x1 y1 x2 y2 | heuristic H K radius |
+//                  ribbon_width w | obstacle x y heading speed time width length | map_file path | clock t0 dt |
+//                  time_remaining T | prev qi0 qi1 qi2 p0 p1 p2 rho type speed start end | repeat n
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "path_planner_amd/Planner.h"
+
+using namespace ppamd;
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::fprintf(stderr, "usage: plan_cli scenario.txt\n"); return 2; }
+    std::ifstream in(argv[1]);
+    if (!in) { std::fprintf(stderr, "cannot open %s\n", argv[1]); return 2; }
+    PlannerConfig config(&std::cerr);
+    State start;
+    int H = 0, K = 0;
+    double hr = 8;
+    std::vector<std::array<double, 4>> ribs;
+    auto obst = std::make_shared<BinaryDynamicObstaclesManager>();
+    bool haveObst = false;
+    Map::SharedPtr map = std::make_shared<Map>();
+    double t0 = 1000, dt = 1e-3, timeRemaining = 0.05;
+    DubinsPlan prev;
+    int repeat = 1;
+    uint32_t mmsi = 1;
+    std::string line;
+    while (std::getline(in, line)) {
+        std::istringstream s(line);
+        std::string k;
+        if (!(s >> k)) continue;
+        if (k == "cfg") {
+            std::string name; double v; s >> name >> v;
+            if (name == "max_speed") config.setMaxSpeed(v);
+            else if (name == "slow_speed") config.setSlowSpeed(v);
+            else if (name == "turning_radius") config.setTurningRadius(v);
+            else if (name == "coverage_turning_radius") config.setCoverageTurningRadius(v);
+            else if (name == "time_horizon") config.setTimeHorizon(v);
+            else if (name == "time_minimum") config.setTimeMinimum(v);
+            else if (name == "collision_checking_increment") config.setCollisionCheckingIncrement(v);
+            else if (name == "branching_factor") config.setBranchingFactor((int)v);
+            else if (name == "initial_samples") config.setInitialSamples((int)v);
+            else if (name == "use_brown_paths") config.setUseBrownPaths(v != 0);
+            else { std::fprintf(stderr, "unknown cfg %s\n", name.c_str()); return 2; }
+        } else if (k == "start") {
+            double x, y, h, v, t; s >> x >> y >> h >> v >> t; start = State(x, y, h, v, t);
+        } else if (k == "ribbon") {
+            std::array<double, 4> r; s >> r[0] >> r[1] >> r[2] >> r[3]; ribs.push_back(r);
+        } else if (k == "heuristic") { s >> H >> K >> hr;
+        } else if (k == "ribbon_width") { double w; s >> w; RibbonManager::setRibbonWidth(w);
+        } else if (k == "obstacle") {
+            double x, y, h, v, t, w, l; s >> x >> y >> h >> v >> t >> w >> l; obst->update(mmsi++, x, y, h, v, t, w, l); haveObst = true;
+        } else if (k == "map_file") { std::string p; s >> p; map = std::make_shared<GridWorldMap>(p);
+        } else if (k == "clock") { s >> t0 >> dt;
+        } else if (k == "time_remaining") { s >> timeRemaining;
+        } else if (k == "repeat") { s >> repeat;
+        } else if (k == "prev") {
+            DubinsPath p; double speed, st, en; int type;
+            s >> p.qi[0] >> p.qi[1] >> p.qi[2] >> p.param[0] >> p.param[1] >> p.param[2] >> p.rho >> type >> speed >> st >> en;
+            p.type = (DubinsPathType)type;
+            DubinsWrapper w; w.fill(p, speed, st);
+            if (w.getEndTime() > en) w.updateEndTime(en);
+            prev.append(w);
+        }
+    }
+    RibbonManager rm((RibbonManager::Heuristic)H, hr, K);
+    for (auto& r : ribs) rm.add(r[0], r[1], r[2], r[3]);
+    config.setMap(map);
+    if (haveObst) config.setObstaclesManager(obst);
+    try {
+        Planner::Stats st;
+        for (int rep = 0; rep < repeat; rep++) {
+            long calls = 0;
+            config.setNowFunction([&]() { return t0 + (double)(calls++) * dt; });
+            GpuAStarPlanner planner;   // a fresh planner every cycle, like Executive::planLoop (executive.cpp:85-90)
+            st = planner.plan(rm, start, config, prev, timeRemaining);
+        }
+        std::printf("{\"samples\": %lu, \"generated\": %lu, \"expanded\": %lu, \"iterations\": %lu, \"plan_f\": %.17g, "
+                    "\"plan_collision_penalty\": %.17g, \"plan_time_penalty\": %.17g, \"plan_h\": %.17g, \"plan_depth\": %lu, "
+                    "\"first_goal_iteration\": %ld, \"edges_costed\": %lu, \"plan\": [",
+                    st.Samples, st.Generated, st.Expanded, st.Iterations, st.PlanFValue, st.PlanCollisionPenalty, st.PlanTimePenalty,
+                    st.PlanHValue, st.PlanDepth, st.FirstGoalIteration, st.EdgesCosted);
+        bool first = true;
+        for (const auto& w : st.Plan.get()) {
+            const DubinsPath& p = w.unwrap();
+            std::printf("%s[%.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %d, %.17g, %.17g, %.17g]", first ? "" : ", ", p.qi[0], p.qi[1],
+                        p.qi[2], p.param[0], p.param[1], p.param[2], p.rho, (int)p.type, w.getSpeed(), w.getStartTime(), w.getEndTime());
+            first = false;
+        }
+        std::printf("]}\n");
+    } catch (const std::exception& e) {
+        std::printf("{\"exception\": \"%s\"}\n", e.what());
+        return 1;
+    }
+    return 0;
+}
