@@ -23,6 +23,14 @@ __device__ __forceinline__ double pp_readlane(double v, int src) {
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), s);
     return __hiloint2double(hi, lo);
 }
+// A wave-uniform double moved to scalar registers: per-edge constants (curve bases, times, source pose) then
+// occupy SGPRs (or, spilled, single lanes of a VGPR) instead of a full VGPR pair per lane — the sweep kernel is
+// latency bound and its occupancy is set by VGPRs.
+__device__ __forceinline__ double pp_sgpr(double v) {
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ int pp_readlane_i(int v, int src) {
     return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src));
 }
@@ -224,6 +232,15 @@ __device__ inline void pp_curve_init(PPCurve& c, double qx, double qy, double qt
     pp_segment(c.t1, d.p1, c.b1x, c.b1y, c.b1th, c.s1, c.c1, c.b2x, c.b2y, c.b2th);
     sincos(c.b2th, &c.s2, &c.c2);
 }
+// all fields are the same in every lane: keep them in scalar registers
+__device__ __forceinline__ void pp_curve_scalarize(PPCurve& c) {
+    c.qx = pp_sgpr(c.qx); c.qy = pp_sgpr(c.qy); c.qth = pp_sgpr(c.qth); c.rho = pp_sgpr(c.rho); c.length = pp_sgpr(c.length);
+    c.p0 = pp_sgpr(c.p0); c.p1 = pp_sgpr(c.p1); c.p2 = pp_sgpr(c.p2);
+    c.t0 = __builtin_amdgcn_readfirstlane(c.t0); c.t1 = __builtin_amdgcn_readfirstlane(c.t1); c.t2 = __builtin_amdgcn_readfirstlane(c.t2);
+    c.b1x = pp_sgpr(c.b1x); c.b1y = pp_sgpr(c.b1y); c.b1th = pp_sgpr(c.b1th);
+    c.b2x = pp_sgpr(c.b2x); c.b2y = pp_sgpr(c.b2y); c.b2th = pp_sgpr(c.b2th);
+    c.s0 = pp_sgpr(c.s0); c.c0 = pp_sgpr(c.c0); c.s1 = pp_sgpr(c.s1); c.c1 = pp_sgpr(c.c1); c.s2 = pp_sgpr(c.s2); c.c2 = pp_sgpr(c.c2);
+}
 
 // dubins_path_sample() for arc length `dist` already validated to lie in [0, length]:
 // pose (x, y, yaw in [0, 2pi)).
@@ -358,6 +375,28 @@ __device__ __forceinline__ double pp_ribbon_line_distance(const PPRibbon& r, dou
     return (fabs((r.ey - r.sy) * x - (r.ex - r.sx) * y + r.ex * r.sy - r.ey * r.sx)) / sqrt(pp_sq_len(r.sx, r.sy, r.ex, r.ey));
 }
 
+// min over lanes [0, n) of a value that is PP_DBL_MAX elsewhere; n is wave-uniform and usually small
+__device__ __forceinline__ double pp_min_first_n(double v, int n) {
+    if (n <= 8) {
+        double m = pp_readlane(v, 0);
+        for (int i = 1; i < n; i++) m = fmin(m, pp_readlane(v, i));
+        return m;
+    }
+    return pp_wave_min(v);
+}
+
+// |num| / sqrt(sqL) < lim, decided WITHOUT the square root and the division whenever the answer cannot depend on
+// their rounding: with correctly rounded sqrt and divide the quotient is within (1 +- 2.1 * 2^-53) of the real
+// value, so A = num^2 against C = lim^2 * sqL with a relative margin of 1e-11 is conclusive; only inside that
+// margin (or for degenerate/NaN input) the reference's own expression (Ribbon.h:118-121) is evaluated.
+__device__ __forceinline__ bool pp_line_distance_lt(double num, double sqL, double lim) {
+    const double A = num * num;
+    const double C = (lim * lim) * sqL;
+    if (A < C * (1.0 - 1e-11)) return true;
+    if (A > C * (1.0 + 1e-11)) return false;
+    return (fabs(num) / sqrt(sqL)) < lim;
+}
+
 // One coverage event of Edge::computeTrueCost (Edge.cpp:158-161), lane i holding ribbon i (i < n):
 //   D = RibbonManager::minDistanceFrom(x, y)                    (RibbonManager.cpp:142-152)
 //   if (doCover) RibbonManager::cover(x, y, strict = true)      (RibbonManager.cpp:14-22, Ribbon::split
@@ -371,41 +410,53 @@ __device__ inline int pp_ribbons_event(PPRibbon& r, int n, double w, double x, d
     if (n == 0) return 0;
     const int lane = pp_lane();
     const bool act = lane < n;
-    double px = 0, py = 0, ld = 0;
-    bool cp = false;
-    if (act) {
-        pp_ribbon_projection(r, x, y, px, py);
-        cp = pp_ribbon_contains_projection(r, px, py);
-        ld = pp_ribbon_line_distance(r, x, y);
+    // Straight-line code on purpose (bitwise &,| instead of &&,||; inactive lanes hold a zero ribbon and are masked
+    // out at the ballots): the event loop is the serial part of the kernel and every branch in it costs.
+    // Ribbon::getProjection (Ribbon.cpp:72-78)
+    const double dxr = r.ex - r.sx, dyr = r.ey - r.sy;
+    const double sqL = dxr * dxr + dyr * dyr;
+    const double dot = (x - r.sx) * dxr + (y - r.sy) * dyr;
+    const double px = dxr * dot / sqL + r.sx;
+    const double py = dyr * dot / sqL + r.sy;
+    // Ribbon::containsProjection (Ribbon.cpp:90-95)
+    const double T = PP_RIBBON_TOL;
+    const double a1 = px - r.sx, a2 = px - r.ex, b1 = py - r.sy, b2 = py - r.ey;
+    const bool outx = ((a1 < -T) & (a2 < -T)) | ((a1 > T) & (a2 > T));
+    const bool outy = ((b1 < -T) & (b2 < -T)) | ((b1 > T) & (b2 > T));
+    const bool cp = act & !(outx | outy);
+    // Ribbon::distance (Ribbon.h:118-121) against w (contains, non-strict) and w/2 (strict, Ribbon.cpp:39-43):
+    // decided on squares with a 1e-11 relative margin (see pp_line_distance_lt), exact expression only if ambiguous
+    const double num = dyr * x - dxr * y + r.ex * r.sy - r.ey * r.sx;
+    const double A = num * num;
+    const double Cn = (w * w) * sqL;
+    const double Cs = ((w / 2.0) * (w / 2.0)) * sqL;
+    bool ltN = A < Cn * (1.0 - 1e-11), gtN = A > Cn * (1.0 + 1e-11);
+    bool ltS = A < Cs * (1.0 - 1e-11), gtS = A > Cs * (1.0 + 1e-11);
+    if (__ballot(cp & (!(ltN | gtN) | !(ltS | gtS))) != 0ull) {
+        const double ld = fabs(num) / sqrt(sqL);
+        ltN = ld < w;
+        ltS = ld < (w / 2.0);
     }
+    const bool ns = cp & ltN;
+    const bool st = cp & ltS & doCover;
     // minDistanceFrom: 0 as soon as one ribbon contains the point (non-strict width), else nearest endpoint
-    if (__ballot(act && cp && (ld < w)) == 0ull) {
-        double m = PP_DBL_MAX;
-        if (act) {
-            double dStart = pp_dist(r.sx, r.sy, x, y);
-            double dEnd = pp_dist(r.ex, r.ey, x, y);
-            m = fmin(fmin(m, dEnd), dStart);
-        }
-        D = pp_wave_min(m);
+    if (__ballot(ns) == 0ull) {
+        const double dStart = pp_dist(r.sx, r.sy, x, y);
+        const double dEnd = pp_dist(r.ex, r.ey, x, y);
+        const double m = act ? fmin(fmin(PP_DBL_MAX, dEnd), dStart) : PP_DBL_MAX;
+        D = pp_min_first_n(m, n);
     }
     if (!doCover) return n;
     const double minLength = 2 * w;                                  // Ribbon::minLength (Ribbon.cpp:52-58)
     const double thr = minLength * minLength / (2.0 * 2.0);          // covered(strict): c_StrictModifier^2
-    bool split = false, keepF = false, keepR = false;
-    if (act) {
-        split = cp && (ld < (w / 2.0));                              // Ribbon::contains(strict) (Ribbon.cpp:39-43)
-        if (split) {
-            keepF = !(pp_sq_len(r.sx, r.sy, px, py) < thr);
-            keepR = !(pp_sq_len(px, py, r.ex, r.ey) < thr);
-        } else {
-            keepR = !(pp_sq_len(r.sx, r.sy, r.ex, r.ey) < thr);
-        }
-    }
-    const unsigned long long mS = __ballot(split), mF = __ballot(keepF), mR = __ballot(keepR);
+    const bool keepF = st & !(pp_sq_len(r.sx, r.sy, px, py) < thr);
+    const bool keepR = act & (st ? !(pp_sq_len(px, py, r.ex, r.ey) < thr) : !(sqL < thr));
+    const unsigned long long mS = __ballot(st), mF = __ballot(keepF), mR = __ballot(keepR);
     const unsigned long long actMask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
     if (mS == 0ull && mR == actMask) return n;                       // nothing split, nothing erased
     if (mF == 0ull && mR == actMask) {                               // splits whose fronts all vanish: starts move, order kept
-        if (split) { r.sx = px; r.sy = py; }
+        r.sx = st ? px : r.sx;
+        r.sy = st ? py : r.sy;
         return n;
     }
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -414,27 +465,38 @@ __device__ inline int pp_ribbons_event(PPRibbon& r, int n, double w, double x, d
     const int total = __popcll(mF) + __popcll(mR);
     if (keepF && posF < 64) { lds[posF * 4 + 0] = r.sx; lds[posF * 4 + 1] = r.sy; lds[posF * 4 + 2] = px; lds[posF * 4 + 3] = py; }
     if (keepR && posR < 64) {
-        lds[posR * 4 + 0] = split ? px : r.sx; lds[posR * 4 + 1] = split ? py : r.sy;
+        lds[posR * 4 + 0] = st ? px : r.sx; lds[posR * 4 + 1] = st ? py : r.sy;
         lds[posR * 4 + 2] = r.ex; lds[posR * 4 + 3] = r.ey;
     }
     pp_wave_lds_fence();
     if (lane < total && lane < 64) { r.sx = lds[lane * 4 + 0]; r.sy = lds[lane * 4 + 1]; r.ex = lds[lane * 4 + 2]; r.ey = lds[lane * 4 + 3]; }
+    else if (lane >= total) { r.sx = 0; r.sy = 0; r.ex = 0; r.ey = 0; }
     pp_wave_lds_fence();
     return total;
 }
 
 // ----------------------------------------------------------------------------- heuristics
 #define PP_TSP_MAX 8      // device limit on ribbons for the brute-force TSP heuristics
-#define PP_RIB_LDS 5      // doubles per ribbon in the heuristic's LDS image: sx, sy, ex, ey, length
+#define PP_H_PTS (2 * PP_TSP_MAX + 1)          // query point + both endpoints of every ribbon
+#define PP_H_LDS (PP_WAVE * 2 + PP_H_PTS * (PP_H_PTS - 1))   // doubles of LDS per wave: points (up to 64 ribbons for
+                                                              // MaxDistance would need 129 points: they use [0, 129*2))
 
-// RibbonManager::maxDistance (RibbonManager.cpp:234-248); ribbons in lds (n of them)
-__device__ inline double pp_h_max_distance(const double* lds, int n, double w, double x, double y) {
+// Every distance the heuristics need is between two of the points {query point, ribbon endpoints}; the TSP enumeration
+// only ever stands on one of those points.  So all sqrt() are taken once, lane-parallel, into a table
+//     T[p][q-1] = sqrt((xp - xq)^2 + (yp - yq)^2),   p in [0, 2n], q in [1, 2n]   (point 0 = query, 1+2i / 2+2i = start / end of ribbon i)
+// (the same expression as RibbonManager::distance, RibbonManager.h:285-287, and Ribbon::length(): (a-b)^2 == (b-a)^2 exactly),
+// and the enumeration itself is lookups, adds and compares.
+__device__ __forceinline__ double pp_h_T(const double* T, int p, int q) { return T[p * (PP_H_PTS - 1) + (q - 1)]; }
+
+// RibbonManager::maxDistance (RibbonManager.cpp:234-248); pts = x,y of the query point then of every ribbon's start, end
+__device__ inline double pp_h_max_distance(const double* pts, int n, double w) {
+    const double x = pts[0], y = pts[1];
     double sumLength = 0, mn = PP_DBL_MAX, mx = 0;
     for (int i = 0; i < n; i++) {
-        const double* rb = lds + PP_RIB_LDS * i;
-        sumLength += rb[4] - 2 * w;
-        double dStart = pp_dist(rb[0], rb[1], x, y);
-        double dEnd = pp_dist(rb[2], rb[3], x, y);
+        const double sx = pts[2 * (1 + 2 * i)], sy = pts[2 * (1 + 2 * i) + 1], ex = pts[2 * (2 + 2 * i)], ey = pts[2 * (2 + 2 * i) + 1];
+        sumLength += sqrt(pp_sq_len(sx, sy, ex, ey)) - 2 * w;
+        double dStart = pp_dist(sx, sy, x, y);
+        double dEnd = pp_dist(ex, ey, x, y);
         mn = fmin(fmin(mn, dEnd), dStart);
         mx = fmax(fmax(mx, dEnd), dStart);
     }
@@ -451,21 +513,18 @@ __device__ inline double pp_h_max_distance(const double* lds, int n, double w, d
 // fmin/fmax are exact, so any evaluation order gives the same bits.  Here the first Ls levels
 // (the "prefix", chosen so that there are >= 64 prefixes when the tree is that large) are spread
 // over the lanes — every lane walks ITS prefix with the same control flow, only the digits differ —
-// and the remaining levels are enumerated by one wave-uniform odometer, so that no lane ever waits
-// for another lane's branch.  Each tree node is sorted once.
-struct PPTspNode { double px, py, sf; unsigned ord; };
+// and the remaining (at most two) levels are enumerated by wave-uniform loops, so that no lane ever
+// waits for another lane's branch.  Each tree node is sorted once.
+struct PPTspNode { double sf; unsigned ord; int pt; };   // accumulated distance, remaining ribbons (4 bits each), current point
 
-__device__ __forceinline__ unsigned pp_tsp_sort(const double* lds, unsigned ord, int rem, double px, double py) {
+__device__ __forceinline__ unsigned pp_tsp_sort(const double* T, unsigned ord, int rem, int pt) {
     double key[PP_TSP_MAX];
     unsigned id[PP_TSP_MAX];
 #pragma unroll
     for (int i = 0; i < PP_TSP_MAX; i++) {
         id[i] = (ord >> (4 * i)) & 0xfu;
         key[i] = 0;
-        if (i < rem) {
-            const double* rb = lds + PP_RIB_LDS * id[i];
-            key[i] = fmin(pp_dist(px, py, rb[0], rb[1]), pp_dist(px, py, rb[2], rb[3]));
-        }
+        if (i < rem) key[i] = fmin(pp_h_T(T, pt, 1 + 2 * (int)id[i]), pp_h_T(T, pt, 2 + 2 * (int)id[i]));
     }
     // stable insertion sort, descending key: an element moves left only past strictly smaller keys
 #pragma unroll
@@ -487,22 +546,21 @@ __device__ __forceinline__ unsigned pp_tsp_sort(const double* lds, unsigned ord,
 }
 
 // take branch `digit` (ribbon position digit>>1 of `srt`, direction digit&1) from node `a`
-__device__ __forceinline__ PPTspNode pp_tsp_child(const double* lds, const PPTspNode& a, unsigned srt, int digit, double twoW) {
+__device__ __forceinline__ PPTspNode pp_tsp_child(const double* T, const PPTspNode& a, unsigned srt, int digit, double twoW) {
     const int c = digit >> 1, dir = digit & 1;
-    const unsigned rid = (srt >> (4 * c)) & 0xfu;
-    const double* rb = lds + PP_RIB_LDS * rid;
-    const double rsx = rb[0], rsy = rb[1], rex = rb[2], rey = rb[3], len = rb[4];
-    const double dd = dir == 0 ? pp_dist(a.px, a.py, rsx, rsy) : pp_dist(a.px, a.py, rex, rey);
+    const int rid = (int)((srt >> (4 * c)) & 0xfu);
+    const int ps = 1 + 2 * rid, pe = 2 + 2 * rid;
+    const double len = pp_h_T(T, ps, pe);                               // Ribbon::length()
+    const double dd = pp_h_T(T, a.pt, dir == 0 ? ps : pe);              // distance(point, r.start()) / (point, r.end())
     PPTspNode b;
     b.sf = fmax(a.sf + len - twoW + dd, 0);
-    b.px = dir == 0 ? rex : rsx;
-    b.py = dir == 0 ? rey : rsy;
+    b.pt = dir == 0 ? pe : ps;
     const unsigned lowmask = (c == 0) ? 0u : ((1u << (4 * c)) - 1u);
     b.ord = (srt & lowmask) | ((srt >> 4) & ~lowmask);
     return b;
 }
 
-__device__ inline double pp_h_tsp_point(const double* lds, int n, double w, int K, bool sortK, double x0, double y0) {
+__device__ inline double pp_h_tsp_point(const double* T, int n, double w, int K, bool sortK) {
     if (n == 0) return 0;
     if (K <= 0) return PP_DBL_MAX;   // the reference's loop body never runs and it returns DBL_MAX
     const int lane = pp_lane();
@@ -525,15 +583,15 @@ __device__ inline double pp_h_tsp_point(const double* lds, int n, double w, int 
         unsigned rest = act ? pid : 0u;
         unsigned stride = NP;
         PPTspNode a;
-        a.px = x0; a.py = y0; a.sf = 0; a.ord = 0x76543210u;
+        a.pt = 0; a.sf = 0; a.ord = 0x76543210u;
         for (int l = 0; l < Ls; l++) {                      // this lane's prefix, level 0 = most significant digit
             const int rem = n - l;
             const unsigned b = (unsigned)(2 * (rem < K ? rem : K));
             stride /= b;
             const unsigned dg = rest / stride;
             rest -= dg * stride;
-            const unsigned srt = sortK ? pp_tsp_sort(lds, a.ord, rem, a.px, a.py) : a.ord;
-            a = pp_tsp_child(lds, a, srt, (int)dg, twoW);
+            const unsigned srt = sortK ? pp_tsp_sort(T, a.ord, rem, a.pt) : a.ord;
+            a = pp_tsp_child(T, a, srt, (int)dg, twoW);
         }
         double v = PP_DBL_MAX;
         if (nsuf == 0) {
@@ -541,17 +599,17 @@ __device__ inline double pp_h_tsp_point(const double* lds, int n, double w, int 
         } else {
             const int remA = n - Ls;
             const int bA = 2 * (remA < K ? remA : K);
-            const unsigned srtA = sortK ? pp_tsp_sort(lds, a.ord, remA, a.px, a.py) : a.ord;
+            const unsigned srtA = sortK ? pp_tsp_sort(T, a.ord, remA, a.pt) : a.ord;
             for (int uA = 0; uA < bA; uA++) {
-                const PPTspNode bnode = pp_tsp_child(lds, a, srtA, uA, twoW);
+                const PPTspNode bnode = pp_tsp_child(T, a, srtA, uA, twoW);
                 if (nsuf == 1) {
                     v = fmin(v, bnode.sf);
                 } else {
                     const int remB = remA - 1;
                     const int bB = 2 * (remB < K ? remB : K);
-                    const unsigned srtB = sortK ? pp_tsp_sort(lds, bnode.ord, remB, bnode.px, bnode.py) : bnode.ord;
+                    const unsigned srtB = sortK ? pp_tsp_sort(T, bnode.ord, remB, bnode.pt) : bnode.ord;
                     for (int uB = 0; uB < bB; uB++) {
-                        const PPTspNode leaf = pp_tsp_child(lds, bnode, srtB, uB, twoW);
+                        const PPTspNode leaf = pp_tsp_child(T, bnode, srtB, uB, twoW);
                         v = fmin(v, leaf.sf);
                     }
                 }

@@ -54,11 +54,17 @@ __global__ void pp_k_time_grid(const ppgpu_vertex* verts, int nverts, double sst
 //   phase B (uniform + ribbon-per-lane)  the sequential coverage state machine of
 //                       Edge.cpp:153-171, visited only at its event steps
 //   phase C             end state, last cover, cost, g/h/f, one 128-byte record per edge
-__global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
-    __shared__ double lds_all[4][PP_WAVE * 4];
+#ifndef PP_WPB
+#define PP_WPB 4   // wavefronts (= edges) per workgroup of the two per-edge kernels
+#endif
+#ifndef PP_MIN_WAVES
+#define PP_MIN_WAVES 1   // 2nd __launch_bounds__ argument: waves per SIMD the register allocator must leave room for
+#endif
+__global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPParams p) {
+    __shared__ double lds_all[PP_WPB][PP_WAVE * 4];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = pp_lane();
-    const long long e = (long long)blockIdx.x * 4 + wave;
+    const long long e = (long long)blockIdx.x * PP_WPB + wave;
     if (e >= p.n_edges) return;
     double* lds = lds_all[wave];
 
@@ -96,9 +102,9 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
     }
 
     const ppgpu_vertex* V = p.verts + vi;
-    const double srcX = V->x, srcY = V->y, srcH = V->heading, srcT = V->time, srcG = V->g;
-    double cct = V->coverage_completed_time;
-    int nrib = V->ribbon_count;
+    const double srcX = pp_sgpr(V->x), srcY = pp_sgpr(V->y), srcH = pp_sgpr(V->heading), srcT = pp_sgpr(V->time), srcG = pp_sgpr(V->g);
+    double cct = pp_sgpr(V->coverage_completed_time);
+    int nrib = __builtin_amdgcn_readfirstlane(V->ribbon_count);
     const bool cov = (cbits & PPGPU_EDGE_COVERAGE) != 0;
     double rho = cov ? p.rho_cov : p.rho;                             // Edge.cpp:73-76
     double speed = (cbits & PPGPU_EDGE_SLOW) ? p.slow_speed : p.max_speed;
@@ -136,7 +142,11 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
         wStart = srcT;
         wEnd = srcT + cv.length / speed;                              // DubinsWrapper::setEndTime
     }
-    double endTime = fmin(p.horizon + 1e-12 + p.sst, wEnd);           // Edge.cpp:90
+    // everything computed so far is identical in all 64 lanes: move it to scalar registers
+    pp_curve_scalarize(cv);
+    dub.p0 = pp_sgpr(dub.p0); dub.p1 = pp_sgpr(dub.p1); dub.p2 = pp_sgpr(dub.p2); dub.type = __builtin_amdgcn_readfirstlane(dub.type);
+    approx = pp_sgpr(approx); wEnd = pp_sgpr(wEnd); wStart = pp_sgpr(wStart); rho = pp_sgpr(rho); speed = pp_sgpr(speed);
+    double endTime = pp_sgpr(fmin(p.horizon + 1e-12 + p.sst, wEnd));  // Edge.cpp:90
     bool infeasible = (srcT >= endTime);                              // :102-110
     bool throwsRef = colocated || (dub.type < 0);
     if (dub.type < 0) flags |= PPGPU_F_DUBINS_ERR;
@@ -188,6 +198,8 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
 #endif
             double prevHeading = __shfl_up(heading, 1, PP_WAVE);
             if (lane == 0) prevHeading = carryHeading;
+            // Edge.cpp:159: cover only when coverage is allowed on this edge or the heading did not change since the last step
+            const unsigned long long coverMask = cov ? ~0ull : __ballot(prevHeading == heading);
 
             const unsigned long long bm = __ballot(blk);
             const int fb = bm ? (__ffsll((long long)bm) - 1) : PP_WAVE;
@@ -200,14 +212,13 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
             nextEvent = 1 << 30;
 #endif
             while (true) {
-                const int j = nextEvent - base;
+                const int j = __builtin_amdgcn_readfirstlane(nextEvent - base);
                 if (j >= limit) break;
                 const double tj = pp_readlane(t, j);
                 if (!(tj < endTime)) break;
                 const double xj = pp_readlane(x, j), yj = pp_readlane(y, j);
-                const double hj = pp_readlane(heading, j), phj = pp_readlane(prevHeading, j);
                 double D;                                                                 // Edge.cpp:158-161
-                nrib = pp_ribbons_event(rib, nrib, w, xj, yj, cov || phj == hj, lds, D);
+                nrib = pp_ribbons_event(rib, nrib, w, xj, yj, ((coverMask >> j) & 1ull) != 0ull, lds, D);
                 if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
                 if (nrib == 0) {                                                          // :162-170
                     if (cct == -1) cct = tj;
@@ -346,41 +357,57 @@ __global__ __launch_bounds__(256) void pp_k_cost_edges(PPParams p) {
 // Vertex::computeApproxToGo (Vertex.cpp:49-64) for every costed edge: h = heuristic(child pose,
 // child ribbons) / maxSpeed, f = g + h, patched into the edge's record.  Its own kernel so that the
 // sweep kernel's register budget is not set by the TSP enumeration.  One wavefront per edge.
-__global__ __launch_bounds__(256) void pp_k_heuristic(PPParams p) {
-    __shared__ double lds_all[4][PP_WAVE * PP_RIB_LDS];
+__global__ __launch_bounds__(PP_WPB * 64) void pp_k_heuristic(PPParams p) {
+    __shared__ double lds_all[PP_WPB][PP_H_LDS];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = pp_lane();
-    const long long e = (long long)blockIdx.x * 4 + wave;
+    const long long e = (long long)blockIdx.x * PP_WPB + wave;
     if (e >= p.n_edges) return;
-    double* lds = lds_all[wave];
+    double* pts = lds_all[wave];                 // x,y of the query point, then start/end of every child ribbon
+    double* T = lds_all[wave] + PP_WAVE * 2;     // distance table of the TSP heuristics (<= 8 ribbons)
     ppgpu_edge_result* rec = p.out + e;
     unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)rec->flags);
     if (flags & PPGPU_F_THROWS) return;
     int nrib = (int)((__builtin_amdgcn_readfirstlane((int)rec->info) >> 8) & 0xff);
     const double endX = rec->end_x, endY = rec->end_y, g = rec->g;
     double hdist = 0;
-    if (nrib > 0) {
-        if (nrib > p.stride) {
-            nrib = 0;   // the list was truncated (already flagged): no meaningful heuristic
+    if (nrib > 0 && nrib <= p.stride) {          // a truncated list (already flagged) carries no heuristic
+        const bool tsp = p.heuristic != PPGPU_H_MAX_DISTANCE;
+        if (tsp && nrib > PP_TSP_MAX) {
+            flags |= PPGPU_F_RIBBON_OVF;
+        } else if (!tsp && nrib > 31) {
+            // MaxDistance over a long list: straight from global memory, no table
+            double sumLength = 0, mn = PP_DBL_MAX, mx = 0;
+            for (int i = 0; i < nrib; i++) {
+                const double* c = p.child + ((size_t)e * p.stride + i) * 4;
+                sumLength += sqrt(pp_sq_len(c[0], c[1], c[2], c[3])) - 2 * p.ribw;
+                double dStart = pp_dist(c[0], c[1], endX, endY);
+                double dEnd = pp_dist(c[2], c[3], endX, endY);
+                mn = fmin(fmin(mn, dEnd), dStart);
+                mx = fmax(fmax(mx, dEnd), dStart);
+            }
+            hdist = fmax(sumLength + mn, mx);
         } else {
+            if (lane == 0) { pts[0] = endX; pts[1] = endY; }
             if (lane < nrib) {
                 const double* c = p.child + ((size_t)e * p.stride + lane) * 4;
-                const double sx = c[0], sy = c[1], ex = c[2], ey = c[3];
-                lds[lane * PP_RIB_LDS + 0] = sx; lds[lane * PP_RIB_LDS + 1] = sy;
-                lds[lane * PP_RIB_LDS + 2] = ex; lds[lane * PP_RIB_LDS + 3] = ey;
-                lds[lane * PP_RIB_LDS + 4] = sqrt(pp_sq_len(sx, sy, ex, ey));    // Ribbon::length()
+                pts[2 * (1 + 2 * lane)] = c[0]; pts[2 * (1 + 2 * lane) + 1] = c[1];
+                pts[2 * (2 + 2 * lane)] = c[2]; pts[2 * (2 + 2 * lane) + 1] = c[3];
             }
             pp_wave_lds_fence();
-            if (p.heuristic == PPGPU_H_MAX_DISTANCE) {
-                hdist = pp_h_max_distance(lds, nrib, p.ribw, endX, endY);
-            } else if (nrib > PP_TSP_MAX) {
-                flags |= PPGPU_F_RIBBON_OVF;
-            } else if (p.heuristic == PPGPU_H_TSP_POINT_ALL) {
-                hdist = pp_h_tsp_point(lds, nrib, p.ribw, PP_TSP_MAX, false, endX, endY);
-            } else if (p.heuristic == PPGPU_H_TSP_POINT_K) {
-                hdist = pp_h_tsp_point(lds, nrib, p.ribw, p.tsp_k, true, endX, endY);
+            if (!tsp) {
+                hdist = pp_h_max_distance(pts, nrib, p.ribw);
             } else {
-                flags |= PPGPU_F_DUBINS_ERR;   // Dubins-TSP heuristics are rejected by ppgpu_set_config
+                const int npts = 2 * nrib + 1;
+                const int ncol = npts - 1;
+                for (int idx = lane; idx < npts * ncol; idx += PP_WAVE) {      // all distances, once
+                    const int pp = idx / ncol, qq = 1 + (idx - pp * ncol);
+                    T[pp * (PP_H_PTS - 1) + (qq - 1)] = pp_dist(pts[2 * pp], pts[2 * pp + 1], pts[2 * qq], pts[2 * qq + 1]);
+                }
+                pp_wave_lds_fence();
+                if (p.heuristic == PPGPU_H_TSP_POINT_ALL) hdist = pp_h_tsp_point(T, nrib, p.ribw, PP_TSP_MAX, false);
+                else if (p.heuristic == PPGPU_H_TSP_POINT_K) hdist = pp_h_tsp_point(T, nrib, p.ribw, p.tsp_k, true);
+                else flags |= PPGPU_F_DUBINS_ERR;   // Dubins-TSP heuristics are rejected by ppgpu_set_config
             }
         }
     }

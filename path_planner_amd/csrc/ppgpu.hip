@@ -493,7 +493,7 @@ int64_t ppgpu_dense_edge_count(int32_t nv, int64_t ns, uint32_t cfg_mask) {
 
 static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     if (p.n_edges <= 0) return PPGPU_OK;
-    long long blocks = (p.n_edges + 3) / 4;
+    long long blocks = (p.n_edges + PP_WPB - 1) / PP_WPB;
     if (blocks > 0x7fffffffll) return fail(PPGPU_ECAPACITY, "cost_edges: too many edges for one launch");
     if (!p.child) {
         // the heuristic kernel reads the child ribbon lists: keep them in a scratch the caller never sees
@@ -504,8 +504,8 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         p.child = c->int_child.p;
         p.stride = stride;
     }
-    hipLaunchKernelGGL(pp_k_cost_edges, dim3((unsigned)blocks), dim3(256), 0, c->stream, p);
-    hipLaunchKernelGGL(pp_k_heuristic, dim3((unsigned)blocks), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(pp_k_cost_edges, dim3((unsigned)blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+    hipLaunchKernelGGL(pp_k_heuristic, dim3((unsigned)blocks), dim3(PP_WPB * 64), 0, c->stream, p);
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;
 }

@@ -11,6 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "abl")
 VARIANTS = {
     "full": [],
+    "occ5": ["-DPP_MIN_WAVES=5"],
+    "occ6": ["-DPP_MIN_WAVES=6"],
+    "occ8": ["-DPP_MIN_WAVES=8"],
+    "wpb1": ["-DPP_WPB=1"],
+    "wpb2": ["-DPP_WPB=2"],
+    "wpb8": ["-DPP_WPB=8"],
     "no_heur": ["-DPP_ABL_NO_HEUR"],
     "no_obst": ["-DPP_ABL_NO_OBST"],
     "no_events": ["-DPP_ABL_NO_EVENTS"],
