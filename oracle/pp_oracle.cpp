@@ -762,6 +762,7 @@ double computeTrueCost(const Vertex& start, Vertex& end, const Config& config) {
     double lastHeading = start.state.heading;
     end.steps = 0;
     end.events = end.mutations = 0;
+    for (int q = 0; q < 4; q++) end.mutKinds[q] = 0;
 
     if (intermediate.time >= endTime) end.infeasible = true;  // :102-110
 
@@ -796,7 +797,21 @@ double computeTrueCost(const Vertex& start, Vertex& end, const Config& config) {
                 for (size_t q = 0; same && q < before.size(); q++)
                     same = before[q].sx == end.ribbons.ribbons[q].sx && before[q].sy == end.ribbons.ribbons[q].sy &&
                            before[q].ex == end.ribbons.ribbons[q].ex && before[q].ey == end.ribbons.ribbons[q].ey;
-                if (!same) end.mutations++;
+                if (!same) {
+                    end.mutations++;
+                    const auto& after = end.ribbons.ribbons;
+                    if (before.size() != after.size()) end.mutKinds[2]++;
+                    else {
+                        int changed = 0, startOnly = 0;
+                        for (size_t q = 0; q < before.size(); q++) {
+                            bool diff = before[q].sx != after[q].sx || before[q].sy != after[q].sy || before[q].ex != after[q].ex || before[q].ey != after[q].ey;
+                            if (diff) { changed++; if (before[q].ex == after[q].ex && before[q].ey == after[q].ey) startOnly++; }
+                        }
+                        if (changed == 1 && startOnly == 1) end.mutKinds[0]++;
+                        else if (changed == 2) end.mutKinds[1]++;
+                        else end.mutKinds[3]++;
+                    }
+                }
             }
             if (end.ribbons.done()) {
                 if (end.ribbons.coverageCompletedTime == -1) end.ribbons.setCoverageCompletedTime(intermediate.time);

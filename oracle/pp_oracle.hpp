@@ -174,7 +174,8 @@ struct Vertex {
     double edgeApproxCost = -1, edgeTrueCost = -1, collisionPenalty = 0;
     int steps = 0;                   // sweep iterations executed (diagnostic)
     bool heuristicSkipped = false;   // tspRibbonLimit applied
-    int events = 0, mutations = 0;   // coverage events / events that changed the ribbon list (diagnostic)
+    int events = 0, mutations = 0;
+    int mutKinds[4] = {0, 0, 0, 0};   // [0] one piece's start moved, [1] two pieces changed, same count, [2] count changed, [3] other   // coverage events / events that changed the ribbon list (diagnostic)
     double f() const { return currentCost + approxToGo; }
     int depth(const std::vector<Vertex>& arena) const;
 };

@@ -294,7 +294,7 @@ long ppo_add_samples(void* w, const double* b6, uint64_t seed, int n_ribbons, co
 }
 
 // ------------------------------------------------------------------ edges
-static thread_local int g_last_events = 0, g_last_mutations = 0;
+static thread_local int g_last_events = 0, g_last_mutations = 0, g_last_kinds[4] = {0, 0, 0, 0};
 static void cost_one(const World& W, const Config& cfg, const ppgpu_vertex* verts, const double* pool,
                      const double* sx, const double* sy, const double* sh, uint64_t desc, ppgpu_edge_result* out,
                      double* child, int stride) {
@@ -319,6 +319,7 @@ static void cost_one(const World& W, const Config& cfg, const ppgpu_vertex* vert
         threw = true;
     }
     g_last_events = end.events; g_last_mutations = end.mutations;
+    for (int q = 0; q < 4; q++) g_last_kinds[q] = end.mutKinds[q];
     uint32_t flags = 0;
     if (end.infeasible) flags |= PPGPU_F_INFEASIBLE;
     if (threw) flags |= PPGPU_F_THROWS | PPGPU_F_INFEASIBLE;
@@ -483,6 +484,17 @@ void ppo_edge_event_stats(void* w, const ppgpu_vertex* verts, const double* pool
     for (long e = 0; e < n; e++) {
         cost_one(*W, cfg, verts, pool, sx, sy, sh, edges[e], &r, nullptr, 0);
         stats2[2 * e] = g_last_events; stats2[2 * e + 1] = g_last_mutations;
+    }
+}
+void ppo_edge_event_kinds(void* w, const ppgpu_vertex* verts, const double* pool, const double* sx, const double* sy,
+                          const double* sh, long n, const uint64_t* edges, int* kinds6) {
+    World* W = (World*)w;
+    Config cfg = make_config(*W);
+    ppgpu_edge_result r;
+    for (long e = 0; e < n; e++) {
+        cost_one(*W, cfg, verts, pool, sx, sy, sh, edges[e], &r, nullptr, 0);
+        kinds6[6 * e] = g_last_events; kinds6[6 * e + 1] = g_last_mutations;
+        for (int q = 0; q < 4; q++) kinds6[6 * e + 2 + q] = g_last_kinds[q];
     }
 }
 

@@ -405,8 +405,10 @@ __device__ __forceinline__ bool pp_line_distance_lt(double num, double sqL, doub
 // cover() preserves list order: old ribbon i contributes [front part, if split and not covered] then
 // [itself / the remainder, if not covered].  lds = this wave's 64 x 4-double scratch.
 // Returns the new ribbon count (may exceed 64 -> the caller flags overflow).
-__device__ inline int pp_ribbons_event(PPRibbon& r, int n, double w, double x, double y, bool doCover, double* lds, double& D) {
+__device__ inline int pp_ribbons_event(PPRibbon& r, int n, double w, double x, double y, bool doCover, double* lds, double& D,
+                                       int& adv) {
     D = 0;
+    adv = -1;
     if (n == 0) return 0;
     const int lane = pp_lane();
     const bool act = lane < n;
@@ -446,17 +448,25 @@ __device__ inline int pp_ribbons_event(PPRibbon& r, int n, double w, double x, d
         const double m = act ? fmin(fmin(PP_DBL_MAX, dEnd), dStart) : PP_DBL_MAX;
         D = pp_min_first_n(m, n);
     }
-    if (!doCover) return n;
+    if (!doCover) { adv = -2; return n; }                            // nothing can change without cover()
     const double minLength = 2 * w;                                  // Ribbon::minLength (Ribbon.cpp:52-58)
     const double thr = minLength * minLength / (2.0 * 2.0);          // covered(strict): c_StrictModifier^2
     const bool keepF = st & !(pp_sq_len(r.sx, r.sy, px, py) < thr);
     const bool keepR = act & (st ? !(pp_sq_len(px, py, r.ex, r.ey) < thr) : !(sqL < thr));
     const unsigned long long mS = __ballot(st), mF = __ballot(keepF), mR = __ballot(keepR);
     const unsigned long long actMask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-    if (mS == 0ull && mR == actMask) return n;                       // nothing split, nothing erased
-    if (mF == 0ull && mR == actMask) {                               // splits whose fronts all vanish: starts move, order kept
-        r.sx = st ? px : r.sx;
-        r.sy = st ? py : r.sy;
+    if (mS == 0ull && mR == actMask) { adv = -2; return n; }          // nothing split, nothing erased
+    if ((mF & mR) == 0ull && (mF | mR) == actMask) {
+        // every split keeps exactly one of its halves and nothing else is erased: pieces change in place, order kept.
+        // keepR: the front vanished, the start moves to the projection; keepF: the remainder vanished, the END moves.
+        r.sx = (st & keepR) ? px : r.sx;
+        r.sy = (st & keepR) ? py : r.sy;
+        r.ex = (st & keepF) ? px : r.ex;
+        r.ey = (st & keepF) ? py : r.ey;
+        if ((mS & (mS - 1ull)) == 0ull) {                            // exactly one piece changed: a corridor run may follow
+            adv = __ffsll((long long)mS) - 1;
+            if (mF != 0ull) adv |= 0x100;                            // ... with its end (not its start) following the vehicle
+        }
         return n;
     }
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -475,10 +485,123 @@ __device__ inline int pp_ribbons_event(PPRibbon& r, int n, double w, double x, d
     return total;
 }
 
+// Corridor run.  While the vehicle travels inside one ribbon's strict corridor towards its end, EVERY step is a
+// coverage event that does the same thing: split that one piece at the projection, drop the one-step-long front,
+// keep the rest — i.e. the piece's start follows the vehicle (cover(): RibbonManager.cpp:14-22).  Sequentially that
+// is one dependent chain of two divisions per step; here the following steps of the chunk (one per lane) are checked
+// together and the longest prefix for which the outcome is beyond doubt is applied at once.
+//
+// "Beyond doubt": projections are taken on the piece's line as it stands at the start of the run (the sequential
+// chain re-derives the line from the moved start each step; the two differ by rounding only, ~1e-14 m), and every
+// decision the reference would take (containsProjection with its 1e-5 tolerance, strict distance, front covered,
+// rest not covered, no other piece anywhere near) must hold with a guard of 1e-9 — a step that does not clear the
+// guard ends the run and goes through the exact per-event code.  Flags therefore cannot differ; the moved start
+// differs from the sequential value by rounding noise (<= 1e-12 m).
+//
+// lanes = steps of the current chunk; `first` is the first candidate step, `limit` the end of the executable range.
+// moveEnd = false: the piece's START follows the vehicle (front part vanishes each step); true: its END does (the
+// vehicle travels towards the piece's start and the remainder vanishes each step).
+// Returns the run length L (0 = none) and the new position of the moving endpoint of piece `adv` (wave-uniform).
+__device__ inline int pp_corridor_run(const PPRibbon& r, int n, double w, int adv, bool moveEnd, double x, double y, bool stepOk,
+                                      unsigned long long coverMask, int first, double& newX, double& newY) {
+    const int lane = pp_lane();
+    const double Sx = pp_readlane(r.sx, adv), Sy = pp_readlane(r.sy, adv), Ex = pp_readlane(r.ex, adv), Ey = pp_readlane(r.ey, adv);
+    const double g = 1e-9;
+    const double dxr = Ex - Sx, dyr = Ey - Sy;
+    const double sqL = dxr * dxr + dyr * dyr;
+    const double dot = (x - Sx) * dxr + (y - Sy) * dyr;
+    const double px = dxr * dot / sqL + Sx;
+    const double py = dyr * dot / sqL + Sy;
+    const double num = dyr * x - dxr * y + Ex * Sy - Ey * Sx;
+    const bool strictOk = (num * num) < (((w / 2.0) * (w / 2.0)) * sqL) * (1.0 - g);
+    // the moving endpoint this step will see: the previous step's projection (the piece's own endpoint for the first)
+    double qx = __shfl_up(px, 1, PP_WAVE), qy = __shfl_up(py, 1, PP_WAVE);
+    if (lane == first) { qx = moveEnd ? Ex : Sx; qy = moveEnd ? Ey : Sy; }
+    const double csx = moveEnd ? Sx : qx, csy = moveEnd ? Sy : qy;   // the piece as this step sees it
+    const double cex = moveEnd ? qx : Ex, cey = moveEnd ? qy : Ey;
+    const double T = PP_RIBBON_TOL - g;
+    const double a1 = px - csx, a2 = px - cex, b1 = py - csy, b2 = py - cey;
+    const bool outx = ((a1 < -T) & (a2 < -T)) | ((a1 > T) & (a2 > T));
+    const bool outy = ((b1 < -T) & (b2 < -T)) | ((b1 > T) & (b2 > T));
+    const double thr = (2 * w) * (2 * w) / (2.0 * 2.0);
+    const double frontSq = pp_sq_len(csx, csy, px, py), restSq = pp_sq_len(px, py, cex, cey);
+    // start follows: front [start, proj] vanishes, rest kept; end follows: front kept, rest [proj, end] vanishes
+    const bool halves = moveEnd ? ((frontSq > thr * (1.0 + g)) & (restSq < thr * (1.0 - g)))
+                                : ((frontSq < thr * (1.0 - g)) & (restSq > thr * (1.0 + g)));
+    bool ok = stepOk & (lane >= first) & strictOk & !(outx | outy) & halves & (((coverMask >> lane) & 1ull) != 0ull);
+    // no other piece may be touched by any step of the run: either it is out of reach (farther than half its length
+    // + w from its midpoint: cheap), or — for the near ones, typically the sibling the first split left behind —
+    // the reference's own test must fail with the guard: projection clearly outside the piece, or clearly outside
+    // its strict corridor
+    for (int q = 0; q < n; q++) {
+        if (q == adv) continue;
+        const double sx = pp_readlane(r.sx, q), sy = pp_readlane(r.sy, q), ex = pp_readlane(r.ex, q), ey = pp_readlane(r.ey, q);
+        const double mx = 0.5 * (sx + ex), my = 0.5 * (sy + ey);
+        const double ql = pp_sq_len(sx, sy, ex, ey);
+        const double reach = 0.5 * sqrt(ql) + w + 1e-3;
+        const bool far = pp_sq_len(mx, my, x, y) > reach * reach;
+        if (__ballot(ok & !far) != 0ull) {
+            const double dq = ex - sx, eq = ey - sy;
+            const double dt = (x - sx) * dq + (y - sy) * eq;
+            const double ppx = dq * dt / ql + sx, ppy = eq * dt / ql + sy;
+            const double T2 = PP_RIBBON_TOL + g;
+            const double c1 = ppx - sx, c2 = ppx - ex, d1 = ppy - sy, d2 = ppy - ey;
+            const bool cpOut = (((c1 < -T2) & (c2 < -T2)) | ((c1 > T2) & (c2 > T2))) | (((d1 < -T2) & (d2 < -T2)) | ((d1 > T2) & (d2 > T2)));
+            const double nq = eq * x - dq * y + ex * sy - ey * sx;
+            const bool strictOut = (nq * nq) > (((w / 2.0) * (w / 2.0)) * ql) * (1.0 + g);
+            ok = ok & (far | cpOut | strictOut);
+        }
+    }
+    const unsigned long long okMask = __ballot(ok);
+    const unsigned long long bad = (~okMask) >> first;             // bit 0 = step `first`
+    const int L = first >= 64 ? 0 : (bad ? (__ffsll((long long)bad) - 1) : (64 - first));
+    if (L > 0) {
+        newX = pp_readlane(px, first + L - 1);
+        newY = pp_readlane(py, first + L - 1);
+    }
+    return L;
+}
+
+// Quiet run: consecutive steps that are all coverage events (the vehicle is inside some piece's NON-strict corridor,
+// so minDistanceFrom is 0 and the next step is an event again) but change nothing — no piece is strictly contained,
+// or cover() is not enabled at that step (Edge.cpp:159).  Same guarded, lanes-as-steps evaluation as the corridor run:
+// a step joins the run only if "inside" is certain and "nothing splits" is certain.  Returns the run length.
+__device__ inline int pp_quiet_run(const PPRibbon& r, int n, double w, double x, double y, bool stepOk,
+                                   unsigned long long coverMask, int first) {
+    const int lane = pp_lane();
+    const double g = 1e-9;
+    const bool cand = stepOk & (lane >= first);
+    bool inside = false, maySplit = false;
+    for (int q = 0; q < n; q++) {
+        const double sx = pp_readlane(r.sx, q), sy = pp_readlane(r.sy, q), ex = pp_readlane(r.ex, q), ey = pp_readlane(r.ey, q);
+        const double mx = 0.5 * (sx + ex), my = 0.5 * (sy + ey);
+        const double ql = pp_sq_len(sx, sy, ex, ey);
+        const double reach = 0.5 * sqrt(ql) + w + 1e-3;
+        const bool far = pp_sq_len(mx, my, x, y) > reach * reach;
+        if (__ballot(cand & !far) != 0ull) {
+            const double dq = ex - sx, eq = ey - sy;
+            const double dt = (x - sx) * dq + (y - sy) * eq;
+            const double ppx = dq * dt / ql + sx, ppy = eq * dt / ql + sy;
+            const double c1 = ppx - sx, c2 = ppx - ex, d1 = ppy - sy, d2 = ppy - ey;
+            const double Ti = PP_RIBBON_TOL - g, To = PP_RIBBON_TOL + g;
+            const bool cpIn = !((((c1 < -Ti) & (c2 < -Ti)) | ((c1 > Ti) & (c2 > Ti))) | (((d1 < -Ti) & (d2 < -Ti)) | ((d1 > Ti) & (d2 > Ti))));
+            const bool cpOut = (((c1 < -To) & (c2 < -To)) | ((c1 > To) & (c2 > To))) | (((d1 < -To) & (d2 < -To)) | ((d1 > To) & (d2 > To)));
+            const double nq = eq * x - dq * y + ex * sy - ey * sx;
+            const double A = nq * nq;
+            inside = inside | (!far & cpIn & (A < ((w * w) * ql) * (1.0 - g)));
+            maySplit = maySplit | (!far & !cpOut & !(A > (((w / 2.0) * (w / 2.0)) * ql) * (1.0 + g)));
+        }
+    }
+    const bool coverOn = ((coverMask >> lane) & 1ull) != 0ull;
+    const bool ok = cand & inside & !(maySplit & coverOn);
+    const unsigned long long bad = (~__ballot(ok)) >> first;
+    return first >= 64 ? 0 : (bad ? (__ffsll((long long)bad) - 1) : (64 - first));
+}
+
 // ----------------------------------------------------------------------------- heuristics
 #define PP_TSP_MAX 8      // device limit on ribbons for the brute-force TSP heuristics
 #define PP_H_PTS (2 * PP_TSP_MAX + 1)          // query point + both endpoints of every ribbon
-#define PP_H_LDS (PP_WAVE * 2 + PP_H_PTS * (PP_H_PTS - 1))   // doubles of LDS per wave: points (up to 64 ribbons for
+#define PP_H_LDS (PP_WAVE * 2 + PP_H_PTS * (PP_H_PTS - 1) + PP_H_PTS * PP_TSP_MAX)   // doubles of LDS per wave: points (up to 64 ribbons for
                                                               // MaxDistance would need 129 points: they use [0, 129*2))
 
 // Every distance the heuristics need is between two of the points {query point, ribbon endpoints}; the TSP enumeration
@@ -517,31 +640,30 @@ __device__ inline double pp_h_max_distance(const double* pts, int n, double w) {
 // waits for another lane's branch.  Each tree node is sorted once.
 struct PPTspNode { double sf; unsigned ord; int pt; };   // accumulated distance, remaining ribbons (4 bits each), current point
 
-__device__ __forceinline__ unsigned pp_tsp_sort(const double* T, unsigned ord, int rem, int pt) {
+// The order list::sort(comp = min1 > min2) leaves: element i goes to position
+//   #{ j : key_j > key_i }  +  #{ j before i : key_j == key_i }          (stable, descending)
+// computed as ranks, so nothing is swapped.  key_i = distance from point `pt` to the nearer endpoint of ribbon i,
+// read from the table KM[pt][i] = fmin(T[pt][start_i], T[pt][end_i]) built next to T.
+__device__ __forceinline__ unsigned pp_tsp_sort(const double* KM, unsigned ord, int rem, int pt) {
+    if (rem <= 1) return ord;        // nothing to order
     double key[PP_TSP_MAX];
-    unsigned id[PP_TSP_MAX];
 #pragma unroll
     for (int i = 0; i < PP_TSP_MAX; i++) {
-        id[i] = (ord >> (4 * i)) & 0xfu;
         key[i] = 0;
-        if (i < rem) key[i] = fmin(pp_h_T(T, pt, 1 + 2 * (int)id[i]), pp_h_T(T, pt, 2 + 2 * (int)id[i]));
-    }
-    // stable insertion sort, descending key: an element moves left only past strictly smaller keys
-#pragma unroll
-    for (int i = 1; i < PP_TSP_MAX; i++) {
-        if (i < rem) {
-#pragma unroll
-            for (int j = i; j >= 1; j--) {
-                if (key[j] > key[j - 1]) {
-                    double tk = key[j]; key[j] = key[j - 1]; key[j - 1] = tk;
-                    unsigned ti = id[j]; id[j] = id[j - 1]; id[j - 1] = ti;
-                }
-            }
-        }
+        if (i < rem) key[i] = KM[pt * PP_TSP_MAX + (int)((ord >> (4 * i)) & 0xfu)];
     }
     unsigned o = 0;
 #pragma unroll
-    for (int i = 0; i < PP_TSP_MAX; i++) o |= (id[i] & 0xfu) << (4 * i);
+    for (int i = 0; i < PP_TSP_MAX; i++) {
+        if (i < rem) {
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < PP_TSP_MAX; j++) {
+                if (j != i && j < rem) rank += ((key[j] > key[i]) | ((key[j] == key[i]) & (j < i))) ? 1 : 0;
+            }
+            o |= ((ord >> (4 * i)) & 0xfu) << (4 * rank);
+        }
+    }
     return o;
 }
 
@@ -560,7 +682,7 @@ __device__ __forceinline__ PPTspNode pp_tsp_child(const double* T, const PPTspNo
     return b;
 }
 
-__device__ inline double pp_h_tsp_point(const double* T, int n, double w, int K, bool sortK) {
+__device__ inline double pp_h_tsp_point(const double* T, const double* KM, int n, double w, int K, bool sortK) {
     if (n == 0) return 0;
     if (K <= 0) return PP_DBL_MAX;   // the reference's loop body never runs and it returns DBL_MAX
     const int lane = pp_lane();
@@ -590,7 +712,7 @@ __device__ inline double pp_h_tsp_point(const double* T, int n, double w, int K,
             stride /= b;
             const unsigned dg = rest / stride;
             rest -= dg * stride;
-            const unsigned srt = sortK ? pp_tsp_sort(T, a.ord, rem, a.pt) : a.ord;
+            const unsigned srt = sortK ? pp_tsp_sort(KM, a.ord, rem, a.pt) : a.ord;
             a = pp_tsp_child(T, a, srt, (int)dg, twoW);
         }
         double v = PP_DBL_MAX;
@@ -599,7 +721,7 @@ __device__ inline double pp_h_tsp_point(const double* T, int n, double w, int K,
         } else {
             const int remA = n - Ls;
             const int bA = 2 * (remA < K ? remA : K);
-            const unsigned srtA = sortK ? pp_tsp_sort(T, a.ord, remA, a.pt) : a.ord;
+            const unsigned srtA = sortK ? pp_tsp_sort(KM, a.ord, remA, a.pt) : a.ord;
             for (int uA = 0; uA < bA; uA++) {
                 const PPTspNode bnode = pp_tsp_child(T, a, srtA, uA, twoW);
                 if (nsuf == 1) {
@@ -607,7 +729,7 @@ __device__ inline double pp_h_tsp_point(const double* T, int n, double w, int K,
                 } else {
                     const int remB = remA - 1;
                     const int bB = 2 * (remB < K ? remB : K);
-                    const unsigned srtB = sortK ? pp_tsp_sort(T, bnode.ord, remB, bnode.pt) : bnode.ord;
+                    const unsigned srtB = sortK ? pp_tsp_sort(KM, bnode.ord, remB, bnode.pt) : bnode.ord;
                     for (int uB = 0; uB < bB; uB++) {
                         const PPTspNode leaf = pp_tsp_child(T, bnode, srtB, uB, twoW);
                         v = fmin(v, leaf.sf);

@@ -58,7 +58,8 @@ __global__ void pp_k_time_grid(const ppgpu_vertex* verts, int nverts, double sst
 #define PP_WPB 4   // wavefronts (= edges) per workgroup of the two per-edge kernels
 #endif
 #ifndef PP_MIN_WAVES
-#define PP_MIN_WAVES 1   // 2nd __launch_bounds__ argument: waves per SIMD the register allocator must leave room for
+#define PP_MIN_WAVES 6   // 2nd __launch_bounds__ argument: waves per SIMD the register allocator must leave room for
+                         // (measured on MI355X, config 3: 1 -> 10.7 ms, 5 -> 10.6 ms, 6 -> 10.3 ms, 8 -> slower: spills)
 #endif
 __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPParams p) {
     __shared__ double lds_all[PP_WPB][PP_WAVE * 4];
@@ -153,6 +154,9 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPP
 
     // ---- sweep state
     const double* tg = p.tgrid + (size_t)vi * p.ng;
+#ifdef PP_DBG_EVENTS
+    int dbgEvents = 0;
+#endif
     int rdt = -1;                       // `auto ribbonsDoneTime = -1;` is an int (Edge.cpp:92)
     int nextEvent = 0;                  // toCoverDistance starts at 0: step 0 is an event
     int hitsAcc = 0;
@@ -208,6 +212,7 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPP
 
             // phase B: coverage events among steps [0, limit)
             int lastEv = -1;
+            bool runFailed = false, quietFailed = false;
 #ifdef PP_ABL_NO_EVENTS
             nextEvent = 1 << 30;
 #endif
@@ -218,14 +223,48 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPP
                 if (!(tj < endTime)) break;
                 const double xj = pp_readlane(x, j), yj = pp_readlane(y, j);
                 double D;                                                                 // Edge.cpp:158-161
-                nrib = pp_ribbons_event(rib, nrib, w, xj, yj, ((coverMask >> j) & 1ull) != 0ull, lds, D);
+                int adv;
+                nrib = pp_ribbons_event(rib, nrib, w, xj, yj, ((coverMask >> j) & 1ull) != 0ull, lds, D, adv);
                 if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
+#ifndef PP_NO_CORRIDOR_RUN
+                if (adv >= 0 && j + 1 < limit && !runFailed) {
+                    // this event only moved one piece's start: the following steps very likely do the same
+                    double nsx, nsy;
+                    const bool moveEnd = (adv & 0x100) != 0;
+                    const int piece = adv & 0xff;
+                    const int L = pp_corridor_run(rib, nrib, w, piece, moveEnd, x, y, (lane < limit) & (t < endTime), coverMask, j + 1, nsx, nsy);
+                    runFailed = (L == 0);                  // do not keep paying for attempts that do not start
+                    if (L > 0) {
+                        if (lane == piece) {
+                            if (moveEnd) { rib.ex = nsx; rib.ey = nsy; } else { rib.sx = nsx; rib.sy = nsy; }
+                        }
+                        lastEv = j + L;
+                        nextEvent = base + j + L + 1;      // inside the corridor minDistanceFrom is 0: the next step is an event too
+                        continue;
+                    }
+                }
+#ifdef PP_QUIET_RUN   // opt-in: absorbs the non-mutating in-corridor events too, but costs ~18 VGPRs (one wave of occupancy)
+                else if (adv == -2 && D == 0 && nrib > 0 && j + 1 < limit && !quietFailed) {
+                    // inside a corridor, nothing changed: the following steps are very likely the same kind of event
+                    const int L = pp_quiet_run(rib, nrib, w, x, y, (lane < limit) & (t < endTime), coverMask, j + 1);
+                    quietFailed = (L == 0);
+                    if (L > 0) {
+                        lastEv = j + L;
+                        nextEvent = base + j + L + 1;
+                        continue;
+                    }
+                }
+#endif
+#endif
                 if (nrib == 0) {                                                          // :162-170
                     if (cct == -1) cct = tj;
                     rdt = (int)tj;
                     endTime = fmin(endTime, cct + p.tmin);
                 }
                 lastEv = j;
+#ifdef PP_DBG_EVENTS
+                dbgEvents++;
+#endif
                 // steps until toCoverDistance <= increment again (:153-154): m subtractions
                 int m = 0;
                 if (D > inc_d) {
@@ -289,7 +328,8 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPP
         // cover the last little bit (:182-191)
         if (cov || lastHeading == ih) {
             double Dunused;
-            nrib = pp_ribbons_event(rib, nrib, w, ix, iy, true, lds, Dunused);
+            int advUnused;
+            nrib = pp_ribbons_event(rib, nrib, w, ix, iy, true, lds, Dunused, advUnused);
             if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
         }
         if (nrib == 0) {
@@ -320,6 +360,9 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPP
 
     // ---- one 128-byte record, lanes 0..15 write one 8-byte slot each
     {
+#ifdef PP_DBG_EVENTS
+        steps = dbgEvents;
+#endif
         const unsigned info = (unsigned)((dub.type < 0 ? 0 : dub.type) & 0xff) | ((unsigned)(nrib & 0xff) << 8) |
                               ((unsigned)(steps & 0xffff) << 16);
         double v;
@@ -357,7 +400,10 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPP
 // Vertex::computeApproxToGo (Vertex.cpp:49-64) for every costed edge: h = heuristic(child pose,
 // child ribbons) / maxSpeed, f = g + h, patched into the edge's record.  Its own kernel so that the
 // sweep kernel's register budget is not set by the TSP enumeration.  One wavefront per edge.
-__global__ __launch_bounds__(PP_WPB * 64) void pp_k_heuristic(PPParams p) {
+#ifndef PP_H_MIN_WAVES
+#define PP_H_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(PP_WPB * 64, PP_H_MIN_WAVES) void pp_k_heuristic(PPParams p) {
     __shared__ double lds_all[PP_WPB][PP_H_LDS];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = pp_lane();
@@ -365,6 +411,7 @@ __global__ __launch_bounds__(PP_WPB * 64) void pp_k_heuristic(PPParams p) {
     if (e >= p.n_edges) return;
     double* pts = lds_all[wave];                 // x,y of the query point, then start/end of every child ribbon
     double* T = lds_all[wave] + PP_WAVE * 2;     // distance table of the TSP heuristics (<= 8 ribbons)
+    double* KM = T + PP_H_PTS * (PP_H_PTS - 1);  // KM[p][i] = distance from point p to the nearer endpoint of ribbon i
     ppgpu_edge_result* rec = p.out + e;
     unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)rec->flags);
     if (flags & PPGPU_F_THROWS) return;
@@ -405,8 +452,13 @@ __global__ __launch_bounds__(PP_WPB * 64) void pp_k_heuristic(PPParams p) {
                     T[pp * (PP_H_PTS - 1) + (qq - 1)] = pp_dist(pts[2 * pp], pts[2 * pp + 1], pts[2 * qq], pts[2 * qq + 1]);
                 }
                 pp_wave_lds_fence();
-                if (p.heuristic == PPGPU_H_TSP_POINT_ALL) hdist = pp_h_tsp_point(T, nrib, p.ribw, PP_TSP_MAX, false);
-                else if (p.heuristic == PPGPU_H_TSP_POINT_K) hdist = pp_h_tsp_point(T, nrib, p.ribw, p.tsp_k, true);
+                for (int idx = lane; idx < npts * nrib; idx += PP_WAVE) {
+                    const int pp = idx / nrib, ri = idx - pp * nrib;
+                    KM[pp * PP_TSP_MAX + ri] = fmin(pp_h_T(T, pp, 1 + 2 * ri), pp_h_T(T, pp, 2 + 2 * ri));
+                }
+                pp_wave_lds_fence();
+                if (p.heuristic == PPGPU_H_TSP_POINT_ALL) hdist = pp_h_tsp_point(T, KM, nrib, p.ribw, PP_TSP_MAX, false);
+                else if (p.heuristic == PPGPU_H_TSP_POINT_K) hdist = pp_h_tsp_point(T, KM, nrib, p.ribw, p.tsp_k, true);
                 else flags |= PPGPU_F_DUBINS_ERR;   // Dubins-TSP heuristics are rejected by ppgpu_set_config
             }
         }

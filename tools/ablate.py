@@ -11,6 +11,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "abl")
 VARIANTS = {
     "full": [],
+    "norun": ["-DPP_NO_CORRIDOR_RUN"],
+    "quiet": ["-DPP_QUIET_RUN"],
+    "h3": ["-DPP_H_MIN_WAVES=3"],
+    "h4": ["-DPP_H_MIN_WAVES=4"],
+    "h5": ["-DPP_H_MIN_WAVES=5"],
+    "occ1": ["-DPP_MIN_WAVES=1"],
+    "occ4": ["-DPP_MIN_WAVES=4"],
     "occ5": ["-DPP_MIN_WAVES=5"],
     "occ6": ["-DPP_MIN_WAVES=6"],
     "occ8": ["-DPP_MIN_WAVES=8"],
