@@ -30,6 +30,8 @@ def _load():
         "ppgpu_last_error": (C.c_char_p, []),
         "ppgpu_set_stream": (C.c_int, [vp, vp]),
         "ppgpu_synchronize": (C.c_int, [vp]),
+        "ppgpu_enable_timing": (C.c_int, [vp, i32]),
+        "ppgpu_last_timing": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(dbl)]),
         "ppgpu_set_config": (C.c_int, [vp, C.POINTER(PpgpuConfig)]),
         "ppgpu_set_grid": (C.c_int, [vp, vp, i32, i32, dbl]),
         "ppgpu_set_obstacles": (C.c_int, [vp, i32, i32, vp]),
@@ -98,6 +100,14 @@ class Context:
 
     def set_stream(self, stream_ptr):
         self._ck(LIB.ppgpu_set_stream(self._h, stream_ptr), "ppgpu_set_stream")
+
+    def enable_timing(self, on=True):
+        self._ck(LIB.ppgpu_enable_timing(self._h, 1 if on else 0), "ppgpu_enable_timing")
+
+    def last_timing(self):
+        a, b = C.c_double(), C.c_double()
+        self._ck(LIB.ppgpu_last_timing(self._h, C.byref(a), C.byref(b)), "ppgpu_last_timing")
+        return a.value, b.value
 
     def synchronize(self):
         self._ck(LIB.ppgpu_synchronize(self._h), "ppgpu_synchronize")

@@ -66,11 +66,66 @@ __device__ __forceinline__ double pp_heading_from_yaw(double yaw) {
     return h;
 }
 
+// ----------------------------------------------------------------------------- sine / cosine
+// sin and cos of the same angle for the bounded arguments of this kernel (|x| of a few pi): the classic
+// reduce-by-pi/2-then-two-polynomials scheme (Cody & Waite reduction carried to ~118 bits in two steps, then the
+// minimax polynomials for sin and cos on [-pi/4, pi/4] with a correction term for the low part of the reduced
+// argument; error below 1 ulp).  It replaces the general-purpose device sincos, whose huge-argument path and extra
+// selects cost about twice as many instructions; arguments outside the fast range take the library call.
+// Like any libm pair, results can differ from the host libm's in the last bit: see DESIGN.md "Numerics".
+__device__ __forceinline__ void pp_sincos(double x, double* sn, double* cs) {
+    if (__ballot(!(fabs(x) < 1.0e5)) != 0ull) { sincos(x, sn, cs); return; }
+    const double fn = rint(x * 6.36619772367581382433e-01);          // x * 2/pi, to nearest
+    const int n = (int)fn;
+    // pi/2 = pio2_1 + pio2_2 + pio2_2t (+ ...), the leading parts having 33 significant bits each
+    double r = x - fn * 1.57079632673412561417e+00;
+    double wlo;
+    {
+        const double t = r;
+        wlo = fn * 6.07710050630396597660e-11;                         // pio2_2
+        r = t - wlo;
+        wlo = fn * 2.02226624879595063154e-21 - ((t - r) - wlo);       // pio2_2t
+    }
+    const double y0 = r - wlo;
+    const double y1 = (r - y0) - wlo;
+    const double z = y0 * y0;
+    // sin(y0 + y1)
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double v = z * y0;
+    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double sinv = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+    // cos(y0 + y1)
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double ax = fabs(y0);
+    double qx = __hiloint2double(__double2hiint(ax) - 0x00200000, 0);  // |y0| / 4, low word cleared
+    qx = (ax > 0.78125) ? 0.28125 : qx;
+    qx = (ax < 0.3) ? 0.0 : qx;
+    const double hz = 0.5 * z - qx;
+    const double cosv = (1.0 - qx) - (hz - (z * rc - y0 * y1));
+    // quadrant
+    const double s2 = (n & 1) ? cosv : sinv;
+    const double c2 = (n & 1) ? sinv : cosv;
+    *sn = (n & 2) ? -s2 : s2;
+    *cs = ((n + 1) & 2) ? -c2 : c2;
+}
+
 // ----------------------------------------------------------------------------- Dubins
 // Third-party `dubins_curves` C library (absent from the reference tree).  Same published
 // six-word formulation as path_planner_amd/csrc/dubins.c (the host library behind
 // include/dubins.h); see that file for the derivation notes.
-__device__ __forceinline__ double pp_mod2pi(double t) { return t - PP_TWO_PI * floor(t / PP_TWO_PI); }
+// mod2pi(t) = t - 2pi * floor(t / 2pi).  floor() of the quotient only depends on the division's rounding when the
+// quotient is within rounding distance of an integer, so the quotient is first taken as t * (1/2pi) and the true
+// division is evaluated only if some lane is within 1e-9 of an integer (same result, one division less).
+__device__ __forceinline__ double pp_mod2pi(double t) {
+    const double q = t * 0.15915494309189533576888376337251;
+    double k = floor(q);
+    const double fr = q - k;
+    if (__ballot(!((fr > 1e-9) & (fr < 1.0 - 1e-9))) != 0ull) k = floor(t / PP_TWO_PI);
+    return t - PP_TWO_PI * k;
+}
 
 struct PPDubins {
     double p0, p1, p2;  // DubinsPath::param
@@ -99,9 +154,10 @@ __device__ inline void pp_dubins_shortest(double q0x, double q0y, double q0t, do
     double alpha = pp_mod2pi(q0t - theta);
     double beta = pp_mod2pi(q1t - theta);
     double sa, ca, sb, cb;
-    sincos(alpha, &sa, &ca);
-    sincos(beta, &sb, &cb);
-    double c_ab = cos(alpha - beta);
+    pp_sincos(alpha, &sa, &ca);
+    pp_sincos(beta, &sb, &cb);
+    double c_ab, s_ab_unused;
+    pp_sincos(alpha - beta, &s_ab_unused, &c_ab);
     double d_sq = d * d;
 
     double best = INFINITY;
@@ -193,13 +249,13 @@ __device__ __forceinline__ void pp_segment(int type, double t, double bx, double
                                            double& x, double& y, double& th) {
     if (type == 0) {  // L
         double s, c;
-        sincos(bth + t, &s, &c);
+        pp_sincos(bth + t, &s, &c);
         x = (+s - sb) + bx;
         y = (-c + cb) + by;
         th = t + bth;
     } else if (type == 2) {  // R
         double s, c;
-        sincos(bth - t, &s, &c);
+        pp_sincos(bth - t, &s, &c);
         x = (-s + sb) + bx;
         y = (+c - cb) + by;
         th = -t + bth;
@@ -214,6 +270,7 @@ __device__ __forceinline__ void pp_segment(int type, double t, double bx, double
 struct PPCurve {
     double qx, qy, qth;   // DubinsPath::qi
     double rho, length;
+    double rho_inv;       // 1/rho when rho is a power of two (the division is then exact as a product), else 0
     double p0, p1, p2;
     int t0, t1, t2;       // segment types
     double b1x, b1y, b1th, b2x, b2y, b2th;     // end of segment 1 / 2 (unit radius, origin at qi)
@@ -222,19 +279,24 @@ struct PPCurve {
 
 __device__ inline void pp_curve_init(PPCurve& c, double qx, double qy, double qth, double rho, const PPDubins& d) {
     c.qx = qx; c.qy = qy; c.qth = qth; c.rho = rho;
+    {
+        int ex;
+        c.rho_inv = (frexp(rho, &ex) == 0.5) ? (1.0 / rho) : 0.0;
+    }
     c.p0 = d.p0; c.p1 = d.p1; c.p2 = d.p2;
     c.length = pp_dubins_length(d, rho);
     int w = d.type < 0 ? 0 : d.type;
     c.t0 = pp_seg_type(w, 0); c.t1 = pp_seg_type(w, 1); c.t2 = pp_seg_type(w, 2);
-    sincos(qth, &c.s0, &c.c0);
+    pp_sincos(qth, &c.s0, &c.c0);
     pp_segment(c.t0, d.p0, 0.0, 0.0, qth, c.s0, c.c0, c.b1x, c.b1y, c.b1th);
-    sincos(c.b1th, &c.s1, &c.c1);
+    pp_sincos(c.b1th, &c.s1, &c.c1);
     pp_segment(c.t1, d.p1, c.b1x, c.b1y, c.b1th, c.s1, c.c1, c.b2x, c.b2y, c.b2th);
-    sincos(c.b2th, &c.s2, &c.c2);
+    pp_sincos(c.b2th, &c.s2, &c.c2);
 }
 // all fields are the same in every lane: keep them in scalar registers
 __device__ __forceinline__ void pp_curve_scalarize(PPCurve& c) {
     c.qx = pp_sgpr(c.qx); c.qy = pp_sgpr(c.qy); c.qth = pp_sgpr(c.qth); c.rho = pp_sgpr(c.rho); c.length = pp_sgpr(c.length);
+    c.rho_inv = pp_sgpr(c.rho_inv);
     c.p0 = pp_sgpr(c.p0); c.p1 = pp_sgpr(c.p1); c.p2 = pp_sgpr(c.p2);
     c.t0 = __builtin_amdgcn_readfirstlane(c.t0); c.t1 = __builtin_amdgcn_readfirstlane(c.t1); c.t2 = __builtin_amdgcn_readfirstlane(c.t2);
     c.b1x = pp_sgpr(c.b1x); c.b1y = pp_sgpr(c.b1y); c.b1th = pp_sgpr(c.b1th);
@@ -242,29 +304,47 @@ __device__ __forceinline__ void pp_curve_scalarize(PPCurve& c) {
     c.s0 = pp_sgpr(c.s0); c.c0 = pp_sgpr(c.c0); c.s1 = pp_sgpr(c.s1); c.c1 = pp_sgpr(c.c1); c.s2 = pp_sgpr(c.s2); c.c2 = pp_sgpr(c.c2);
 }
 
-// dubins_path_sample() for arc length `dist` already validated to lie in [0, length]:
-// pose (x, y, yaw in [0, 2pi)).
-__device__ __forceinline__ void pp_curve_sample(const PPCurve& c, double dist, double& x, double& y, double& yaw) {
-    double tprime = dist / c.rho;
-    int type; double tt, bx, by, bth, sb, cb;
-    if (tprime < c.p0) {
-        type = c.t0; tt = tprime; bx = 0.0; by = 0.0; bth = c.qth; sb = c.s0; cb = c.c0;
-    } else if (tprime < (c.p0 + c.p1)) {
-        type = c.t1; tt = tprime - c.p0; bx = c.b1x; by = c.b1y; bth = c.b1th; sb = c.s1; cb = c.c1;
-    } else {
-        type = c.t2; tt = tprime - c.p0 - c.p1; bx = c.b2x; by = c.b2y; bth = c.b2th; sb = c.s2; cb = c.c2;
-    }
-    double ux, uy, uth;
-    if (type == 1) {  // straight: no transcendental
+// one segment of dubins_path_sample(): advance by tt from base (bx, by, bth) whose sin/cos are (sb, cb)
+__device__ __forceinline__ void pp_curve_seg(int type, double tt, double bx, double by, double bth, double sb, double cb,
+                                             double& ux, double& uy, double& uth) {
+    if (type == 1) {            // straight: no transcendental
         ux = cb * tt + bx;
         uy = sb * tt + by;
         uth = 0.0 + bth;
     } else {
-        double arg = (type == 0) ? (bth + tt) : (bth - tt);
+        const double arg = (type == 0) ? (bth + tt) : (bth - tt);
         double s, co;
-        sincos(arg, &s, &co);
+        pp_sincos(arg, &s, &co);
         if (type == 0) { ux = (+s - sb) + bx; uy = (-co + cb) + by; uth = tt + bth; }
         else           { ux = (-s + sb) + bx; uy = (+co - cb) + by; uth = -tt + bth; }
+    }
+}
+
+// dubins_path_sample() for arc length `dist` already validated to lie in [0, length]:
+// pose (x, y, yaw in [0, 2pi)).  Called by the lanes holding valid steps (64 consecutive arc lengths): almost always
+// they all fall into the same segment, which is then handled with wave-uniform base values and a wave-uniform type.
+__device__ __forceinline__ void pp_curve_sample(const PPCurve& c, double dist, double& x, double& y, double& yaw) {
+    const double tprime = (c.rho_inv != 0.0) ? dist * c.rho_inv : dist / c.rho;
+    const bool in0 = tprime < c.p0;
+    const bool in1 = !in0 & (tprime < (c.p0 + c.p1));
+    const unsigned long long act = __ballot(true), m0 = __ballot(in0), m1 = __ballot(in1);
+    double ux, uy, uth;
+    if (m0 == act) {
+        pp_curve_seg(c.t0, tprime, 0.0, 0.0, c.qth, c.s0, c.c0, ux, uy, uth);
+    } else if (m1 == act) {
+        pp_curve_seg(c.t1, tprime - c.p0, c.b1x, c.b1y, c.b1th, c.s1, c.c1, ux, uy, uth);
+    } else if ((m0 | m1) == 0ull) {
+        pp_curve_seg(c.t2, tprime - c.p0 - c.p1, c.b2x, c.b2y, c.b2th, c.s2, c.c2, ux, uy, uth);
+    } else {
+        int type; double tt, bx, by, bth, sb, cb;
+        if (in0) {
+            type = c.t0; tt = tprime; bx = 0.0; by = 0.0; bth = c.qth; sb = c.s0; cb = c.c0;
+        } else if (in1) {
+            type = c.t1; tt = tprime - c.p0; bx = c.b1x; by = c.b1y; bth = c.b1th; sb = c.s1; cb = c.c1;
+        } else {
+            type = c.t2; tt = tprime - c.p0 - c.p1; bx = c.b2x; by = c.b2y; bth = c.b2th; sb = c.s2; cb = c.c2;
+        }
+        pp_curve_seg(type, tt, bx, by, bth, sb, cb, ux, uy, uth);
     }
     x = ux * c.rho + c.qx;
     y = uy * c.rho + c.qy;
@@ -275,13 +355,23 @@ __device__ __forceinline__ void pp_curve_sample(const PPCurve& c, double dist, d
 struct PPGrid {
     const uint32_t* bits;  // rows x words_per_row, bit (c & 31) of word c >> 5; NULL with rows == 0: base Map
     int rows, cols, wpr;
-    double res;
+    double res, inv_res;
 };
-// GridWorldMap::isBlocked (path_planner/src/common/map/GridWorldMap.cpp:84-93); Map::isBlocked (Map.cpp:4-6)
+// GridWorldMap::isBlocked (path_planner/src/common/map/GridWorldMap.cpp:84-93); Map::isBlocked (Map.cpp:4-6).
+// The cell index is size_t(x / res): the quotient is first taken as x * (1/res) and the exact division is done only
+// where that product is within 1e-9 of an integer (relative), i.e. where the division's rounding could matter.
 __device__ __forceinline__ bool pp_is_blocked(const PPGrid& g, double x, double y) {
     if (g.rows == 0) return false;
-    double cx = x / g.res;
-    double cy = y / g.res;
+    double cx = x * g.inv_res;
+    double cy = y * g.inv_res;
+    {
+        const double fx = cx - floor(cx), fy = cy - floor(cy);
+        const double mx = 1e-9 * fmax(1.0, fabs(cx)), my = 1e-9 * fmax(1.0, fabs(cy));
+        if (__ballot(!((fx > mx) & (fx < 1.0 - mx) & (fy > my) & (fy < 1.0 - my))) != 0ull) {
+            cx = x / g.res;
+            cy = y / g.res;
+        }
+    }
     if (x < 0 || cx >= (double)g.cols) return true;
     if (y < 0 || cy >= (double)g.rows) return true;
     unsigned r = (unsigned)cy;

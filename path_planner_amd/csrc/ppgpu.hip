@@ -80,6 +80,10 @@ struct ppgpu_ctx {
     DevBuf<ppgpu_wrapper_edge> tmp_wedges;
     DevBuf<ppgpu_edge_result> tmp_results;
     DevBuf<double> tmp_child, tmp_lengths, tmp_len_out, int_child;
+    // optional per-kernel timing of costing launches (ppgpu_enable_timing)
+    bool timing = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool ev_valid = false;
     int max_vertex_ribbons = 0;
     DevBuf<int> tmp_idx;
     DevBuf<unsigned long long> gather;
@@ -123,6 +127,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->s_bytes.release(); c->s_u64.release(); c->s_u32a.release(); c->s_u32b.release(); c->s_cand.release();
     c->tmp_edges.release(); c->tmp_wedges.release(); c->partial.release(); c->tmp_results.release(); c->tmp_child.release();
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
+    for (int i = 0; i < 3; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PPGPU_OK;
@@ -131,6 +136,28 @@ int ppgpu_destroy(ppgpu_ctx* c) {
 int ppgpu_set_stream(ppgpu_ctx* c, void* s) {
     if (!c) return fail(PPGPU_EINVAL, "null context");
     c->stream = s ? (hipStream_t)s : c->own_stream;
+    return PPGPU_OK;
+}
+
+int ppgpu_enable_timing(ppgpu_ctx* c, int32_t on) {
+    if (!c) return fail(PPGPU_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (on && !c->ev[0])
+        for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+    c->timing = on != 0;
+    c->ev_valid = false;
+    return PPGPU_OK;
+}
+
+int ppgpu_last_timing(ppgpu_ctx* c, double* ms_sweep, double* ms_heuristic) {
+    if (!c || !ms_sweep || !ms_heuristic) return fail(PPGPU_EINVAL, "null argument");
+    if (!c->timing || !c->ev_valid) return fail(PPGPU_ESTATE, "no timed costing launch (ppgpu_enable_timing, then cost edges)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev[2]));
+    float a = 0, b = 0;
+    HIP_TRY(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+    *ms_sweep = a; *ms_heuristic = b;
     return PPGPU_OK;
 }
 
@@ -407,7 +434,7 @@ int ppgpu_sampler_add(ppgpu_ctx* c, int64_t n_attempts, int64_t* n_total_out) {
     hipLaunchKernelGGL(pp_k_generate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, s.on_ribbons ? qpos : nullptr,
                        s.on_ribbons ? proj : nullptr, c->samp_ribbons.p, n, c->s_cand.p);
     // 5. SamplingBasedPlanner::addSamples' map filter, order-preserving compaction into the store
-    PPGrid g{c->grid.p, c->rows, c->cols, c->wpr, c->res};
+    PPGrid g{c->grid.p, c->rows, c->cols, c->wpr, c->res, c->res > 0 ? 1.0 / c->res : 0.0};
     unsigned char* keep = proj;  // the projection bits are no longer needed once the candidates exist
     hipLaunchKernelGGL(pp_k_keep_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, c->s_cand.p, n, keep);
     hipLaunchKernelGGL(pp_k_count_reduce, dim3(nblk_n), dim3(256), 0, st, keep, n, 1u, blk32);
@@ -438,7 +465,7 @@ static void fill_params(ppgpu_ctx* c, PPParams& p) {
     p.sst = g.start_state_time; p.ribw = g.ribbon_width;
     p.cpf = g.collision_penalty_factor; p.tpf = g.time_penalty_factor;
     p.heuristic = g.heuristic; p.tsp_k = g.tsp_k;
-    p.grid = PPGrid{c->grid.p, c->rows, c->cols, c->wpr, c->res};
+    p.grid = PPGrid{c->grid.p, c->rows, c->cols, c->wpr, c->res, c->res > 0 ? 1.0 / c->res : 0.0};
     p.obst = c->obst.p; p.n_obst = c->n_obst;
     p.verts = c->verts.p; p.ribbons = c->ribbons.p; p.tgrid = c->tgrid.p; p.ng = c->ng; p.nverts = c->nverts;
     p.sx = c->sx.p; p.sy = c->sy.p; p.sh = c->sh.p; p.n_samples = c->n_samples + c->n_extra;
@@ -504,8 +531,11 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         p.child = c->int_child.p;
         p.stride = stride;
     }
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL(pp_k_cost_edges, dim3((unsigned)blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     hipLaunchKernelGGL(pp_k_heuristic, dim3((unsigned)blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+    if (c->timing) { HIP_TRY(hipEventRecord(c->ev[2], c->stream)); c->ev_valid = true; }
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;
 }
