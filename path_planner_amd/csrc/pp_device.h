@@ -234,6 +234,88 @@ __device__ inline void pp_dubins_shortest(double q0x, double q0y, double q0t, do
     }
 }
 
+// The same solve, spread over a wavefront: lane w < 6 evaluates word w.  The expensive calls (atan2 x2, acos, sqrt,
+// mod2pi x6, one sincos for alpha / beta / alpha-beta) are each issued ONCE for all lanes instead of once per word;
+// every per-word expression is the one of pp_dubins_shortest above, term for term, so the selected word and its
+// parameters are bit-identical.  All arguments and the result are wave-uniform.
+__device__ inline void pp_dubins_shortest_wave(double q0x, double q0y, double q0t, double q1x, double q1y, double q1t,
+                                               double rho, PPDubins& out) {
+    const int lane = pp_lane();
+    const int w = lane < 6 ? lane : 0;
+    double dx = q1x - q0x;
+    double dy = q1y - q0y;
+    double D = sqrt(dx * dx + dy * dy);
+    double d = D / rho;
+    double theta = 0;
+    if (d > 0) theta = pp_mod2pi(atan2(dy, dx));
+    const double alpha = pp_mod2pi(q0t - theta);
+    const double beta = pp_mod2pi(q1t - theta);
+    // sin/cos of alpha (lane 0), beta (lane 1), alpha - beta (lane 2) in one call
+    double sv, cv;
+    pp_sincos(lane == 1 ? beta : (lane == 2 ? (alpha - beta) : alpha), &sv, &cv);
+    const double sa = pp_readlane(sv, 0), ca = pp_readlane(cv, 0);
+    const double sb = pp_readlane(sv, 1), cb = pp_readlane(cv, 1);
+    const double c_ab = pp_readlane(cv, 2);
+    const double d_sq = d * d;
+    const double mbeta = pp_mod2pi(beta);
+
+    // stage 1: feasibility, first atan2 operands
+    double y1 = 0, x1 = 1, psq = 0, tc = 0;
+    bool feas = false;
+    switch (w) {
+        case 0: { x1 = d + sa - sb; psq = 2 + d_sq - (2 * c_ab) + (2 * d * (sa - sb)); y1 = (cb - ca); feas = psq >= 0; break; }                 // LSL
+        case 1: { psq = -2 + (d_sq) + (2 * c_ab) + (2 * d * (sa + sb)); y1 = (-ca - cb); x1 = (d + sa + sb); feas = psq >= 0; break; }          // LSR
+        case 2: { psq = -2 + d_sq + (2 * c_ab) - (2 * d * (sa + sb)); y1 = (ca + cb); x1 = (d - sa - sb); feas = psq >= 0; break; }             // RSL
+        case 3: { x1 = d - sa + sb; psq = 2 + d_sq - (2 * c_ab) + (2 * d * (sb - sa)); y1 = (ca - cb); feas = psq >= 0; break; }                 // RSR
+        case 4: { tc = (6. - d_sq + 2 * c_ab + 2 * d * (sa - sb)) / 8.; y1 = ca - cb; x1 = d - sa + sb; feas = fabs(tc) <= 1; break; }          // RLR
+        default: { tc = (6. - d_sq + 2 * c_ab + 2 * d * (sb - sa)) / 8.; y1 = ca - cb; x1 = d + sa - sb; feas = fabs(tc) <= 1; break; }         // LRL
+    }
+    if (!feas) { y1 = 0; x1 = 1; psq = 0; tc = 0; }
+    const double a1 = atan2(y1, x1);
+    const double p = sqrt(psq);
+    const double a2 = atan2(w == 1 ? -2.0 : 2.0, (w == 1 || w == 2) ? p : 1.0);
+    const double ac = acos(tc);
+    // stage 2: CCC middle arc and its wrapped halves
+    const double pc = pp_mod2pi((PP_TWO_PI) - ac);
+    const double mph = pp_mod2pi(pc / 2.);
+    const double mpp = pp_mod2pi(pc);
+    // stage 3: t
+    double targ, pp;
+    switch (w) {
+        case 0: targ = a1 - alpha; pp = p; break;
+        case 1: targ = (a1 - a2) - alpha; pp = p; break;
+        case 2: targ = alpha - (a1 - a2); pp = p; break;
+        case 3: targ = alpha - a1; pp = p; break;
+        case 4: targ = alpha - a1 + mph; pp = pc; break;
+        default: targ = -alpha - a1 + pc / 2.; pp = pc; break;
+    }
+    const double t = pp_mod2pi(targ);
+    double qarg;
+    switch (w) {
+        case 0: qarg = beta - a1; break;
+        case 1: qarg = (a1 - a2) - mbeta; break;
+        case 2: qarg = beta - (a1 - a2); break;
+        case 3: qarg = a1 - beta; break;
+        case 4: qarg = alpha - beta - t + mpp; break;
+        default: qarg = mbeta - alpha - t + mpp; break;
+    }
+    const double q = pp_mod2pi(qarg);
+    const double cost = t + pp + q;
+    // first strictly smallest cost in word order
+    const unsigned long long candMask = __ballot(feas & (lane < 6));
+    double best = INFINITY;
+    int bw = -1;
+    for (int i = 0; i < 6; i++) {
+        const double ci = pp_readlane(cost, i);
+        if (((candMask >> i) & 1ull) != 0ull && ci < best) { best = ci; bw = i; }
+    }
+    out.type = bw;
+    const int src = bw < 0 ? 0 : bw;
+    out.p0 = bw < 0 ? 0.0 : pp_readlane(t, src);
+    out.p1 = bw < 0 ? 0.0 : pp_readlane(pp, src);
+    out.p2 = bw < 0 ? 0.0 : pp_readlane(q, src);
+}
+
 // dubins_path_length(): ((p0 + p1) + p2) * rho
 __device__ __forceinline__ double pp_dubins_length(const PPDubins& d, double rho) {
     double length = 0.;
@@ -293,6 +375,44 @@ __device__ inline void pp_curve_init(PPCurve& c, double qx, double qy, double qt
     pp_segment(c.t1, d.p1, c.b1x, c.b1y, c.b1th, c.s1, c.c1, c.b2x, c.b2y, c.b2th);
     pp_sincos(c.b2th, &c.s2, &c.c2);
 }
+// pp_curve_init with its three sincos issued as one (lane 0: qth, lane 1: end of segment 1, lane 2: end of segment 2 —
+// the heading at the end of an arc is base +- length, so all three angles are known before any trigonometry, and
+// sin/cos of an arc's end heading is exactly what positions that end).  Same expressions as pp_segment, wave-uniform.
+__device__ inline void pp_curve_init_wave(PPCurve& c, double qx, double qy, double qth, double rho, const PPDubins& d) {
+    const int lane = pp_lane();
+    c.qx = qx; c.qy = qy; c.qth = qth; c.rho = rho;
+    {
+        int ex;
+        c.rho_inv = (frexp(rho, &ex) == 0.5) ? (1.0 / rho) : 0.0;
+    }
+    c.p0 = d.p0; c.p1 = d.p1; c.p2 = d.p2;
+    c.length = pp_dubins_length(d, rho);
+    const int wd = d.type < 0 ? 0 : d.type;
+    c.t0 = pp_seg_type(wd, 0); c.t1 = pp_seg_type(wd, 1); c.t2 = pp_seg_type(wd, 2);
+    // dubins_segment(): th = t + base (L), -t + base (R), 0.0 + base (S); the trig argument is base + t / base - t
+    const double a1 = c.t0 == 0 ? (qth + d.p0) : (c.t0 == 2 ? (qth - d.p0) : qth);
+    c.b1th = c.t0 == 0 ? (d.p0 + qth) : (c.t0 == 2 ? (-d.p0 + qth) : (0.0 + qth));
+    const double a2 = c.t1 == 0 ? (c.b1th + d.p1) : (c.t1 == 2 ? (c.b1th - d.p1) : c.b1th);
+    c.b2th = c.t1 == 0 ? (d.p1 + c.b1th) : (c.t1 == 2 ? (-d.p1 + c.b1th) : (0.0 + c.b1th));
+    double sv, cv;
+    pp_sincos(lane == 1 ? a1 : (lane == 2 ? a2 : qth), &sv, &cv);
+    c.s0 = pp_readlane(sv, 0); c.c0 = pp_readlane(cv, 0);
+    const double sA1 = pp_readlane(sv, 1), cA1 = pp_readlane(cv, 1);     // sin/cos(base0 +- p0)
+    const double sA2 = pp_readlane(sv, 2), cA2 = pp_readlane(cv, 2);     // sin/cos(base1 +- p1)
+    // end of segment 1 from (0, 0, qth)
+    if (c.t0 == 0)      { c.b1x = (+sA1 - c.s0) + 0.0; c.b1y = (-cA1 + c.c0) + 0.0; }
+    else if (c.t0 == 2) { c.b1x = (-sA1 + c.s0) + 0.0; c.b1y = (+cA1 - c.c0) + 0.0; }
+    else                { c.b1x = c.c0 * d.p0 + 0.0;   c.b1y = c.s0 * d.p0 + 0.0; }
+    // sin/cos of the heading at the end of segment 1: the arc's own end angle, or unchanged on a straight
+    c.s1 = (c.t0 == 1) ? c.s0 : sA1;
+    c.c1 = (c.t0 == 1) ? c.c0 : cA1;
+    if (c.t1 == 0)      { c.b2x = (+sA2 - c.s1) + c.b1x; c.b2y = (-cA2 + c.c1) + c.b1y; }
+    else if (c.t1 == 2) { c.b2x = (-sA2 + c.s1) + c.b1x; c.b2y = (+cA2 - c.c1) + c.b1y; }
+    else                { c.b2x = c.c1 * d.p1 + c.b1x;   c.b2y = c.s1 * d.p1 + c.b1y; }
+    c.s2 = (c.t1 == 1) ? c.s1 : sA2;
+    c.c2 = (c.t1 == 1) ? c.c1 : cA2;
+}
+
 // all fields are the same in every lane: keep them in scalar registers
 __device__ __forceinline__ void pp_curve_scalarize(PPCurve& c) {
     c.qx = pp_sgpr(c.qx); c.qy = pp_sgpr(c.qy); c.qth = pp_sgpr(c.qth); c.rho = pp_sgpr(c.rho); c.length = pp_sgpr(c.length);

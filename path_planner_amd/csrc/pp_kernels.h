@@ -132,13 +132,13 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPP
         dub.p0 = W->param[0]; dub.p1 = W->param[1]; dub.p2 = W->param[2]; dub.type = W->type;
         if (dub.type < 0 || dub.type > 5) dub.type = -1;
         rho = W->rho; speed = W->speed;
-        pp_curve_init(cv, W->qi[0], W->qi[1], W->qi[2], rho, dub);
+        pp_curve_init_wave(cv, W->qi[0], W->qi[1], W->qi[2], rho, dub);
         wStart = W->start_time; wEnd = W->end_time;
         approx = (wEnd - srcT) * 1.0;                                 // Edge::setEnd(wrapper), Edge.cpp:208-216
     } else {
         colocated = (srcX == tgtX) && (srcY == tgtY) && (srcH == tgtH);              // State::isCoLocated
-        pp_dubins_shortest(srcX, srcY, pp_yaw(srcH), tgtX, tgtY, pp_yaw(tgtH), rho, dub);
-        pp_curve_init(cv, srcX, srcY, pp_yaw(srcH), rho, dub);
+        pp_dubins_shortest_wave(srcX, srcY, pp_yaw(srcH), tgtX, tgtY, pp_yaw(tgtH), rho, dub);
+        pp_curve_init_wave(cv, srcX, srcY, pp_yaw(srcH), rho, dub);
         approx = cv.length / speed * 1.0;                             // Edge.cpp:17
         wStart = srcT;
         wEnd = srcT + cv.length / speed;                              // DubinsWrapper::setEndTime
@@ -189,7 +189,11 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPP
                 if (dist < 0 || dist > cv.length) dist = dist - 1e-5; // EDUBPARAM retry, :39-42
                 if (dist < 0 || dist > cv.length) { dubErr = true; dist = fmin(fmax(dist, 0.0), cv.length); }
                 double yaw;
+#ifdef PP_ABL_NO_POSE
+                x = srcX + dist * 1e-3; y = srcY; yaw = 1.0;
+#else
                 pp_curve_sample(cv, dist, x, y, yaw);
+#endif
                 heading = pp_heading_from_yaw(yaw);                   // :47
 #ifndef PP_ABL_NO_GRID
                 blk = pp_is_blocked(p.grid, x, y);                    // Edge.cpp:144
