@@ -73,12 +73,20 @@ __device__ __forceinline__ double pp_heading_from_yaw(double yaw) {
 // argument; error below 1 ulp).  It replaces the general-purpose device sincos, whose huge-argument path and extra
 // selects cost about twice as many instructions; arguments outside the fast range take the library call.
 // Like any libm pair, results can differ from the host libm's in the last bit: see DESIGN.md "Numerics".
+__device__ __forceinline__ void pp_sincos_bounded(double x, double* sn, double* cs);
 __device__ __forceinline__ void pp_sincos(double x, double* sn, double* cs) {
     if (__ballot(!(fabs(x) < 1.0e5)) != 0ull) { sincos(x, sn, cs); return; }
+    pp_sincos_bounded(x, sn, cs);
+}
+// The fast range only (|x| < 2^20 * pi/2 keeps the first reduction step exact).  The sweep kernels call this directly:
+// their arguments are segment base heading +- arc, and pp_k_solve_edges refuses (PPGPU_F_DUBINS_ERR) any curve for which
+// |start yaw| + arcs reaches 9e4 rad.  The library call's huge-argument reduction would otherwise sit in the sweep loop
+// and set its register budget.
+__device__ __forceinline__ void pp_sincos_bounded(double x, double* sn, double* cs) {
     const double fn = rint(x * 6.36619772367581382433e-01);          // x * 2/pi, to nearest
     const int n = (int)fn;
     // pi/2 = pio2_1 + pio2_2 + pio2_2t (+ ...), the leading parts having 33 significant bits each
-    double r = x - fn * 1.57079632673412561417e+00;
+    double r = fma(-fn, 1.57079632673412561417e+00, x);             // exact either way: the product has <= 53 bits
     double wlo;
     {
         const double t = r;
@@ -93,12 +101,12 @@ __device__ __forceinline__ void pp_sincos(double x, double* sn, double* cs) {
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
                  S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
     const double v = z * y0;
-    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double rs = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
     const double sinv = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
     // cos(y0 + y1)
     const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                  C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double rc = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
     const double ax = fabs(y0);
     double qx = __hiloint2double(__double2hiint(ax) - 0x00200000, 0);  // |y0| / 4, low word cleared
     qx = (ax > 0.78125) ? 0.28125 : qx;
@@ -234,88 +242,6 @@ __device__ inline void pp_dubins_shortest(double q0x, double q0y, double q0t, do
     }
 }
 
-// The same solve, spread over a wavefront: lane w < 6 evaluates word w.  The expensive calls (atan2 x2, acos, sqrt,
-// mod2pi x6, one sincos for alpha / beta / alpha-beta) are each issued ONCE for all lanes instead of once per word;
-// every per-word expression is the one of pp_dubins_shortest above, term for term, so the selected word and its
-// parameters are bit-identical.  All arguments and the result are wave-uniform.
-__device__ inline void pp_dubins_shortest_wave(double q0x, double q0y, double q0t, double q1x, double q1y, double q1t,
-                                               double rho, PPDubins& out) {
-    const int lane = pp_lane();
-    const int w = lane < 6 ? lane : 0;
-    double dx = q1x - q0x;
-    double dy = q1y - q0y;
-    double D = sqrt(dx * dx + dy * dy);
-    double d = D / rho;
-    double theta = 0;
-    if (d > 0) theta = pp_mod2pi(atan2(dy, dx));
-    const double alpha = pp_mod2pi(q0t - theta);
-    const double beta = pp_mod2pi(q1t - theta);
-    // sin/cos of alpha (lane 0), beta (lane 1), alpha - beta (lane 2) in one call
-    double sv, cv;
-    pp_sincos(lane == 1 ? beta : (lane == 2 ? (alpha - beta) : alpha), &sv, &cv);
-    const double sa = pp_readlane(sv, 0), ca = pp_readlane(cv, 0);
-    const double sb = pp_readlane(sv, 1), cb = pp_readlane(cv, 1);
-    const double c_ab = pp_readlane(cv, 2);
-    const double d_sq = d * d;
-    const double mbeta = pp_mod2pi(beta);
-
-    // stage 1: feasibility, first atan2 operands
-    double y1 = 0, x1 = 1, psq = 0, tc = 0;
-    bool feas = false;
-    switch (w) {
-        case 0: { x1 = d + sa - sb; psq = 2 + d_sq - (2 * c_ab) + (2 * d * (sa - sb)); y1 = (cb - ca); feas = psq >= 0; break; }                 // LSL
-        case 1: { psq = -2 + (d_sq) + (2 * c_ab) + (2 * d * (sa + sb)); y1 = (-ca - cb); x1 = (d + sa + sb); feas = psq >= 0; break; }          // LSR
-        case 2: { psq = -2 + d_sq + (2 * c_ab) - (2 * d * (sa + sb)); y1 = (ca + cb); x1 = (d - sa - sb); feas = psq >= 0; break; }             // RSL
-        case 3: { x1 = d - sa + sb; psq = 2 + d_sq - (2 * c_ab) + (2 * d * (sb - sa)); y1 = (ca - cb); feas = psq >= 0; break; }                 // RSR
-        case 4: { tc = (6. - d_sq + 2 * c_ab + 2 * d * (sa - sb)) / 8.; y1 = ca - cb; x1 = d - sa + sb; feas = fabs(tc) <= 1; break; }          // RLR
-        default: { tc = (6. - d_sq + 2 * c_ab + 2 * d * (sb - sa)) / 8.; y1 = ca - cb; x1 = d + sa - sb; feas = fabs(tc) <= 1; break; }         // LRL
-    }
-    if (!feas) { y1 = 0; x1 = 1; psq = 0; tc = 0; }
-    const double a1 = atan2(y1, x1);
-    const double p = sqrt(psq);
-    const double a2 = atan2(w == 1 ? -2.0 : 2.0, (w == 1 || w == 2) ? p : 1.0);
-    const double ac = acos(tc);
-    // stage 2: CCC middle arc and its wrapped halves
-    const double pc = pp_mod2pi((PP_TWO_PI) - ac);
-    const double mph = pp_mod2pi(pc / 2.);
-    const double mpp = pp_mod2pi(pc);
-    // stage 3: t
-    double targ, pp;
-    switch (w) {
-        case 0: targ = a1 - alpha; pp = p; break;
-        case 1: targ = (a1 - a2) - alpha; pp = p; break;
-        case 2: targ = alpha - (a1 - a2); pp = p; break;
-        case 3: targ = alpha - a1; pp = p; break;
-        case 4: targ = alpha - a1 + mph; pp = pc; break;
-        default: targ = -alpha - a1 + pc / 2.; pp = pc; break;
-    }
-    const double t = pp_mod2pi(targ);
-    double qarg;
-    switch (w) {
-        case 0: qarg = beta - a1; break;
-        case 1: qarg = (a1 - a2) - mbeta; break;
-        case 2: qarg = beta - (a1 - a2); break;
-        case 3: qarg = a1 - beta; break;
-        case 4: qarg = alpha - beta - t + mpp; break;
-        default: qarg = mbeta - alpha - t + mpp; break;
-    }
-    const double q = pp_mod2pi(qarg);
-    const double cost = t + pp + q;
-    // first strictly smallest cost in word order
-    const unsigned long long candMask = __ballot(feas & (lane < 6));
-    double best = INFINITY;
-    int bw = -1;
-    for (int i = 0; i < 6; i++) {
-        const double ci = pp_readlane(cost, i);
-        if (((candMask >> i) & 1ull) != 0ull && ci < best) { best = ci; bw = i; }
-    }
-    out.type = bw;
-    const int src = bw < 0 ? 0 : bw;
-    out.p0 = bw < 0 ? 0.0 : pp_readlane(t, src);
-    out.p1 = bw < 0 ? 0.0 : pp_readlane(pp, src);
-    out.p2 = bw < 0 ? 0.0 : pp_readlane(q, src);
-}
-
 // dubins_path_length(): ((p0 + p1) + p2) * rho
 __device__ __forceinline__ double pp_dubins_length(const PPDubins& d, double rho) {
     double length = 0.;
@@ -375,55 +301,6 @@ __device__ inline void pp_curve_init(PPCurve& c, double qx, double qy, double qt
     pp_segment(c.t1, d.p1, c.b1x, c.b1y, c.b1th, c.s1, c.c1, c.b2x, c.b2y, c.b2th);
     pp_sincos(c.b2th, &c.s2, &c.c2);
 }
-// pp_curve_init with its three sincos issued as one (lane 0: qth, lane 1: end of segment 1, lane 2: end of segment 2 —
-// the heading at the end of an arc is base +- length, so all three angles are known before any trigonometry, and
-// sin/cos of an arc's end heading is exactly what positions that end).  Same expressions as pp_segment, wave-uniform.
-__device__ inline void pp_curve_init_wave(PPCurve& c, double qx, double qy, double qth, double rho, const PPDubins& d) {
-    const int lane = pp_lane();
-    c.qx = qx; c.qy = qy; c.qth = qth; c.rho = rho;
-    {
-        int ex;
-        c.rho_inv = (frexp(rho, &ex) == 0.5) ? (1.0 / rho) : 0.0;
-    }
-    c.p0 = d.p0; c.p1 = d.p1; c.p2 = d.p2;
-    c.length = pp_dubins_length(d, rho);
-    const int wd = d.type < 0 ? 0 : d.type;
-    c.t0 = pp_seg_type(wd, 0); c.t1 = pp_seg_type(wd, 1); c.t2 = pp_seg_type(wd, 2);
-    // dubins_segment(): th = t + base (L), -t + base (R), 0.0 + base (S); the trig argument is base + t / base - t
-    const double a1 = c.t0 == 0 ? (qth + d.p0) : (c.t0 == 2 ? (qth - d.p0) : qth);
-    c.b1th = c.t0 == 0 ? (d.p0 + qth) : (c.t0 == 2 ? (-d.p0 + qth) : (0.0 + qth));
-    const double a2 = c.t1 == 0 ? (c.b1th + d.p1) : (c.t1 == 2 ? (c.b1th - d.p1) : c.b1th);
-    c.b2th = c.t1 == 0 ? (d.p1 + c.b1th) : (c.t1 == 2 ? (-d.p1 + c.b1th) : (0.0 + c.b1th));
-    double sv, cv;
-    pp_sincos(lane == 1 ? a1 : (lane == 2 ? a2 : qth), &sv, &cv);
-    c.s0 = pp_readlane(sv, 0); c.c0 = pp_readlane(cv, 0);
-    const double sA1 = pp_readlane(sv, 1), cA1 = pp_readlane(cv, 1);     // sin/cos(base0 +- p0)
-    const double sA2 = pp_readlane(sv, 2), cA2 = pp_readlane(cv, 2);     // sin/cos(base1 +- p1)
-    // end of segment 1 from (0, 0, qth)
-    if (c.t0 == 0)      { c.b1x = (+sA1 - c.s0) + 0.0; c.b1y = (-cA1 + c.c0) + 0.0; }
-    else if (c.t0 == 2) { c.b1x = (-sA1 + c.s0) + 0.0; c.b1y = (+cA1 - c.c0) + 0.0; }
-    else                { c.b1x = c.c0 * d.p0 + 0.0;   c.b1y = c.s0 * d.p0 + 0.0; }
-    // sin/cos of the heading at the end of segment 1: the arc's own end angle, or unchanged on a straight
-    c.s1 = (c.t0 == 1) ? c.s0 : sA1;
-    c.c1 = (c.t0 == 1) ? c.c0 : cA1;
-    if (c.t1 == 0)      { c.b2x = (+sA2 - c.s1) + c.b1x; c.b2y = (-cA2 + c.c1) + c.b1y; }
-    else if (c.t1 == 2) { c.b2x = (-sA2 + c.s1) + c.b1x; c.b2y = (+cA2 - c.c1) + c.b1y; }
-    else                { c.b2x = c.c1 * d.p1 + c.b1x;   c.b2y = c.s1 * d.p1 + c.b1y; }
-    c.s2 = (c.t1 == 1) ? c.s1 : sA2;
-    c.c2 = (c.t1 == 1) ? c.c1 : cA2;
-}
-
-// all fields are the same in every lane: keep them in scalar registers
-__device__ __forceinline__ void pp_curve_scalarize(PPCurve& c) {
-    c.qx = pp_sgpr(c.qx); c.qy = pp_sgpr(c.qy); c.qth = pp_sgpr(c.qth); c.rho = pp_sgpr(c.rho); c.length = pp_sgpr(c.length);
-    c.rho_inv = pp_sgpr(c.rho_inv);
-    c.p0 = pp_sgpr(c.p0); c.p1 = pp_sgpr(c.p1); c.p2 = pp_sgpr(c.p2);
-    c.t0 = __builtin_amdgcn_readfirstlane(c.t0); c.t1 = __builtin_amdgcn_readfirstlane(c.t1); c.t2 = __builtin_amdgcn_readfirstlane(c.t2);
-    c.b1x = pp_sgpr(c.b1x); c.b1y = pp_sgpr(c.b1y); c.b1th = pp_sgpr(c.b1th);
-    c.b2x = pp_sgpr(c.b2x); c.b2y = pp_sgpr(c.b2y); c.b2th = pp_sgpr(c.b2th);
-    c.s0 = pp_sgpr(c.s0); c.c0 = pp_sgpr(c.c0); c.s1 = pp_sgpr(c.s1); c.c1 = pp_sgpr(c.c1); c.s2 = pp_sgpr(c.s2); c.c2 = pp_sgpr(c.c2);
-}
-
 // one segment of dubins_path_sample(): advance by tt from base (bx, by, bth) whose sin/cos are (sb, cb)
 __device__ __forceinline__ void pp_curve_seg(int type, double tt, double bx, double by, double bth, double sb, double cb,
                                              double& ux, double& uy, double& uth) {
@@ -434,41 +311,41 @@ __device__ __forceinline__ void pp_curve_seg(int type, double tt, double bx, dou
     } else {
         const double arg = (type == 0) ? (bth + tt) : (bth - tt);
         double s, co;
-        pp_sincos(arg, &s, &co);
+        pp_sincos_bounded(arg, &s, &co);
         if (type == 0) { ux = (+s - sb) + bx; uy = (-co + cb) + by; uth = tt + bth; }
         else           { ux = (-s + sb) + bx; uy = (+co - cb) + by; uth = -tt + bth; }
     }
 }
 
-// dubins_path_sample() for arc length `dist` already validated to lie in [0, length]:
-// pose (x, y, yaw in [0, 2pi)).  Called by the lanes holding valid steps (64 consecutive arc lengths): almost always
-// they all fall into the same segment, which is then handled with wave-uniform base values and a wave-uniform type.
-__device__ __forceinline__ void pp_curve_sample(const PPCurve& c, double dist, double& x, double& y, double& yaw) {
-    const double tprime = (c.rho_inv != 0.0) ? dist * c.rho_inv : dist / c.rho;
-    const bool in0 = tprime < c.p0;
-    const bool in1 = !in0 & (tprime < (c.p0 + c.p1));
-    const unsigned long long act = __ballot(true), m0 = __ballot(in0), m1 = __ballot(in1);
-    double ux, uy, uth;
-    if (m0 == act) {
-        pp_curve_seg(c.t0, tprime, 0.0, 0.0, c.qth, c.s0, c.c0, ux, uy, uth);
-    } else if (m1 == act) {
-        pp_curve_seg(c.t1, tprime - c.p0, c.b1x, c.b1y, c.b1th, c.s1, c.c1, ux, uy, uth);
-    } else if ((m0 | m1) == 0ull) {
-        pp_curve_seg(c.t2, tprime - c.p0 - c.p1, c.b2x, c.b2y, c.b2th, c.s2, c.c2, ux, uy, uth);
-    } else {
-        int type; double tt, bx, by, bth, sb, cb;
-        if (in0) {
-            type = c.t0; tt = tprime; bx = 0.0; by = 0.0; bth = c.qth; sb = c.s0; cb = c.c0;
-        } else if (in1) {
-            type = c.t1; tt = tprime - c.p0; bx = c.b1x; by = c.b1y; bth = c.b1th; sb = c.s1; cb = c.c1;
-        } else {
-            type = c.t2; tt = tprime - c.p0 - c.p1; bx = c.b2x; by = c.b2y; bth = c.b2th; sb = c.s2; cb = c.c2;
-        }
-        pp_curve_seg(type, tt, bx, by, bth, sb, cb, ux, uy, uth);
-    }
-    x = ux * c.rho + c.qx;
-    y = uy * c.rho + c.qy;
-    yaw = pp_mod2pi(uth);
+// One segment of a solved curve as the sweep wants it: the interval of tprime (arc length / rho) it covers, the two
+// subtractions dubins_path_sample() applies to tprime inside it (none / p0 / p0 then p1, in that order), and its base.
+struct PPSeg {
+    double bx, by, bth, sb, cb;   // base pose (unit radius, origin at qi), sin/cos of the base heading
+    double lo, hi;                // tprime in [lo, hi) is sampled on this segment
+    double o1, o2;                // tt = (tprime - o1) - o2
+    int type, pad;                // 0 = L, 1 = S, 2 = R
+};
+__device__ __forceinline__ void pp_curve_segments(const PPCurve& c, PPSeg* sg) {
+    sg[0] = PPSeg{0.0, 0.0, c.qth, c.s0, c.c0, -INFINITY, c.p0, 0.0, 0.0, c.t0, 0};
+    sg[1] = PPSeg{c.b1x, c.b1y, c.b1th, c.s1, c.c1, c.p0, c.p0 + c.p1, c.p0, 0.0, c.t1, 0};
+    sg[2] = PPSeg{c.b2x, c.b2y, c.b2th, c.s2, c.c2, c.p0 + c.p1, INFINITY, c.p0, c.p1, c.t2, 0};
+}
+// Wave-uniform reads of data written by an EARLIER kernel, through the constant address space: the compiler then always
+// issues scalar loads (s_load) for them, which it otherwise only does where it can prove no store in this kernel aliases.
+#define PP_AS4 __attribute__((address_space(4)))
+__device__ __forceinline__ const PP_AS4 double* pp_const_f64(const void* p) { return (const PP_AS4 double*)(unsigned long long)p; }
+__device__ __forceinline__ const PP_AS4 int* pp_const_i32(const void* p) { return (const PP_AS4 int*)(unsigned long long)p; }
+__device__ __forceinline__ const PP_AS4 unsigned long long* pp_const_u64(const void* p) { return (const PP_AS4 unsigned long long*)(unsigned long long)p; }
+__device__ __forceinline__ PPSeg pp_seg_load_uniform(const PPSeg* g) {
+    const PP_AS4 double* d = pp_const_f64(g);
+    PPSeg s;
+    s.bx = d[0]; s.by = d[1]; s.bth = d[2]; s.sb = d[3]; s.cb = d[4]; s.lo = d[5]; s.hi = d[6]; s.o1 = d[7]; s.o2 = d[8];
+    s.type = pp_const_i32(g)[18]; s.pad = 0;
+    return s;
+}
+// which segment dubins_path_sample() picks for tprime: `tprime < p0`, else `tprime < p0 + p1`, else the third
+__device__ __forceinline__ int pp_seg_of(double tprime, double hi0, double hi1) {
+    return (tprime < hi0) ? 0 : ((tprime < hi1) ? 1 : 2);
 }
 
 // ----------------------------------------------------------------------------- occupancy grid
@@ -653,10 +530,12 @@ __device__ inline int pp_ribbons_event(PPRibbon& r, int n, double w, double x, d
     const bool st = cp & ltS & doCover;
     // minDistanceFrom: 0 as soon as one ribbon contains the point (non-strict width), else nearest endpoint
     if (__ballot(ns) == 0ull) {
-        const double dStart = pp_dist(r.sx, r.sy, x, y);
-        const double dEnd = pp_dist(r.ex, r.ey, x, y);
-        const double m = act ? fmin(fmin(PP_DBL_MAX, dEnd), dStart) : PP_DBL_MAX;
-        D = pp_min_first_n(m, n);
+        // min over endpoints of sqrt(squared distance) (RibbonManager.h:285-287) = sqrt of the min: sqrt is monotone
+        // and correctly rounded, so one square root after the reduction gives the same double
+        const double qS = (r.sx - x) * (r.sx - x) + (r.sy - y) * (r.sy - y);
+        const double qE = (r.ex - x) * (r.ex - x) + (r.ey - y) * (r.ey - y);
+        const double m = act ? fmin(qE, qS) : PP_DBL_MAX;
+        D = fmin(PP_DBL_MAX, sqrt(pp_min_first_n(m, n)));
     }
     if (!doCover) { adv = -2; return n; }                            // nothing can change without cover()
     const double minLength = 2 * w;                                  // Ribbon::minLength (Ribbon.cpp:52-58)

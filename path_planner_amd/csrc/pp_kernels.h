@@ -7,6 +7,7 @@
 struct PPParams {
     // PlannerConfig / Edge constants / RibbonManager settings
     double max_speed, slow_speed, rho, rho_cov, horizon, tmin, inc_d, sst, ribw, cpf, tpf;
+    double inv_inc_d;                    // 1 / inc_d (host division): first guess of a quotient that is then verified
     int heuristic, tsp_k;
     // world
     PPGrid grid;
@@ -22,6 +23,31 @@ struct PPParams {
     int v0, nv; long long s0, ns; unsigned cfg_mask; int per;
     // outputs
     ppgpu_edge_result* out; double* child; int stride;
+    // A launch may be cut into slices of consecutive edges (n_edges = slice size): e_base = first edge of the slice in
+    // the caller's list, ws_base = where the slice's workspace starts.
+    long long e_base, ws_base;
+    // workspace: one PPEdgeSetup per edge from pp_k_solve_edges, then the pose sweep's track of each edge
+    struct PPEdgeSetup* setup;
+    double2* track_pose;                 // [edge][ngp]  x, y of step k
+    unsigned short* track_hits;          // [edge][ngp]  dynamic-obstacle boxes hit at step k
+    unsigned long long* track_eq;        // [edge][nch]  bit k & 63 of word k >> 6: heading(k) == heading(k - 1)
+    unsigned* track_chunk_hits;          // [edge][nch]  hits summed over the chunk's executable steps
+    struct PPTrackSummary* track_summary;
+    int ngp, nch;                        // steps per edge rounded up to whole 64-step chunks, and that many chunks
+};
+
+// Phase 0 of an edge (Vertex::connect + Edge::computeApproxCost: which vertex/target/configuration, the Dubins word and
+// the constants of its curve), solved with one LANE per edge by pp_k_solve_edges and consumed with scalar loads by the
+// one-WAVE-per-edge sweep.  384 bytes, device-only.
+#define PP_SETUP_MALFORMED 1u   // descriptor out of range
+#define PP_SETUP_COLOCATED 2u   // State::isCoLocated(start, end): the reference throws
+struct __attribute__((aligned(128))) PPEdgeSetup {
+    PPSeg seg[3];                          // what the sweep keeps one of in registers at a time
+    double qx, qy, rho, rho_inv, length;   // DubinsPath::qi (position), rho, path length
+    double wStart, wEnd, speed;            // DubinsWrapper start / end time and speed
+    double approx, p0, p1, p2;             // Edge::approxCost, DubinsPath::param (only read when the record is written)
+    int type;                              // DubinsPathType, -1 = no path
+    unsigned vi, cbits, sflags;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -46,31 +72,8 @@ __global__ void pp_k_time_grid(const ppgpu_vertex* verts, int nverts, double sst
 }
 
 // ------------------------------------------------------------------------------------------
-// Edge costing: one wavefront per edge, 4 edges per 256-thread workgroup.
-//
-//   phase 0 (uniform)   Vertex::connect + Edge::computeApproxCost: Dubins solve, curve constants
-//   phase A (64 lanes)  64 consecutive collision-check steps at a time: closed-form pose,
-//                       occupancy lookup, dynamic-obstacle box tests
-//   phase B (uniform + ribbon-per-lane)  the sequential coverage state machine of
-//                       Edge.cpp:153-171, visited only at its event steps
-//   phase C             end state, last cover, cost, g/h/f, one 128-byte record per edge
-#ifndef PP_WPB
-#define PP_WPB 4   // wavefronts (= edges) per workgroup of the two per-edge kernels
-#endif
-#ifndef PP_MIN_WAVES
-#define PP_MIN_WAVES 6   // 2nd __launch_bounds__ argument: waves per SIMD the register allocator must leave room for
-                         // (measured on MI355X, config 3: 1 -> 10.7 ms, 5 -> 10.6 ms, 6 -> 10.3 ms, 8 -> slower: spills)
-#endif
-__global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPParams p) {
-    __shared__ double lds_all[PP_WPB][PP_WAVE * 4];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = pp_lane();
-    const long long e = (long long)blockIdx.x * PP_WPB + wave;
-    if (e >= p.n_edges) return;
-    double* lds = lds_all[wave];
-
-    // ---- which edge
-    unsigned vi, target, cbits;
+// Which (vertex, target, configuration) edge `e` of the launch is: wrapper list, explicit list or dense enumeration.
+__device__ __forceinline__ void pp_edge_decode(const PPParams& p, long long e, unsigned& vi, unsigned& target, unsigned& cbits) {
     if (p.wedges) {
         vi = (unsigned)p.wedges[e].vertex;
         target = 0;
@@ -90,27 +93,259 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPP
         for (int i = 0; i < rank; i++) m &= m - 1;   // drop `rank` lowest set bits
         cbits = (unsigned)(__ffs((int)m) - 1);
     }
-    vi = (unsigned)__builtin_amdgcn_readfirstlane((int)vi);
-    target = (unsigned)__builtin_amdgcn_readfirstlane((int)target);
-    cbits = (unsigned)__builtin_amdgcn_readfirstlane((int)cbits);
+}
 
-    unsigned flags = 0;
-    ppgpu_edge_result* rec = p.out + e;
+// Phase 0 for every edge of a launch, one lane per edge (Vertex::connect -> Edge::computeApproxCost ->
+// DubinsWrapper::set, Edge.cpp:14-18,73-76; Edge::setEnd(wrapper), Edge.cpp:208-216 for wrapper edges).
+__global__ __launch_bounds__(256) void pp_k_solve_edges(PPParams p) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.n_edges) return;
+    unsigned vi, target, cbits;
+    const long long eg = p.e_base + e;            // position in the caller's edge list; e = position in this slice
+    pp_edge_decode(p, eg, vi, target, cbits);
+    PPEdgeSetup* __restrict__ O = p.setup + p.ws_base + e;
+    PPCurve cv;
+    struct { double approx, wStart, wEnd, speed; int type; unsigned vi, cbits, sflags; } S;
+    S.vi = vi; S.cbits = cbits; S.sflags = 0; S.type = -1;
+    S.approx = S.wStart = S.wEnd = 0; S.speed = 1;
+    PPDubins dub;
+    dub.p0 = dub.p1 = dub.p2 = 0; dub.type = -1;
     if (vi >= (unsigned)p.nverts || (!p.wedges && (long long)target >= p.n_samples)) {
+        S.sflags = PP_SETUP_MALFORMED;
+        pp_curve_init(cv, 0, 0, 0, 1.0, dub);
+    } else {
+        const ppgpu_vertex* V = p.verts + vi;
+        const double srcX = V->x, srcY = V->y, srcH = V->heading, srcT = V->time;
+        double rho = (cbits & PPGPU_EDGE_COVERAGE) ? p.rho_cov : p.rho;             // Edge.cpp:73-76
+        double speed = (cbits & PPGPU_EDGE_SLOW) ? p.slow_speed : p.max_speed;
+        if (p.wedges) {
+            // the wrapper comes with the edge: DubinsWrapper::fill semantics, start time of ITS curve, possibly truncated end
+            const ppgpu_wrapper_edge* W = p.wedges + eg;
+            dub.p0 = W->param[0]; dub.p1 = W->param[1]; dub.p2 = W->param[2]; dub.type = W->type;
+            if (dub.type < 0 || dub.type > 5) dub.type = -1;
+            rho = W->rho; speed = W->speed;
+            pp_curve_init(cv, W->qi[0], W->qi[1], W->qi[2], rho, dub);
+            S.wStart = W->start_time; S.wEnd = W->end_time;
+            S.approx = (S.wEnd - srcT) * 1.0;                         // Edge::setEnd(wrapper), Edge.cpp:208-216
+        } else {
+            const double tgtX = p.sx[target], tgtY = p.sy[target], tgtH = p.sh[target];
+            if ((srcX == tgtX) && (srcY == tgtY) && (srcH == tgtH)) S.sflags |= PP_SETUP_COLOCATED;   // State::isCoLocated
+            pp_dubins_shortest(srcX, srcY, pp_yaw(srcH), tgtX, tgtY, pp_yaw(tgtH), rho, dub);
+            pp_curve_init(cv, srcX, srcY, pp_yaw(srcH), rho, dub);
+            S.approx = cv.length / speed * 1.0;                     // Edge.cpp:17
+            S.wStart = srcT;
+            S.wEnd = srcT + cv.length / speed;                      // DubinsWrapper::setEndTime
+        }
+        // the sweeps take sin/cos of (segment base heading +- arc) with the bounded-argument routine: refuse curves whose
+        // angles leave its range (a heading of tens of thousands of radians, or NaN) instead of sampling them wrongly
+        {
+            const double bound = fabs(cv.qth) + cv.p0 + (cv.t1 == 1 ? 0.0 : cv.p1) + cv.p2;
+            if (!(bound < 9.0e4)) dub.type = -1;
+        }
+        S.type = dub.type;
+        S.speed = speed;
+    }
+    pp_curve_segments(cv, O->seg);
+    O->qx = cv.qx; O->qy = cv.qy; O->rho = cv.rho; O->rho_inv = cv.rho_inv; O->length = cv.length;
+    O->p0 = cv.p0; O->p1 = cv.p1; O->p2 = cv.p2;
+    O->approx = S.approx; O->wStart = S.wStart; O->wEnd = S.wEnd; O->speed = S.speed;
+    O->type = S.type; O->vi = S.vi; O->cbits = S.cbits; O->sflags = S.sflags;
+}
+
+// ------------------------------------------------------------------------------------------
+// Edge costing = three launches over the same edge list, one wavefront-sized piece of work each:
+//
+//   pp_k_solve_edges  (lane per edge)  phase 0: Vertex::connect + Edge::computeApproxCost: Dubins solve, curve constants
+//   pp_k_pose_sweep   (wave per edge)  phase A: 64 consecutive collision-check steps at a time: closed-form pose,
+//                                      occupancy lookup, dynamic-obstacle box tests  ->  the edge's "track"
+//   pp_k_cover_sweep  (wave per edge)  phase B: the sequential coverage state machine of Edge.cpp:153-171, visited only
+//                                      at its event steps (ribbon per lane); phase C: end state, last cover, cost, g,
+//                                      one 128-byte record per edge
+//
+// The track (x, y of every step, hit counts, heading-unchanged bits) goes through HBM between the two sweeps.  Fused
+// in one kernel the state machine's registers and the pose pipeline's registers are live together and the loop spills;
+// apart, the pose sweep is a spill-free streaming kernel and the state machine reads only the steps it visits
+// (event poses by scalar load, runs of steps by one coalesced load).
+#ifndef PP_WPB
+#define PP_WPB 4   // wavefronts (= edges) per workgroup of the per-edge kernels
+#endif
+#ifndef PP_MIN_WAVES
+#define PP_MIN_WAVES 6   // cover sweep: waves per SIMD the register allocator must leave room for
+#endif
+#define PP_SF64(field) (pp_const_f64(&S->field)[0])
+#define PP_SI32(field) (pp_const_i32(&S->field)[0])
+
+// per-edge result of the pose sweep
+struct PPTrackSummary {
+    int limit;      // steps [0, limit) can execute: the first blocked step, or the first step at/after the edge's end time
+    int blocked;    // 1: step `limit` exists and is blocked (Edge.cpp:144-147)
+    int dub_err;    // some sampled arc length fell outside the curve even after the reference's 1e-5 retry
+    int pad;
+};
+
+// e = the edge's slot in the workspace
+__device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long long e) {
+    const int lane = pp_lane();
+    const PPEdgeSetup* S = p.setup + e;
+    PPTrackSummary* sum = p.track_summary + e;
+    const unsigned sflags = (unsigned)PP_SI32(sflags);
+    const int dubType = PP_SI32(type);
+    if ((sflags & (PP_SETUP_MALFORMED | PP_SETUP_COLOCATED)) || dubType < 0) {
+        if (lane == 0) { sum->limit = 0; sum->blocked = 0; sum->dub_err = 0; sum->pad = 0; }
+        return;
+    }
+    const unsigned vi = (unsigned)PP_SI32(vi);
+    const bool cov = (((unsigned)PP_SI32(cbits)) & PPGPU_EDGE_COVERAGE) != 0;
+    const ppgpu_vertex* V = p.verts + vi;
+    const double srcH = pp_sgpr(V->heading);
+    const double wEnd = PP_SF64(wEnd), wStart = PP_SF64(wStart), speed = PP_SF64(speed);
+    const double cvLength = PP_SF64(length), cvRho = PP_SF64(rho), cvRhoInv = PP_SF64(rho_inv), cvQx = PP_SF64(qx), cvQy = PP_SF64(qy);
+    const double endTime = fmin(p.horizon + 1e-12 + p.sst, wEnd);    // Edge.cpp:90 (the cover sweep may end the edge earlier)
+    // the segment of the curve the sweep is on: its constants live in scalar registers, the other two stay in memory
+    int cur = 0;
+    PPSeg cs = pp_seg_load_uniform(&S->seg[0]);
+
+    const double* tg = p.tgrid + (size_t)vi * p.ng;
+    double2* track = p.track_pose + (size_t)e * p.ngp;
+    unsigned short* thits = p.track_hits + (size_t)e * p.ngp;
+    unsigned long long* teq = p.track_eq + (size_t)e * p.nch;
+    unsigned* tch = p.track_chunk_hits + (size_t)e * p.nch;
+    // bounds used by the obstacle culling: how far the vehicle / time advance over one 64-step chunk
+    const double chunkTime = 64.0 * (p.inc_d / p.max_speed);
+    const double chunkSpan = 64.0 * (p.inc_d / p.max_speed) * speed;
+    double carryHeading = srcH;                                       // `lastHeading`, Edge.cpp:96
+    bool dubErr = false;
+    int limit = 0, blocked = 0;
+    // Can any obstacle come near this edge at all?  Every sampled pose lies within `travel` (arc length from the start of
+    // the curve) of the curve's first point, and an obstacle moves at most |Speed| * duration during the sweep: the same
+    // kind of exact bound as the per-chunk culling, applied once.
+    bool anyObstacle = false;
+#ifndef PP_ABL_NO_OBST
+    if (p.n_obst > 0 && p.ng > 0) {
+        const double t0 = pp_const_f64(tg)[0];
+        const double duration = fmax(endTime - t0, 0.0) + chunkTime;
+        const double travel = fmin(cvLength, fmax(endTime - wStart, 0.0) * speed) + 1e-3;
+        for (int b = 0; b < p.n_obst && !anyObstacle; b += PP_WAVE) {
+            bool near = false;
+            if (b + lane < p.n_obst) {
+                const PPObst o = p.obst[b + lane];
+                const double dt = t0 - o.Time;
+                const double X = o.X + o.Speed * dt * o.cosYaw, Y = o.Y + o.Speed * dt * o.sinYaw;
+                const double R = o.reach + travel + fabs(o.Speed) * duration + 1e-3;
+                const double dx = cvQx - X, dy = cvQy - Y;
+                near = !(dx * dx + dy * dy > R * R);
+            }
+            anyObstacle = __ballot(near) != 0ull;
+        }
+    }
+#endif
+
+    double tNext = (lane < p.ng) ? tg[lane] : INFINITY;
+    for (int base = 0;; base += PP_WAVE) {
+        const int k = base + lane;
+        const double t = tNext;
+        const double tFirst = pp_readlane(t, 0);
+        if (!(tFirst < endTime)) { limit = base; break; }             // `while (intermediate.time() < endTime)`
+        tNext = (k + PP_WAVE < p.ng) ? tg[k + PP_WAVE] : INFINITY;    // the next chunk's times travel while this one computes
+        const bool valid = t < endTime;
+        double x, y, heading;
+        bool blk = false;
+        int hits = 0;
+        {
+            // lanes past the end of the sweep redo lane 0's step (benign arithmetic, uniform control flow); masked below
+            const double tl = valid ? t : tFirst;
+            double dist = (tl - wStart) * speed;                      // DubinsWrapper.cpp:36
+            if (__ballot((dist < 0) | (dist > cvLength)) != 0ull) {   // rare: the first / last step of a curve
+                if (dist < 0 || dist > cvLength) dist = dist - 1e-5;  // EDUBPARAM retry, :39-42
+                if (dist < 0 || dist > cvLength) { dubErr = true; dist = fmin(fmax(dist, 0.0), cvLength); }
+            }
+            // dubins_path_sample(): 64 consecutive arc lengths almost always fall on the segment the previous chunk
+            // ended on, which is then advanced with wave-uniform constants
+            const double tprime = (cvRhoInv != 0.0) ? dist * cvRhoInv : dist / cvRho;
+            double ux, uy, uth;
+            bool uniformSeg = __ballot(!((tprime >= cs.lo) & (tprime < cs.hi))) == 0ull;
+            if (!uniformSeg) {
+                const double hi0 = PP_SF64(seg[0].hi), hi1 = PP_SF64(seg[1].hi);
+                const int mine = pp_seg_of(tprime, hi0, hi1);
+                const int firstSeg = __builtin_amdgcn_readfirstlane(mine);
+                const int lastSeg = __builtin_amdgcn_readlane(mine, 63 - __clzll((long long)__ballot(valid)));
+                if (__ballot(mine != firstSeg) != 0ull) {
+                    // the chunk straddles a junction: every lane takes its own segment's constants from memory
+                    const PPSeg* g = &S->seg[mine];
+                    pp_curve_seg(g->type, (tprime - g->o1) - g->o2, g->bx, g->by, g->bth, g->sb, g->cb, ux, uy, uth);
+                } else {
+                    uniformSeg = true;
+                    if (cur != firstSeg) { cur = firstSeg; cs = pp_seg_load_uniform(&S->seg[cur]); }
+                }
+                if (cur != lastSeg && !uniformSeg) { cur = lastSeg; cs = pp_seg_load_uniform(&S->seg[cur]); }
+            }
+            if (uniformSeg) pp_curve_seg(cs.type, (tprime - cs.o1) - cs.o2, cs.bx, cs.by, cs.bth, cs.sb, cs.cb, ux, uy, uth);
+            x = ux * cvRho + cvQx;
+            y = uy * cvRho + cvQy;
+            // the heading itself (:47) only matters for "unchanged since the last step" (Edge.cpp:159), which only matters
+            // on edges that may not cover while turning
+            heading = cov ? 0.0 : pp_heading_from_yaw(pp_mod2pi(uth));
+#ifndef PP_ABL_NO_GRID
+            blk = valid & pp_is_blocked(p.grid, x, y);                // Edge.cpp:144
+#endif
+        }
+#ifndef PP_ABL_NO_OBST
+        if (anyObstacle)                                              // :150-151
+            hits = pp_obstacle_hits_chunk(p.obst, p.n_obst, x, y, t, valid, pp_readlane(x, 0), pp_readlane(y, 0), tFirst, chunkSpan, chunkTime);
+#endif
+        unsigned long long eqMask = ~0ull;
+        if (!cov) {
+            double prevHeading = __shfl_up(heading, 1, PP_WAVE);
+            if (lane == 0) prevHeading = carryHeading;
+            eqMask = __ballot(prevHeading == heading);
+            carryHeading = pp_readlane(heading, 63);
+        }
+
+        const unsigned long long bm = __ballot(blk);
+        const int fb = bm ? (__ffsll((long long)bm) - 1) : PP_WAVE;
+        const int nvalid = __popcll(__ballot(valid));
+        const int nlim = fb < nvalid ? fb : nvalid;
+
+        track[k] = make_double2(x, y);                                // k < ngp: ngp is ng rounded up to whole chunks
+        int chunkHits = 0;
+        if (__ballot(hits != 0) != 0ull) {
+            // per-step counts are only ever read for a chunk whose sum is not zero
+            chunkHits = pp_wave_sum_i(lane < nlim ? hits : 0);
+            thits[k] = (unsigned short)(hits > 65535 ? 65535 : hits);
+        }
+        if (lane == 0) {
+            tch[base >> 6] = (unsigned)chunkHits;
+            if (!cov) teq[base >> 6] = eqMask;                        // only read for edges that may not cover while turning
+        }
+
+        if (fb < nvalid) { limit = base + fb; blocked = 1; break; }
+        if (nvalid < PP_WAVE) { limit = base + nvalid; break; }
+        limit = base + PP_WAVE;
+    }
+    const int anyErr = (__ballot(dubErr) != 0ull) ? 1 : 0;
+    if (lane == 0) { sum->limit = limit; sum->blocked = blocked; sum->dub_err = anyErr; sum->pad = 0; }
+}
+
+// e = the edge's slot in the workspace, eg = its position in the caller's edge list, lds = 256 doubles private to the wave
+__device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const long long e, const long long eg, double* lds) {
+    const int lane = pp_lane();
+
+    // ---- phase 0 was done by pp_k_solve_edges: everything here is wave-uniform and arrives through scalar loads
+    const PPEdgeSetup* S = p.setup + e;
+    unsigned flags = 0;
+    ppgpu_edge_result* rec = p.out + eg;
+    const unsigned sflags = (unsigned)PP_SI32(sflags);
+    if (sflags & PP_SETUP_MALFORMED) {
         // malformed descriptor: fail loudly in the record, touch nothing else
         if (lane == 0) { rec->flags = PPGPU_F_INFEASIBLE | PPGPU_F_THROWS | PPGPU_F_DUBINS_ERR; rec->info = 0; }
         return;
     }
-
+    const unsigned vi = (unsigned)PP_SI32(vi), cbits = (unsigned)PP_SI32(cbits);
     const ppgpu_vertex* V = p.verts + vi;
-    const double srcX = pp_sgpr(V->x), srcY = pp_sgpr(V->y), srcH = pp_sgpr(V->heading), srcT = pp_sgpr(V->time), srcG = pp_sgpr(V->g);
+    const double srcX = pp_sgpr(V->x), srcY = pp_sgpr(V->y), srcT = pp_sgpr(V->time), srcG = pp_sgpr(V->g);
     double cct = pp_sgpr(V->coverage_completed_time);
     int nrib = __builtin_amdgcn_readfirstlane(V->ribbon_count);
     const bool cov = (cbits & PPGPU_EDGE_COVERAGE) != 0;
-    double rho = cov ? p.rho_cov : p.rho;                             // Edge.cpp:73-76
-    double speed = (cbits & PPGPU_EDGE_SLOW) ? p.slow_speed : p.max_speed;
-    double tgtX = 0, tgtY = 0, tgtH = 0;
-    if (!p.wedges) { tgtX = p.sx[target]; tgtY = p.sy[target]; tgtH = p.sh[target]; }
 
     // this vertex's ribbons, one per lane (Vertex::connect copies the parent's RibbonManager, Vertex.cpp:24)
     PPRibbon rib = {0, 0, 0, 0};
@@ -121,158 +356,92 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPP
     }
     const bool startedDone = (nrib == 0);                             // Edge.cpp:93
 
-    // ---- phase 0: the curve (Edge::computeApproxCost -> DubinsWrapper::set)
-    bool colocated = false;
-    PPDubins dub;
-    PPCurve cv;
-    double approx, wEnd, wStart;
-    if (p.wedges) {
-        // the wrapper comes with the edge: DubinsWrapper::fill semantics, start time of ITS curve, possibly truncated end
-        const ppgpu_wrapper_edge* W = p.wedges + e;
-        dub.p0 = W->param[0]; dub.p1 = W->param[1]; dub.p2 = W->param[2]; dub.type = W->type;
-        if (dub.type < 0 || dub.type > 5) dub.type = -1;
-        rho = W->rho; speed = W->speed;
-        pp_curve_init_wave(cv, W->qi[0], W->qi[1], W->qi[2], rho, dub);
-        wStart = W->start_time; wEnd = W->end_time;
-        approx = (wEnd - srcT) * 1.0;                                 // Edge::setEnd(wrapper), Edge.cpp:208-216
-    } else {
-        colocated = (srcX == tgtX) && (srcY == tgtY) && (srcH == tgtH);              // State::isCoLocated
-        pp_dubins_shortest_wave(srcX, srcY, pp_yaw(srcH), tgtX, tgtY, pp_yaw(tgtH), rho, dub);
-        pp_curve_init_wave(cv, srcX, srcY, pp_yaw(srcH), rho, dub);
-        approx = cv.length / speed * 1.0;                             // Edge.cpp:17
-        wStart = srcT;
-        wEnd = srcT + cv.length / speed;                              // DubinsWrapper::setEndTime
-    }
-    // everything computed so far is identical in all 64 lanes: move it to scalar registers
-    pp_curve_scalarize(cv);
-    dub.p0 = pp_sgpr(dub.p0); dub.p1 = pp_sgpr(dub.p1); dub.p2 = pp_sgpr(dub.p2); dub.type = __builtin_amdgcn_readfirstlane(dub.type);
-    approx = pp_sgpr(approx); wEnd = pp_sgpr(wEnd); wStart = pp_sgpr(wStart); rho = pp_sgpr(rho); speed = pp_sgpr(speed);
-    double endTime = pp_sgpr(fmin(p.horizon + 1e-12 + p.sst, wEnd));  // Edge.cpp:90
+    const int dubType = PP_SI32(type);
+    const double wEnd = PP_SF64(wEnd), wStart = PP_SF64(wStart), speed = PP_SF64(speed);
+    const double endTime0 = fmin(p.horizon + 1e-12 + p.sst, wEnd);    // Edge.cpp:90
+    double endTime = endTime0;
     bool infeasible = (srcT >= endTime);                              // :102-110
-    bool throwsRef = colocated || (dub.type < 0);
-    if (dub.type < 0) flags |= PPGPU_F_DUBINS_ERR;
+    bool throwsRef = ((sflags & PP_SETUP_COLOCATED) != 0) || (dubType < 0);
+    if (dubType < 0) flags |= PPGPU_F_DUBINS_ERR;
 
-    // ---- sweep state
+    // ---- the pose sweep's track of this edge
+    const PPTrackSummary* sum = p.track_summary + e;
+    const int limit = pp_const_i32(&sum->limit)[0];
+    const bool blockedAtLimit = pp_const_i32(&sum->blocked)[0] != 0;
+    if (pp_const_i32(&sum->dub_err)[0]) flags |= PPGPU_F_DUBINS_ERR;
+    const double2* track = p.track_pose + (size_t)e * p.ngp;
+    const unsigned long long* teq = p.track_eq + (size_t)e * p.nch;
     const double* tg = p.tgrid + (size_t)vi * p.ng;
+
 #ifdef PP_DBG_EVENTS
     int dbgEvents = 0;
 #endif
     int rdt = -1;                       // `auto ribbonsDoneTime = -1;` is an int (Edge.cpp:92)
     int nextEvent = 0;                  // toCoverDistance starts at 0: step 0 is an event
-    int hitsAcc = 0;
-    int steps = 0;
-    double ix = srcX, iy = srcY, ih = srcH;   // `intermediate` pose
-    double lastHeading = srcH;                // Edge.cpp:96
-    double carryHeading = srcH;
-    double tfinal = tg[0];
-    bool dubErr = false;
+    int lastEv = -1;
     const double w = p.ribw;
     const double inc_d = p.inc_d;
-    // bounds used by the obstacle culling: how far the vehicle / time advance over one 64-step chunk
-    const double chunkTime = 64.0 * (p.inc_d / p.max_speed);
-    const double chunkSpan = 64.0 * (p.inc_d / p.max_speed) * speed;
 
+    // ---- phase B: coverage events among steps [0, limit)
+#ifdef PP_ABL_NO_EVENTS
+    nextEvent = 1 << 30;
+#endif
     if (!throwsRef) {
-        for (int base = 0;; base += PP_WAVE) {
+        bool ended = false;
+        while (!ended) {
+            if (nextEvent >= limit) break;
+            // the 64-step chunk of the track that holds the next event, one step per lane (chunks without events are
+            // never loaded)
+            const int base = nextEvent & ~(PP_WAVE - 1);
             const int k = base + lane;
             const double t = (k < p.ng) ? tg[k] : INFINITY;
-            const double tFirst = pp_readlane(t, 0);
-            if (!(tFirst < endTime)) { tfinal = tFirst; break; }      // `while (intermediate.time() < endTime)`
-            const bool valid = t < endTime;
-
-            // phase A: pose + static + dynamic obstacles for 64 steps
-            double x = 0, y = 0, heading = 0;
-            bool blk = false;
-            int hits = 0;
-            if (valid) {
-                double dist = (t - wStart) * speed;                   // DubinsWrapper.cpp:36
-                if (dist < 0 || dist > cv.length) dist = dist - 1e-5; // EDUBPARAM retry, :39-42
-                if (dist < 0 || dist > cv.length) { dubErr = true; dist = fmin(fmax(dist, 0.0), cv.length); }
-                double yaw;
-#ifdef PP_ABL_NO_POSE
-                x = srcX + dist * 1e-3; y = srcY; yaw = 1.0;
-#else
-                pp_curve_sample(cv, dist, x, y, yaw);
-#endif
-                heading = pp_heading_from_yaw(yaw);                   // :47
-#ifndef PP_ABL_NO_GRID
-                blk = pp_is_blocked(p.grid, x, y);                    // Edge.cpp:144
-#endif
-            }
-#ifndef PP_ABL_NO_OBST
-            if (p.n_obst > 0)                                         // :150-151
-                hits = pp_obstacle_hits_chunk(p.obst, p.n_obst, x, y, t, valid, pp_readlane(x, 0), pp_readlane(y, 0), tFirst,
-                                              chunkSpan, chunkTime);
-#endif
-            double prevHeading = __shfl_up(heading, 1, PP_WAVE);
-            if (lane == 0) prevHeading = carryHeading;
+            double2 q = make_double2(0.0, 0.0);
+            if (k < limit) q = track[k];
             // Edge.cpp:159: cover only when coverage is allowed on this edge or the heading did not change since the last step
-            const unsigned long long coverMask = cov ? ~0ull : __ballot(prevHeading == heading);
-
-            const unsigned long long bm = __ballot(blk);
-            const int fb = bm ? (__ffsll((long long)bm) - 1) : PP_WAVE;
-            const int nvalid = __popcll(__ballot(valid));
-            const int limit = fb < nvalid ? fb : nvalid;
-
-            // phase B: coverage events among steps [0, limit)
-            int lastEv = -1;
-            bool runFailed = false, quietFailed = false;
-#ifdef PP_ABL_NO_EVENTS
-            nextEvent = 1 << 30;
-#endif
+            const unsigned long long coverMask = cov ? ~0ull : pp_const_u64(teq + (base >> 6))[0];
+            const int climit = (limit - base) < PP_WAVE ? (limit - base) : PP_WAVE;
+            bool runFailed = false;
             while (true) {
-                const int j = __builtin_amdgcn_readfirstlane(nextEvent - base);
-                if (j >= limit) break;
+                const int j = nextEvent - base;
+                if (j >= climit) break;
                 const double tj = pp_readlane(t, j);
-                if (!(tj < endTime)) break;
-                const double xj = pp_readlane(x, j), yj = pp_readlane(y, j);
-                double D;                                                                 // Edge.cpp:158-161
+                if (!(tj < endTime)) { ended = true; break; }         // `while (intermediate.time() < endTime)`
+                const double xj = pp_readlane(q.x, j), yj = pp_readlane(q.y, j);
+                double D;                                             // Edge.cpp:158-161
                 int adv;
                 nrib = pp_ribbons_event(rib, nrib, w, xj, yj, ((coverMask >> j) & 1ull) != 0ull, lds, D, adv);
                 if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
 #ifndef PP_NO_CORRIDOR_RUN
-                if (adv >= 0 && j + 1 < limit && !runFailed) {
-                    // this event only moved one piece's start: the following steps very likely do the same
+                if (adv >= 0 && j + 1 < climit && !runFailed) {
+                    // this event only moved one piece's endpoint: the following steps very likely do the same
                     double nsx, nsy;
                     const bool moveEnd = (adv & 0x100) != 0;
                     const int piece = adv & 0xff;
-                    const int L = pp_corridor_run(rib, nrib, w, piece, moveEnd, x, y, (lane < limit) & (t < endTime), coverMask, j + 1, nsx, nsy);
+                    const int L = pp_corridor_run(rib, nrib, w, piece, moveEnd, q.x, q.y, (lane < climit) & (t < endTime), coverMask, j + 1, nsx, nsy);
                     runFailed = (L == 0);                  // do not keep paying for attempts that do not start
                     if (L > 0) {
                         if (lane == piece) {
                             if (moveEnd) { rib.ex = nsx; rib.ey = nsy; } else { rib.sx = nsx; rib.sy = nsy; }
                         }
-                        lastEv = j + L;
+                        lastEv = base + j + L;
                         nextEvent = base + j + L + 1;      // inside the corridor minDistanceFrom is 0: the next step is an event too
                         continue;
                     }
                 }
-#ifdef PP_QUIET_RUN   // opt-in: absorbs the non-mutating in-corridor events too, but costs ~18 VGPRs (one wave of occupancy)
-                else if (adv == -2 && D == 0 && nrib > 0 && j + 1 < limit && !quietFailed) {
-                    // inside a corridor, nothing changed: the following steps are very likely the same kind of event
-                    const int L = pp_quiet_run(rib, nrib, w, x, y, (lane < limit) & (t < endTime), coverMask, j + 1);
-                    quietFailed = (L == 0);
-                    if (L > 0) {
-                        lastEv = j + L;
-                        nextEvent = base + j + L + 1;
-                        continue;
-                    }
-                }
 #endif
-#endif
-                if (nrib == 0) {                                                          // :162-170
+                if (nrib == 0) {                                      // :162-170
                     if (cct == -1) cct = tj;
                     rdt = (int)tj;
                     endTime = fmin(endTime, cct + p.tmin);
                 }
-                lastEv = j;
+                lastEv = base + j;
 #ifdef PP_DBG_EVENTS
                 dbgEvents++;
 #endif
                 // steps until toCoverDistance <= increment again (:153-154): m subtractions
                 int m = 0;
                 if (D > inc_d) {
-                    const double qd = D / inc_d;
+                    const double qd = D * p.inv_inc_d;                 // a guess good to an ulp or two; m0 is verified below
                     if (qd > (double)(p.ng + 2)) {
                         m = p.ng + 1;                                  // beyond the grid: never again
                     } else {
@@ -289,48 +458,70 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPP
                 }
                 nextEvent = base + j + m + 1;
             }
-
-            const int cnt = __popcll(__ballot(valid && (t < endTime)));
-            int nexec = cnt > lastEv + 1 ? cnt : lastEv + 1;
-            nexec = nexec < limit ? nexec : limit;
-            if (lane < nexec) hitsAcc += hits;
-
-            if (fb < nvalid && nexec == fb) {           // reached the blocked step: `break` at :146
-                infeasible = true;
-                ix = pp_readlane(x, fb); iy = pp_readlane(y, fb); ih = pp_readlane(heading, fb);
-                lastHeading = pp_readlane(prevHeading, fb);
-                tfinal = pp_readlane(t, fb);
-                steps = base + fb + 1;
-                break;
-            }
-            if (nexec < PP_WAVE) {                      // loop condition failed inside this chunk
-                ix = pp_readlane(x, nexec - 1); iy = pp_readlane(y, nexec - 1); ih = pp_readlane(heading, nexec - 1);
-                lastHeading = ih;
-                tfinal = pp_readlane(t, nexec);
-                steps = base + nexec;
-                break;
-            }
-            ix = pp_readlane(x, 63); iy = pp_readlane(y, 63); ih = pp_readlane(heading, 63);
-            lastHeading = ih;
-            carryHeading = ih;
-            steps = base + PP_WAVE;
         }
     }
-    if (__ballot(dubErr) != 0ull) flags |= PPGPU_F_DUBINS_ERR;
+
+    // ---- where the loop of Edge.cpp:143-175 stopped
+    int steps = 0;
+    double ix = srcX, iy = srcY;        // `intermediate` position
+    double tfinal = (p.ng > 0) ? pp_const_f64(tg)[0] : INFINITY;
+    bool coverFinal = true;             // `lastHeading == intermediate.heading()` unless the loop broke at a blocked step
+    int hexec = 0;                      // steps whose obstacle hits count
+    if (!throwsRef) {
+        // cnt = steps k < limit with t_k < endTime (the time grid is non-decreasing)
+        int cnt = limit;
+        if (endTime != endTime0) {
+            int lo = 0, hi = limit;
+            while (hi > lo) {
+                const int span = hi - lo, stride = (span + 63) >> 6;
+                const int k = lo + lane * stride;
+                const bool lt = (k < hi) && (tg[k] < endTime);
+                const int c = __popcll(__ballot(lt));
+                if (c == 0) { hi = lo; break; }
+                const int nlo = lo + (c - 1) * stride + 1;
+                const int nhi = lo + c * stride;
+                hi = nhi < hi ? nhi : hi;
+                lo = nlo;
+            }
+            cnt = lo;
+        }
+        int nexec = cnt > lastEv + 1 ? cnt : lastEv + 1;
+        nexec = nexec < limit ? nexec : limit;
+        if (blockedAtLimit && nexec == limit) {             // reached the blocked step: `break` at :146
+            infeasible = true;
+            ix = pp_const_f64(&track[limit].x)[0]; iy = pp_const_f64(&track[limit].y)[0];
+            coverFinal = cov || (((pp_const_u64(teq + (limit >> 6))[0] >> (limit & 63)) & 1ull) != 0ull);
+            tfinal = pp_const_f64(tg + limit)[0];
+            steps = limit + 1;
+            hexec = limit;
+        } else {                                            // loop condition failed
+            if (nexec > 0) { ix = pp_const_f64(&track[nexec - 1].x)[0]; iy = pp_const_f64(&track[nexec - 1].y)[0]; }
+            tfinal = (nexec < p.ng) ? pp_const_f64(tg + nexec)[0] : INFINITY;
+            steps = nexec;
+            hexec = nexec;
+        }
+    }
 
     // ---- phase C
     // end()->state().time() = endTime; wrapper.sample(end state)  (Edge.cpp:177-178)
     if (!throwsRef && !(wStart <= endTime && wEnd >= endTime)) throwsRef = true;  // DubinsWrapper::containsTime
     double endX = 0, endY = 0, endHeading = 0;
+    int hitsTotal = 0;
     if (!throwsRef) {
+        const double cvLength = PP_SF64(length), cvRho = PP_SF64(rho), cvRhoInv = PP_SF64(rho_inv);
         double dist = (endTime - wStart) * speed;
-        if (dist < 0 || dist > cv.length) dist = dist - 1e-5;
-        if (dist < 0 || dist > cv.length) { flags |= PPGPU_F_DUBINS_ERR; dist = fmin(fmax(dist, 0.0), cv.length); }
-        double yaw;
-        pp_curve_sample(cv, dist, endX, endY, yaw);
-        endHeading = pp_heading_from_yaw(yaw);
+        if (dist < 0 || dist > cvLength) dist = dist - 1e-5;
+        if (dist < 0 || dist > cvLength) { flags |= PPGPU_F_DUBINS_ERR; dist = fmin(fmax(dist, 0.0), cvLength); }
+        const double tprime = (cvRhoInv != 0.0) ? dist * cvRhoInv : dist / cvRho;
+        const int es = __builtin_amdgcn_readfirstlane(pp_seg_of(tprime, PP_SF64(seg[0].hi), PP_SF64(seg[1].hi)));
+        const PPSeg cs = pp_seg_load_uniform(&S->seg[es]);
+        double ux, uy, uth;
+        pp_curve_seg(cs.type, (tprime - cs.o1) - cs.o2, cs.bx, cs.by, cs.bth, cs.sb, cs.cb, ux, uy, uth);
+        endX = ux * cvRho + PP_SF64(qx);
+        endY = uy * cvRho + PP_SF64(qy);
+        endHeading = pp_heading_from_yaw(pp_mod2pi(uth));
         // cover the last little bit (:182-191)
-        if (cov || lastHeading == ih) {
+        if (cov || coverFinal) {
             double Dunused;
             int advUnused;
             nrib = pp_ribbons_event(rib, nrib, w, ix, iy, true, lds, Dunused, advUnused);
@@ -340,8 +531,18 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPP
             if (cct == -1) cct = tfinal;
             rdt = (int)tfinal;
         }
+        // obstacle hits of the executed steps (:150-151 summed): whole chunks from the pose sweep's per-chunk sums, the
+        // last partial chunk step by step
+        const unsigned* tch = p.track_chunk_hits + (size_t)e * p.nch;
+        const unsigned short* thits = p.track_hits + (size_t)e * p.ngp;
+        const int cfull = hexec >> 6;
+        int acc = 0;
+        if (p.n_obst > 0) {
+            for (int c = lane; c < cfull; c += PP_WAVE) acc += (int)tch[c];
+            if ((hexec & 63) != 0 && tch[cfull] != 0u && (cfull << 6) + lane < hexec) acc += (int)thits[(cfull << 6) + lane];
+            hitsTotal = pp_wave_sum_i(acc);
+        }
     }
-    const int hitsTotal = pp_wave_sum_i(hitsAcc);
     const double penalty = (double)hitsTotal * p.cpf;                             // :150-151 summed
     const double netTime = endTime - srcT;                                        // Edge::netTime
     double tc = fmax(netTime - ((nrib == 0) ? (endTime - (double)rdt) : 0), 0);  // :197
@@ -367,14 +568,14 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPP
 #ifdef PP_DBG_EVENTS
         steps = dbgEvents;
 #endif
-        const unsigned info = (unsigned)((dub.type < 0 ? 0 : dub.type) & 0xff) | ((unsigned)(nrib & 0xff) << 8) |
+        const unsigned info = (unsigned)((dubType < 0 ? 0 : dubType) & 0xff) | ((unsigned)(nrib & 0xff) << 8) |
                               ((unsigned)(steps & 0xffff) << 16);
         double v;
         switch (lane) {
             case 0: v = __hiloint2double((int)info, (int)flags); break;   // {flags (low), info (high)}
             case 1: v = trueCost; break;
             case 2: v = penalty; break;
-            case 3: v = approx; break;
+            case 3: v = PP_SF64(approx); break;
             case 4: v = endX; break;
             case 5: v = endY; break;
             case 6: v = endHeading; break;
@@ -384,9 +585,9 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPP
             case 10: v = h; break;
             case 11: v = g + h; break;
             case 12: v = cct; break;
-            case 13: v = dub.p0; break;
-            case 14: v = dub.p1; break;
-            default: v = dub.p2; break;
+            case 13: v = PP_SF64(p0); break;
+            case 14: v = PP_SF64(p1); break;
+            default: v = PP_SF64(p2); break;
         }
         if (throwsRef && lane != 0) v = 0;
         if (lane < 16) reinterpret_cast<double*>(rec)[lane] = v;
@@ -394,10 +595,26 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cost_edges(PPP
     if (!throwsRef) {
         if (nrib > p.stride && lane == 0) rec->flags = flags | PPGPU_F_RIBBON_OVF;   // after the record store above
         if (lane < nrib && lane < p.stride) {
-            double* c = p.child + ((size_t)e * p.stride + lane) * 4;
+            double* c = p.child + ((size_t)eg * p.stride + lane) * 4;
             c[0] = rib.sx; c[1] = rib.sy; c[2] = rib.ex; c[3] = rib.ey;
         }
     }
+}
+
+#ifndef PP_POSE_MIN_WAVES
+#define PP_POSE_MIN_WAVES 7
+#endif
+// n_edges = slice size (ppgpu.hip: launch_cost)
+__global__ __launch_bounds__(PP_WPB * 64, PP_POSE_MIN_WAVES) void pp_k_pose_sweep(PPParams p) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long idx = (long long)blockIdx.x * PP_WPB + wave;
+    if (idx < p.n_edges) pp_pose_sweep_edge(p, p.ws_base + idx);
+}
+__global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep(PPParams p) {
+    __shared__ double lds_all[PP_WPB][PP_WAVE * 4];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long idx = (long long)blockIdx.x * PP_WPB + wave;
+    if (idx < p.n_edges) pp_cover_sweep_edge(p, p.ws_base + idx, p.e_base + idx, lds_all[wave]);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -27,6 +27,13 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
             return fail(PPGPU_EHIP, std::string(#call) + ": " + hipGetErrorString(_e));            \
     } while (0)
 
+// Workspace of one costing slice: PPEdgeSetup + the pose sweep's track, (384 + 18 * ngp + 12 * nch + 16) bytes per edge
+// (~29 KB per edge for a 1 500-step horizon: 6.9 GB for the 236 140 edges of the bench step).  A launch whose workspace
+// would exceed PP_SLICE_BYTES runs as consecutive slices.  (Running slice i's cover sweep next to slice i+1's pose sweep
+// on a second stream was measured and gains nothing: both sweeps are bound by fp64 VALU issue.)
+#ifndef PP_SLICE_BYTES
+#define PP_SLICE_BYTES (32ull << 30)
+#endif
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -80,6 +87,13 @@ struct ppgpu_ctx {
     DevBuf<ppgpu_wrapper_edge> tmp_wedges;
     DevBuf<ppgpu_edge_result> tmp_results;
     DevBuf<double> tmp_child, tmp_lengths, tmp_len_out, int_child;
+    size_t slice_bytes = PP_SLICE_BYTES; // workspace budget of one costing slice (env PPGPU_SLICE_BYTES overrides: tests)
+    DevBuf<PPEdgeSetup> setup;          // workspace of the current costing slice: phase-0 records ...
+    DevBuf<double2> track_pose;         // ... and the pose sweep's track (see PPParams)
+    DevBuf<unsigned short> track_hits;
+    DevBuf<unsigned long long> track_eq;
+    DevBuf<unsigned> track_chunk_hits;
+    DevBuf<PPTrackSummary> track_summary;
     // optional per-kernel timing of costing launches (ppgpu_enable_timing)
     bool timing = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -114,6 +128,10 @@ int ppgpu_create(int device, ppgpu_ctx** out) {
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    if (const char* sb = std::getenv("PPGPU_SLICE_BYTES")) {
+        const long long v = std::atoll(sb);
+        if (v > 0) c->slice_bytes = (size_t)v;
+    }
     *out = c;
     return PPGPU_OK;
 }
@@ -127,6 +145,8 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->s_bytes.release(); c->s_u64.release(); c->s_u32a.release(); c->s_u32b.release(); c->s_cand.release();
     c->tmp_edges.release(); c->tmp_wedges.release(); c->partial.release(); c->tmp_results.release(); c->tmp_child.release();
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
+    c->setup.release(); c->track_pose.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
+    c->track_summary.release();
     for (int i = 0; i < 3; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -463,6 +483,7 @@ static void fill_params(ppgpu_ctx* c, PPParams& p) {
     p.rho = g.turning_radius; p.rho_cov = g.coverage_turning_radius;
     p.horizon = g.time_horizon; p.tmin = g.time_minimum; p.inc_d = g.collision_checking_increment;
     p.sst = g.start_state_time; p.ribw = g.ribbon_width;
+    p.inv_inc_d = 1.0 / p.inc_d;
     p.cpf = g.collision_penalty_factor; p.tpf = g.time_penalty_factor;
     p.heuristic = g.heuristic; p.tsp_k = g.tsp_k;
     p.grid = PPGrid{c->grid.p, c->rows, c->cols, c->wpr, c->res, c->res > 0 ? 1.0 / c->res : 0.0};
@@ -520,21 +541,50 @@ int64_t ppgpu_dense_edge_count(int32_t nv, int64_t ns, uint32_t cfg_mask) {
 
 static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     if (p.n_edges <= 0) return PPGPU_OK;
-    long long blocks = (p.n_edges + PP_WPB - 1) / PP_WPB;
-    if (blocks > 0x7fffffffll) return fail(PPGPU_ECAPACITY, "cost_edges: too many edges for one launch");
+    const long long total = p.n_edges;
+    if ((total + PP_WPB - 1) / PP_WPB > 0x3fffffffll) return fail(PPGPU_ECAPACITY, "cost_edges: too many edges for one launch");
     if (!p.child) {
         // the heuristic kernel reads the child ribbon lists: keep them in a scratch the caller never sees
         int stride = c->max_vertex_ribbons + 8;
         if (stride > PP_WAVE) stride = PP_WAVE;
-        int rc = c->int_child.reserve((size_t)p.n_edges * stride * 4, false, c->stream);
+        int rc = c->int_child.reserve((size_t)total * stride * 4, false, c->stream);
         if (rc) return rc;
         p.child = c->int_child.p;
         p.stride = stride;
     }
+    p.nch = (p.ng + PP_WAVE - 1) / PP_WAVE;
+    if (p.nch < 1) p.nch = 1;
+    p.ngp = p.nch * PP_WAVE;
+    const size_t per_edge = sizeof(PPEdgeSetup) + (size_t)p.ngp * (sizeof(double2) + sizeof(unsigned short)) +
+                            (size_t)p.nch * (sizeof(unsigned long long) + sizeof(unsigned)) + sizeof(PPTrackSummary);
+    long long slice = (long long)(c->slice_bytes / per_edge);
+    if (slice < PP_WPB) slice = PP_WPB;
+    if (slice > total) slice = total;
+    const size_t ws = (size_t)slice;
+    {
+        int rc;
+        if ((rc = c->setup.reserve(ws, false, c->stream)) ||
+            (rc = c->track_pose.reserve(ws * p.ngp, false, c->stream)) ||
+            (rc = c->track_hits.reserve(ws * p.ngp, false, c->stream)) ||
+            (rc = c->track_eq.reserve(ws * p.nch, false, c->stream)) ||
+            (rc = c->track_chunk_hits.reserve(ws * p.nch, false, c->stream)) ||
+            (rc = c->track_summary.reserve(ws, false, c->stream)))
+            return rc;
+    }
+    p.setup = c->setup.p; p.track_pose = c->track_pose.p; p.track_hits = c->track_hits.p; p.track_eq = c->track_eq.p;
+    p.track_chunk_hits = c->track_chunk_hits.p; p.track_summary = c->track_summary.p;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL(pp_k_cost_edges, dim3((unsigned)blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+    for (long long e0 = 0; e0 < total; e0 += slice) {
+        p.e_base = e0; p.ws_base = 0; p.n_edges = (total - e0 < slice) ? (total - e0) : slice;
+        const unsigned blocks = (unsigned)((p.n_edges + PP_WPB - 1) / PP_WPB);
+        hipLaunchKernelGGL(pp_k_solve_edges, dim3((unsigned)((p.n_edges + 255) / 256)), dim3(256), 0, c->stream, p);
+        hipLaunchKernelGGL(pp_k_pose_sweep, dim3(blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+        hipLaunchKernelGGL(pp_k_cover_sweep, dim3(blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+    }
+    p.e_base = 0;
+    p.n_edges = total;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    hipLaunchKernelGGL(pp_k_heuristic, dim3((unsigned)blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+    hipLaunchKernelGGL(pp_k_heuristic, dim3((unsigned)((total + PP_WPB - 1) / PP_WPB)), dim3(PP_WPB * 64), 0, c->stream, p);
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[2], c->stream)); c->ev_valid = true; }
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;

@@ -307,3 +307,31 @@ def test_full_size_properties_config3(torch_cuda):
     rep = compare_results(gpu[sub], cpu)
     print(rep)
     assert rep["ok"], rep
+
+
+def test_sliced_launch_is_bit_identical(torch_cuda, monkeypatch):
+    """A launch whose workspace exceeds the slice budget runs as consecutive slices (ppgpu.hip: launch_cost): same
+    records, same child ribbons, whatever the cut."""
+    from path_planner_amd import workloads
+    w = workloads.config2()
+    ctx, world, n, cs = _setup(w, 700)
+    whole, wchild = _dense(torch_cuda, ctx, 1, n, 0xF)
+    monkeypatch.setenv("PPGPU_SLICE_BYTES", str(3 << 20))          # a few hundred edges per slice, not a multiple of 4
+    ctx2, _, n2, _ = _setup(w, 700)
+    cut, cchild = _dense(torch_cuda, ctx2, 1, n2, 0xF)
+    assert n2 == n and whole.tobytes() == cut.tobytes() and wchild.tobytes() == cchild.tobytes()
+
+
+def test_out_of_range_heading_is_refused(torch_cuda):
+    """The sweeps' sin/cos covers |angle| < 9e4 rad; a source heading beyond that is refused loudly (DUBINS_ERR +
+    THROWS), never sampled approximately."""
+    from path_planner_amd import workloads
+    from path_planner_amd.types import F_DUBINS_ERR, F_THROWS, F_INFEASIBLE
+    w = workloads.config2()
+    ctx, world, n, cs = _setup(w, 64)
+    v = w.root().copy()
+    v["heading"] = 2.5e5
+    ctx.set_vertices(v, w.ribbons4)
+    res, _ = _dense(torch_cuda, ctx, 1, n, 0xF)
+    want = F_DUBINS_ERR | F_THROWS | F_INFEASIBLE
+    assert np.all((res["flags"] & want) == want)

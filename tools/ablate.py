@@ -21,6 +21,10 @@ VARIANTS = {
     "occ5": ["-DPP_MIN_WAVES=5"],
     "occ6": ["-DPP_MIN_WAVES=6"],
     "occ8": ["-DPP_MIN_WAVES=8"],
+    "pose4": ["-DPP_POSE_MIN_WAVES=4"],
+    "pose6": ["-DPP_POSE_MIN_WAVES=6"],
+    "pose7": ["-DPP_POSE_MIN_WAVES=7"],
+    "pose8": ["-DPP_POSE_MIN_WAVES=8"],
     "wpb1": ["-DPP_WPB=1"],
     "wpb2": ["-DPP_WPB=2"],
     "wpb8": ["-DPP_WPB=8"],
