@@ -49,6 +49,13 @@ __device__ __forceinline__ int pp_wave_sum_i(int v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, PP_WAVE);
     return v;
 }
+// x / d for small operands (x < 2^21, d > 0) without the integer-division expansion: (x + 0.5) / d is at least 0.5 / d
+// away from every integer while the float evaluation (x + 0.5 exact, rcp within 1 ulp, one rounded product) is off by
+// less than 2e-7 of its value, i.e. by less than 0.5 / d whenever x < 2.5e6: truncation gives the exact quotient.
+// (Largest use: 1 290 240 prefixes of an 8-ribbon TspPointRobotNoSplitAllRibbons tree.)
+__device__ __forceinline__ unsigned pp_udiv_small(unsigned x, unsigned d) {
+    return (unsigned)(((float)x + 0.5f) * __builtin_amdgcn_rcpf((float)d));
+}
 // orders this wave's LDS writes before its later LDS reads (single-wave producer/consumer)
 __device__ __forceinline__ void pp_wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
@@ -733,27 +740,35 @@ struct PPTspNode { double sf; unsigned ord; int pt; };   // accumulated distance
 //   #{ j : key_j > key_i }  +  #{ j before i : key_j == key_i }          (stable, descending)
 // computed as ranks, so nothing is swapped.  key_i = distance from point `pt` to the nearer endpoint of ribbon i,
 // read from the table KM[pt][i] = fmin(T[pt][start_i], T[pt][end_i]) built next to T.
-__device__ __forceinline__ unsigned pp_tsp_sort(const double* KM, unsigned ord, int rem, int pt) {
-    if (rem <= 1) return ord;        // nothing to order
-    double key[PP_TSP_MAX];
+template <int REM>
+__device__ __forceinline__ unsigned pp_tsp_sort_n(const double* KM, unsigned ord, int pt) {
+    double key[REM];
 #pragma unroll
-    for (int i = 0; i < PP_TSP_MAX; i++) {
-        key[i] = 0;
-        if (i < rem) key[i] = KM[pt * PP_TSP_MAX + (int)((ord >> (4 * i)) & 0xfu)];
-    }
+    for (int i = 0; i < REM; i++) key[i] = KM[pt * PP_TSP_MAX + (int)((ord >> (4 * i)) & 0xfu)];
     unsigned o = 0;
 #pragma unroll
-    for (int i = 0; i < PP_TSP_MAX; i++) {
-        if (i < rem) {
-            int rank = 0;
+    for (int i = 0; i < REM; i++) {
+        int rank = 0;
 #pragma unroll
-            for (int j = 0; j < PP_TSP_MAX; j++) {
-                if (j != i && j < rem) rank += ((key[j] > key[i]) | ((key[j] == key[i]) & (j < i))) ? 1 : 0;
-            }
-            o |= ((ord >> (4 * i)) & 0xfu) << (4 * rank);
+        for (int j = 0; j < REM; j++) {
+            if (j != i) rank += ((key[j] > key[i]) | ((key[j] == key[i]) & (j < i))) ? 1 : 0;
         }
+        o |= ((ord >> (4 * i)) & 0xfu) << (4 * rank);
     }
     return o;
+}
+// `rem` is wave-uniform: one branch picks the network of exactly that size (rem * (rem - 1) comparisons instead of 56)
+__device__ __forceinline__ unsigned pp_tsp_sort(const double* KM, unsigned ord, int rem, int pt) {
+    switch (rem) {
+        case 2: return pp_tsp_sort_n<2>(KM, ord, pt);
+        case 3: return pp_tsp_sort_n<3>(KM, ord, pt);
+        case 4: return pp_tsp_sort_n<4>(KM, ord, pt);
+        case 5: return pp_tsp_sort_n<5>(KM, ord, pt);
+        case 6: return pp_tsp_sort_n<6>(KM, ord, pt);
+        case 7: return pp_tsp_sort_n<7>(KM, ord, pt);
+        case 8: return pp_tsp_sort_n<8>(KM, ord, pt);
+        default: return ord;         // 0 or 1 left: nothing to order
+    }
 }
 
 // take branch `digit` (ribbon position digit>>1 of `srt`, direction digit&1) from node `a`
@@ -798,8 +813,8 @@ __device__ inline double pp_h_tsp_point(const double* T, const double* KM, int n
         for (int l = 0; l < Ls; l++) {                      // this lane's prefix, level 0 = most significant digit
             const int rem = n - l;
             const unsigned b = (unsigned)(2 * (rem < K ? rem : K));
-            stride /= b;
-            const unsigned dg = rest / stride;
+            stride = pp_udiv_small(stride, b);              // exact: NP is the product of the b's
+            const unsigned dg = pp_udiv_small(rest, stride);
             rest -= dg * stride;
             const unsigned srt = sortK ? pp_tsp_sort(KM, a.ord, rem, a.pt) : a.ord;
             a = pp_tsp_child(T, a, srt, (int)dg, twoW);

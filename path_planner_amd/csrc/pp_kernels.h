@@ -669,12 +669,12 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_H_MIN_WAVES) void pp_k_heuristic(PP
                 const int npts = 2 * nrib + 1;
                 const int ncol = npts - 1;
                 for (int idx = lane; idx < npts * ncol; idx += PP_WAVE) {      // all distances, once
-                    const int pp = idx / ncol, qq = 1 + (idx - pp * ncol);
+                    const int pp = (int)pp_udiv_small((unsigned)idx, (unsigned)ncol), qq = 1 + (idx - pp * ncol);
                     T[pp * (PP_H_PTS - 1) + (qq - 1)] = pp_dist(pts[2 * pp], pts[2 * pp + 1], pts[2 * qq], pts[2 * qq + 1]);
                 }
                 pp_wave_lds_fence();
                 for (int idx = lane; idx < npts * nrib; idx += PP_WAVE) {
-                    const int pp = idx / nrib, ri = idx - pp * nrib;
+                    const int pp = (int)pp_udiv_small((unsigned)idx, (unsigned)nrib), ri = idx - pp * nrib;
                     KM[pp * PP_TSP_MAX + ri] = fmin(pp_h_T(T, pp, 1 + 2 * ri), pp_h_T(T, pp, 2 + 2 * ri));
                 }
                 pp_wave_lds_fence();
