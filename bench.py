@@ -61,7 +61,7 @@ def main():
     ctx.set_grid(w.grid, w.res)
     ctx.set_obstacles(w.obst)
     ctx.set_vertices(w.root(), w.ribbons4)
-    ctx.enable_timing(True)                  # HIP events around each of the two per-edge kernels, on this stream
+    ctx.enable_timing(True)                  # HIP events between the four kernels of a costing launch, on this stream
 
     max_edges = 4 * B
     d_res = torch.zeros(max_edges * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
@@ -82,7 +82,7 @@ def main():
             dist.all_gather_into_tensor(d_gather, d_key2)          # one collective: 16 B per rank over xGMI
             ctx.key_min(world, d_gather.data_ptr(), d_key2.data_ptr())
         if timed:
-            kernel_events.append(ctx.last_timing())     # (sweep ms, heuristic ms) of this step's launch, from HIP events
+            kernel_events.append(ctx.last_timing())     # (solve, pose, cover, heuristic) ms of this step's launch, from HIP events
         return ne
 
     def fence():
@@ -111,19 +111,24 @@ def main():
         total_edges, t = float(edges), elapsed
 
     if rank == 0:
-        kern_ms = float(np.mean([a for a, b in kernel_events]))          # pp_k_cost_edges, the dominant kernel
-        heur_ms = float(np.mean([b for a, b in kernel_events]))          # pp_k_heuristic
+        solve_ms, pose_ms, cover_ms, heur_ms = [float(x) for x in np.mean(np.array(kernel_events), axis=0)]
+        kern_ms = cover_ms                                               # pp_k_cover_sweep, the dominant kernel
+        launch_ms = solve_ms + pose_ms + cover_ms + heur_ms
         res = d_res.cpu().numpy().view(RESULT_DTYPE)[: edges // args.steps]
         n_edges_launch = len(res)
         steps_mean = float((res["info"] >> 16).mean())
         feas_frac = float(((res["flags"] & F_INFEASIBLE) == 0).mean())
         M = 0 if w.obst is None else len(w.obst)
         R = len(w.ribbons4)
-        # algorithmic bytes / flops per edge with the MEASURED mean step count
+        # algorithmic bytes / flops per edge with the MEASURED mean step count.  The per-edge figure is
+        # the whole edge's (descriptor, source vertex, ribbons in and out, record, grid bits); the cover sweep is the
+        # kernel that reads the ribbons and writes the record and the child ribbons.
         bytes_per_edge = 88 + 32 + 32 * R + 56 * M / 4.0 + 150 + steps_mean / 8.0
-        flops_per_edge = 1000 + steps_mean * (70 + 21 * M)               # sweep kernel only; the heuristic kernel is ~4e4 more
+        flops_per_edge = 1000 + steps_mean * (70 + 21 * M)               # pose + cover sweeps; the heuristic kernel is ~4e4 more
         ach_gbs = bytes_per_edge * n_edges_launch / (kern_ms * 1e-3) / 1e9
-        ach_tf = flops_per_edge * n_edges_launch / (kern_ms * 1e-3) / 1e12
+        ach_tf = flops_per_edge * n_edges_launch / ((pose_ms + cover_ms) * 1e-3) / 1e12
+        # what the split into two sweeps costs: the track that goes through HBM between them
+        track_bytes_per_edge = 16.0 * steps_mean + 12.0 * (steps_mean / 64.0) + 384 + 16
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")   # written from a separate rocprofv3 --pmc pass
         if os.path.exists(tp):
@@ -149,13 +154,16 @@ def main():
                        "dynamic_obstacles": M, "ribbons": R, "heuristic": "TspPointRobotNoSplitKRibbons K=2",
                        "edges_per_iter_per_gpu": n_edges_launch, "sharding": "sample batch split by rank, 1 all-gather/iter"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "pp_k_cost_edges", "kernel_ms": kern_ms, "heuristic_kernel_ms": heur_ms,
-                         "algorithmic_bytes_per_edge": bytes_per_edge,
-                         "note": "this sweep is fp64-VALU bound, not HBM bound (SURVEY 8d): see valu_fp64"},
+                         "traffic": traffic, "kernel": "pp_k_cover_sweep", "kernel_ms": kern_ms,
+                         "kernels_ms": {"pp_k_solve_edges": solve_ms, "pp_k_pose_sweep": pose_ms, "pp_k_cover_sweep": cover_ms,
+                                        "pp_k_heuristic": heur_ms},
+                         "algorithmic_bytes_per_edge": bytes_per_edge, "track_bytes_per_edge": track_bytes_per_edge,
+                         "pose_sweep_track_write_GBps": 16.0 * steps_mean * n_edges_launch / (pose_ms * 1e-3) / 1e9,
+                         "note": "all four kernels are fp64-VALU bound, not HBM bound (SURVEY 8d): see valu_fp64"},
             "valu_fp64": {"achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TFLOPS,
                           "algorithmic_flops_per_edge": flops_per_edge},
             "workload_stats": {"mean_sweep_steps_per_edge": steps_mean, "feasible_fraction": feas_frac,
-                               "kernel_edges_per_s": n_edges_launch / ((kern_ms + heur_ms) * 1e-3),
+                               "kernel_edges_per_s": n_edges_launch / (launch_ms * 1e-3),
                                "best_f": float(np.array([key[0]], dtype=np.uint64).view(np.float64)[0]), "best_edge": int(key[1])},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -159,11 +159,12 @@ const char* ppgpu_last_error(void);
 /* Launch on a caller-owned hipStream_t (NULL = the handle's own stream). */
 int ppgpu_set_stream(ppgpu_ctx* ctx, void* hip_stream);
 int ppgpu_synchronize(ppgpu_ctx* ctx);
-/* Measurement aid: with timing on, every costing launch records HIP events on the handle's stream around its two
- * kernels; ppgpu_last_timing waits for the last launch and returns their durations in milliseconds
- * (sweep = pp_k_cost_edges, heuristic = pp_k_heuristic). */
+/* Measurement aid: with timing on, every costing launch records HIP events on the handle's stream between its four
+ * kernels (curve solve, pose sweep, cover sweep, heuristic); ppgpu_last_timing waits for the last launch and returns their
+ * durations in milliseconds.  For a launch that ran as several workspace slices the first three are the last slice's.
+ * The events cost a few microseconds per launch: leave timing off in production. */
 int ppgpu_enable_timing(ppgpu_ctx* ctx, int32_t on);
-int ppgpu_last_timing(ppgpu_ctx* ctx, double* ms_sweep, double* ms_heuristic);
+int ppgpu_last_timing(ppgpu_ctx* ctx, double* ms_solve, double* ms_pose, double* ms_cover, double* ms_heuristic);
 
 /* ---------------------------------------------------------------- world state */
 

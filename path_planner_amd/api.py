@@ -31,7 +31,7 @@ def _load():
         "ppgpu_set_stream": (C.c_int, [vp, vp]),
         "ppgpu_synchronize": (C.c_int, [vp]),
         "ppgpu_enable_timing": (C.c_int, [vp, i32]),
-        "ppgpu_last_timing": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(dbl)]),
+        "ppgpu_last_timing": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]),
         "ppgpu_set_config": (C.c_int, [vp, C.POINTER(PpgpuConfig)]),
         "ppgpu_set_grid": (C.c_int, [vp, vp, i32, i32, dbl]),
         "ppgpu_set_obstacles": (C.c_int, [vp, i32, i32, vp]),
@@ -105,9 +105,10 @@ class Context:
         self._ck(LIB.ppgpu_enable_timing(self._h, 1 if on else 0), "ppgpu_enable_timing")
 
     def last_timing(self):
-        a, b = C.c_double(), C.c_double()
-        self._ck(LIB.ppgpu_last_timing(self._h, C.byref(a), C.byref(b)), "ppgpu_last_timing")
-        return a.value, b.value
+        """(solve, pose sweep, cover sweep, heuristic) kernel durations in ms of the last costing launch."""
+        t = [C.c_double() for _ in range(4)]
+        self._ck(LIB.ppgpu_last_timing(self._h, *[C.byref(x) for x in t]), "ppgpu_last_timing")
+        return tuple(x.value for x in t)
 
     def synchronize(self):
         self._ck(LIB.ppgpu_synchronize(self._h), "ppgpu_synchronize")

@@ -306,7 +306,9 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
         const int nvalid = __popcll(__ballot(valid));
         const int nlim = fb < nvalid ? fb : nvalid;
 
+#ifndef PP_ABL_NO_TRACK_STORE
         track[k] = make_double2(x, y);                                // k < ngp: ngp is ng rounded up to whole chunks
+#endif
         int chunkHits = 0;
         if (__ballot(hits != 0) != 0ull) {
             // per-step counts are only ever read for a chunk whose sum is not zero

@@ -96,7 +96,7 @@ struct ppgpu_ctx {
     DevBuf<PPTrackSummary> track_summary;
     // optional per-kernel timing of costing launches (ppgpu_enable_timing)
     bool timing = false;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
     int max_vertex_ribbons = 0;
     DevBuf<int> tmp_idx;
@@ -147,7 +147,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     c->setup.release(); c->track_pose.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
     c->track_summary.release();
-    for (int i = 0; i < 3; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 5; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PPGPU_OK;
@@ -163,21 +163,20 @@ int ppgpu_enable_timing(ppgpu_ctx* c, int32_t on) {
     if (!c) return fail(PPGPU_EINVAL, "null context");
     HIP_TRY(hipSetDevice(c->device));
     if (on && !c->ev[0])
-        for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+        for (int i = 0; i < 5; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
     c->timing = on != 0;
     c->ev_valid = false;
     return PPGPU_OK;
 }
 
-int ppgpu_last_timing(ppgpu_ctx* c, double* ms_sweep, double* ms_heuristic) {
-    if (!c || !ms_sweep || !ms_heuristic) return fail(PPGPU_EINVAL, "null argument");
+int ppgpu_last_timing(ppgpu_ctx* c, double* ms_solve, double* ms_pose, double* ms_cover, double* ms_heuristic) {
+    if (!c || !ms_solve || !ms_pose || !ms_cover || !ms_heuristic) return fail(PPGPU_EINVAL, "null argument");
     if (!c->timing || !c->ev_valid) return fail(PPGPU_ESTATE, "no timed costing launch (ppgpu_enable_timing, then cost edges)");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipEventSynchronize(c->ev[2]));
-    float a = 0, b = 0;
-    HIP_TRY(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
-    *ms_sweep = a; *ms_heuristic = b;
+    HIP_TRY(hipEventSynchronize(c->ev[4]));
+    float t[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&t[i], c->ev[i], c->ev[i + 1]));
+    *ms_solve = t[0]; *ms_pose = t[1]; *ms_cover = t[2]; *ms_heuristic = t[3];
     return PPGPU_OK;
 }
 
@@ -573,19 +572,21 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     }
     p.setup = c->setup.p; p.track_pose = c->track_pose.p; p.track_hits = c->track_hits.p; p.track_eq = c->track_eq.p;
     p.track_chunk_hits = c->track_chunk_hits.p; p.track_summary = c->track_summary.p;
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     for (long long e0 = 0; e0 < total; e0 += slice) {
         p.e_base = e0; p.ws_base = 0; p.n_edges = (total - e0 < slice) ? (total - e0) : slice;
         const unsigned blocks = (unsigned)((p.n_edges + PP_WPB - 1) / PP_WPB);
+        if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(pp_k_solve_edges, dim3((unsigned)((p.n_edges + 255) / 256)), dim3(256), 0, c->stream, p);
+        if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         hipLaunchKernelGGL(pp_k_pose_sweep, dim3(blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+        if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
         hipLaunchKernelGGL(pp_k_cover_sweep, dim3(blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+        if (c->timing) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     }
     p.e_base = 0;
     p.n_edges = total;
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     hipLaunchKernelGGL(pp_k_heuristic, dim3((unsigned)((total + PP_WPB - 1) / PP_WPB)), dim3(PP_WPB * 64), 0, c->stream, p);
-    if (c->timing) { HIP_TRY(hipEventRecord(c->ev[2], c->stream)); c->ev_valid = true; }
+    if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], c->stream)); c->ev_valid = true; }
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;
 }

@@ -25,6 +25,7 @@ VARIANTS = {
     "pose6": ["-DPP_POSE_MIN_WAVES=6"],
     "pose7": ["-DPP_POSE_MIN_WAVES=7"],
     "pose8": ["-DPP_POSE_MIN_WAVES=8"],
+    "no_track_store": ["-DPP_ABL_NO_TRACK_STORE"],
     "wpb1": ["-DPP_WPB=1"],
     "wpb2": ["-DPP_WPB=2"],
     "wpb8": ["-DPP_WPB=8"],
