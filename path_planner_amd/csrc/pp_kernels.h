@@ -402,7 +402,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
             // Edge.cpp:159: cover only when coverage is allowed on this edge or the heading did not change since the last step
             const unsigned long long coverMask = cov ? ~0ull : pp_const_u64(teq + (base >> 6))[0];
             const int climit = (limit - base) < PP_WAVE ? (limit - base) : PP_WAVE;
-            bool runFailed = false;
+            bool runFailed = false, quietFailed = false;
             while (true) {
                 const int j = nextEvent - base;
                 if (j >= climit) break;
@@ -430,6 +430,18 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                         continue;
                     }
                 }
+#ifndef PP_NO_QUIET_RUN
+                else if (adv == -2 && D == 0 && nrib > 0 && j + 1 < climit && !quietFailed) {
+                    // inside a corridor, nothing changed: the following steps are very likely the same kind of event
+                    const int L = pp_quiet_run(rib, nrib, w, q.x, q.y, (lane < climit) & (t < endTime), coverMask, j + 1);
+                    quietFailed = (L == 0);
+                    if (L > 0) {
+                        lastEv = base + j + L;
+                        nextEvent = base + j + L + 1;
+                        continue;
+                    }
+                }
+#endif
 #endif
                 if (nrib == 0) {                                      // :162-170
                     if (cct == -1) cct = tj;

@@ -12,7 +12,7 @@ OUT = os.path.join(ROOT, "gpurun_out", "abl")
 VARIANTS = {
     "full": [],
     "norun": ["-DPP_NO_CORRIDOR_RUN"],
-    "quiet": ["-DPP_QUIET_RUN"],
+    "noquiet": ["-DPP_NO_QUIET_RUN"],
     "h3": ["-DPP_H_MIN_WAVES=3"],
     "h4": ["-DPP_H_MIN_WAVES=4"],
     "h5": ["-DPP_H_MIN_WAVES=5"],

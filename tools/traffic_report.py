@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the two PMC passes of tools/traffic.sh.  Per kernel and per launch: FETCH_SIZE and
+WRITE_SIZE (rocprofv3 reports KiB-scaled units of 1 KB = 1024 B per the counter definitions; TCC_EA request counts x 64 B),
+with the gfx950 correction of MI355X_MICROARCH.md "HBM": FETCH_SIZE counts 128-B read requests as 64 B, so reads are
+doubled.  `hbm_bytes_per_launch` is the dominant kernel's (pp_k_cover_sweep) corrected read + write bytes."""
+import collections, csv, glob, json, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = {"unit": "bytes per kernel launch", "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE x1; counter unit 1 KB = 1024 B", "kernels": {}}
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(os.path.join(ROOT, "gpurun_out", f"traffic_{counter}", "*", "*counter_collection.csv"))[0]
+    tot, calls = collections.Counter(), collections.Counter()
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"].split("(")[0]
+        tot[k] += float(r["Counter_Value"])
+        key = (k, r.get("Dispatch_Id"))
+        if key not in seen:
+            seen.add(key); calls[k] += 1
+    for k in tot:
+        if not k.startswith("pp_k_"):
+            continue
+        d = out["kernels"].setdefault(k, {})
+        scale = 2.0 if counter == "FETCH_SIZE" else 1.0
+        d[counter.lower() + "_bytes"] = tot[k] / calls[k] * 1024.0 * scale
+        d["launches_measured"] = calls[k]
+dom = out["kernels"].get("pp_k_cover_sweep", {})
+out["dominant_kernel"] = "pp_k_cover_sweep"
+out["hbm_bytes_per_launch"] = dom.get("fetch_size_bytes", 0.0) + dom.get("write_size_bytes", 0.0)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "traffic.json"), "w"), indent=1)
+for k, d in sorted(out["kernels"].items()):
+    print(f"{k:28s} read {d.get('fetch_size_bytes', 0) / 1e6:10.1f} MB   write {d.get('write_size_bytes', 0) / 1e6:10.1f} MB   per launch")
