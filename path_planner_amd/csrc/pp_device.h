@@ -73,6 +73,13 @@ __device__ __forceinline__ double pp_heading_from_yaw(double yaw) {
     return h;
 }
 
+// State::headingTo / setHeadingTowards (ppc State.cpp:51-57,64-67)
+__device__ __forceinline__ double pp_heading_to(double x, double y, double x1, double y1) {
+    double h = PP_PI_2 - atan2(y1 - y, x1 - x);
+    if (h < 0) h += PP_TWO_PI;
+    return h;
+}
+
 // ----------------------------------------------------------------------------- sine / cosine
 // sin and cos of the same angle for the bounded arguments of this kernel (|x| of a few pi): the classic
 // reduce-by-pi/2-then-two-polynomials scheme (Cody & Waite reduction carried to ~118 bits in two steps, then the
@@ -772,11 +779,13 @@ __device__ __forceinline__ unsigned pp_tsp_sort(const double* KM, unsigned ord, 
 }
 
 // take branch `digit` (ribbon position digit>>1 of `srt`, direction digit&1) from node `a`
-__device__ __forceinline__ PPTspNode pp_tsp_child(const double* T, const PPTspNode& a, unsigned srt, int digit, double twoW) {
+// LEN == nullptr: T holds point-to-point distances and a ribbon's length is T[start][end]; otherwise T holds the Dubins
+// distances between oriented endpoints (RibbonManager::dubinsDistance) and LEN[i] = Ribbon::length() of ribbon i.
+__device__ __forceinline__ PPTspNode pp_tsp_child(const double* T, const double* LEN, const PPTspNode& a, unsigned srt, int digit, double twoW) {
     const int c = digit >> 1, dir = digit & 1;
     const int rid = (int)((srt >> (4 * c)) & 0xfu);
     const int ps = 1 + 2 * rid, pe = 2 + 2 * rid;
-    const double len = pp_h_T(T, ps, pe);                               // Ribbon::length()
+    const double len = LEN ? LEN[rid] : pp_h_T(T, ps, pe);              // Ribbon::length()
     const double dd = pp_h_T(T, a.pt, dir == 0 ? ps : pe);              // distance(point, r.start()) / (point, r.end())
     PPTspNode b;
     b.sf = fmax(a.sf + len - twoW + dd, 0);
@@ -786,7 +795,7 @@ __device__ __forceinline__ PPTspNode pp_tsp_child(const double* T, const PPTspNo
     return b;
 }
 
-__device__ inline double pp_h_tsp_point(const double* T, const double* KM, int n, double w, int K, bool sortK) {
+__device__ inline double pp_h_tsp_point(const double* T, const double* KM, int n, double w, int K, bool sortK, const double* LEN = nullptr) {
     if (n == 0) return 0;
     if (K <= 0) return PP_DBL_MAX;   // the reference's loop body never runs and it returns DBL_MAX
     const int lane = pp_lane();
@@ -817,7 +826,7 @@ __device__ inline double pp_h_tsp_point(const double* T, const double* KM, int n
             const unsigned dg = pp_udiv_small(rest, stride);
             rest -= dg * stride;
             const unsigned srt = sortK ? pp_tsp_sort(KM, a.ord, rem, a.pt) : a.ord;
-            a = pp_tsp_child(T, a, srt, (int)dg, twoW);
+            a = pp_tsp_child(T, LEN, a, srt, (int)dg, twoW);
         }
         double v = PP_DBL_MAX;
         if (nsuf == 0) {
@@ -827,7 +836,7 @@ __device__ inline double pp_h_tsp_point(const double* T, const double* KM, int n
             const int bA = 2 * (remA < K ? remA : K);
             const unsigned srtA = sortK ? pp_tsp_sort(KM, a.ord, remA, a.pt) : a.ord;
             for (int uA = 0; uA < bA; uA++) {
-                const PPTspNode bnode = pp_tsp_child(T, a, srtA, uA, twoW);
+                const PPTspNode bnode = pp_tsp_child(T, LEN, a, srtA, uA, twoW);
                 if (nsuf == 1) {
                     v = fmin(v, bnode.sf);
                 } else {
@@ -835,7 +844,7 @@ __device__ inline double pp_h_tsp_point(const double* T, const double* KM, int n
                     const int bB = 2 * (remB < K ? remB : K);
                     const unsigned srtB = sortK ? pp_tsp_sort(KM, bnode.ord, remB, bnode.pt) : bnode.ord;
                     for (int uB = 0; uB < bB; uB++) {
-                        const PPTspNode leaf = pp_tsp_child(T, bnode, srtB, uB, twoW);
+                        const PPTspNode leaf = pp_tsp_child(T, LEN, bnode, srtB, uB, twoW);
                         v = fmin(v, leaf.sf);
                     }
                 }

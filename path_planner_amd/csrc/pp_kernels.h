@@ -9,6 +9,7 @@ struct PPParams {
     double max_speed, slow_speed, rho, rho_cov, horizon, tmin, inc_d, sst, ribw, cpf, tpf;
     double inv_inc_d;                    // 1 / inc_d (host division): first guess of a quotient that is then verified
     int heuristic, tsp_k;
+    double h_rho;                        // RibbonManager::m_TurningRadius of the Dubins-TSP heuristics
     // world
     PPGrid grid;
     const PPObst* obst; int n_obst;
@@ -638,14 +639,14 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep(PP
 #ifndef PP_H_MIN_WAVES
 #define PP_H_MIN_WAVES 1
 #endif
-__global__ __launch_bounds__(PP_WPB * 64, PP_H_MIN_WAVES) void pp_k_heuristic(PPParams p) {
-    __shared__ double lds_all[PP_WPB][PP_H_LDS];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+// DUBINS = the two Dubins-TSP heuristics (RibbonManager.cpp:97-140): the same enumeration over a table of Dubins
+// distances between oriented ribbon endpoints.  A separate instantiation so that the six-word solve does not set the
+// register budget of the common kernel.
+template <bool DUBINS>
+__device__ __forceinline__ void pp_heuristic_edge(const PPParams& p, const long long e, double* lds_wave) {
     const int lane = pp_lane();
-    const long long e = (long long)blockIdx.x * PP_WPB + wave;
-    if (e >= p.n_edges) return;
-    double* pts = lds_all[wave];                 // x,y of the query point, then start/end of every child ribbon
-    double* T = lds_all[wave] + PP_WAVE * 2;     // distance table of the TSP heuristics (<= 8 ribbons)
+    double* pts = lds_wave;                      // x,y of the query point, then start/end of every child ribbon
+    double* T = lds_wave + PP_WAVE * 2;          // distance table of the TSP heuristics (<= 8 ribbons)
     double* KM = T + PP_H_PTS * (PP_H_PTS - 1);  // KM[p][i] = distance from point p to the nearer endpoint of ribbon i
     ppgpu_edge_result* rec = p.out + e;
     unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)rec->flags);
@@ -677,11 +678,11 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_H_MIN_WAVES) void pp_k_heuristic(PP
                 pts[2 * (2 + 2 * lane)] = c[2]; pts[2 * (2 + 2 * lane) + 1] = c[3];
             }
             pp_wave_lds_fence();
+            const int npts = 2 * nrib + 1;
+            const int ncol = npts - 1;
             if (!tsp) {
                 hdist = pp_h_max_distance(pts, nrib, p.ribw);
-            } else {
-                const int npts = 2 * nrib + 1;
-                const int ncol = npts - 1;
+            } else if (!DUBINS) {
                 for (int idx = lane; idx < npts * ncol; idx += PP_WAVE) {      // all distances, once
                     const int pp = (int)pp_udiv_small((unsigned)idx, (unsigned)ncol), qq = 1 + (idx - pp * ncol);
                     T[pp * (PP_H_PTS - 1) + (qq - 1)] = pp_dist(pts[2 * pp], pts[2 * pp + 1], pts[2 * qq], pts[2 * qq + 1]);
@@ -693,13 +694,49 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_H_MIN_WAVES) void pp_k_heuristic(PP
                 }
                 pp_wave_lds_fence();
                 if (p.heuristic == PPGPU_H_TSP_POINT_ALL) hdist = pp_h_tsp_point(T, KM, nrib, p.ribw, PP_TSP_MAX, false);
-                else if (p.heuristic == PPGPU_H_TSP_POINT_K) hdist = pp_h_tsp_point(T, KM, nrib, p.ribw, p.tsp_k, true);
-                else flags |= PPGPU_F_DUBINS_ERR;   // Dubins-TSP heuristics are rejected by ppgpu_set_config
+                else hdist = pp_h_tsp_point(T, KM, nrib, p.ribw, p.tsp_k, true);
+            } else {
+                // Oriented endpoints (Ribbon::startAsState / endAsState, Ribbon.cpp:60-70: at one end, heading towards the
+                // other); the query pose passes the child's HEADING where the callee says yaw (Vertex.cpp:51) — kept.
+                double* YAW = KM;                        // yaw of point q (q >= 1), then the ribbon lengths
+                double* LEN = KM + PP_H_PTS;
+                if (lane < nrib) {
+                    const double sx = pts[2 * (1 + 2 * lane)], sy = pts[2 * (1 + 2 * lane) + 1];
+                    const double ex = pts[2 * (2 + 2 * lane)], ey = pts[2 * (2 + 2 * lane) + 1];
+                    YAW[1 + 2 * lane] = pp_yaw(pp_heading_to(sx, sy, ex, ey));
+                    YAW[2 + 2 * lane] = pp_yaw(pp_heading_to(ex, ey, sx, sy));
+                    LEN[lane] = sqrt(pp_sq_len(sx, sy, ex, ey));                       // Ribbon::length()
+                }
+                if (lane == 0) YAW[0] = rec->end_heading;
+                pp_wave_lds_fence();
+                for (int idx = lane; idx < npts * ncol; idx += PP_WAVE) {      // RibbonManager::dubinsDistance for every ordered pair
+                    const int pp = (int)pp_udiv_small((unsigned)idx, (unsigned)ncol), qq = 1 + (idx - pp * ncol);
+                    PPDubins d;
+                    pp_dubins_shortest(pts[2 * pp], pts[2 * pp + 1], YAW[pp], pts[2 * qq], pts[2 * qq + 1], YAW[qq], p.h_rho, d);
+                    T[pp * (PP_H_PTS - 1) + (qq - 1)] = pp_dubins_length(d, p.h_rho);
+                }
+                pp_wave_lds_fence();
+                // K variant: its comparator compares r1 with r1 (:121-122), so the sort changes nothing, and its counter is
+                // never incremented (:128), so every ribbon is branched: the All enumeration, unless K <= 0 (nothing runs)
+                const int K = (p.heuristic == PPGPU_H_TSP_DUBINS_K && p.tsp_k <= 0) ? 0 : PP_TSP_MAX;
+                hdist = pp_h_tsp_point(T, KM, nrib, p.ribw, K, false, LEN);
             }
         }
     }
     const double h = hdist / p.max_speed * p.tpf;
     if (lane == 0) { rec->h = h; rec->f = g + h; rec->flags = flags; }
+}
+__global__ __launch_bounds__(PP_WPB * 64, PP_H_MIN_WAVES) void pp_k_heuristic(PPParams p) {
+    __shared__ double lds_all[PP_WPB][PP_H_LDS];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long e = (long long)blockIdx.x * PP_WPB + wave;
+    if (e < p.n_edges) pp_heuristic_edge<false>(p, e, lds_all[wave]);
+}
+__global__ __launch_bounds__(PP_WPB * 64) void pp_k_heuristic_dubins(PPParams p) {
+    __shared__ double lds_all[PP_WPB][PP_H_LDS];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long e = (long long)blockIdx.x * PP_WPB + wave;
+    if (e < p.n_edges) pp_heuristic_edge<true>(p, e, lds_all[wave]);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -193,8 +193,9 @@ int ppgpu_set_config(ppgpu_ctx* c, const ppgpu_config* cfg) {
         return fail(PPGPU_EINVAL, "config: speeds, radii, increment and horizon must be positive");
     if (cfg->heuristic < PPGPU_H_MAX_DISTANCE || cfg->heuristic > PPGPU_H_TSP_DUBINS_K)
         return fail(PPGPU_EINVAL, "config: unknown heuristic");
-    if (cfg->heuristic == PPGPU_H_TSP_DUBINS_ALL || cfg->heuristic == PPGPU_H_TSP_DUBINS_K)
-        return fail(PPGPU_EINVAL, "config: the Dubins-TSP heuristics are not implemented on the device path yet");
+    if ((cfg->heuristic == PPGPU_H_TSP_DUBINS_ALL || cfg->heuristic == PPGPU_H_TSP_DUBINS_K) && !(cfg->heuristic_turning_radius > 0))
+        return fail(PPGPU_EINVAL, "config: the Dubins-TSP heuristics need heuristic_turning_radius > 0 "
+                                  "(RibbonManager throws \"Cannot compute ribbon dubins distance with unset turning radius\")");
     double steps = cfg->time_horizon / (cfg->collision_checking_increment / cfg->max_speed);
     if (!(steps < 60000.0)) return fail(PPGPU_ECAPACITY, "config: more than 60000 collision-check steps per edge");
     c->cfg = *cfg;
@@ -484,7 +485,7 @@ static void fill_params(ppgpu_ctx* c, PPParams& p) {
     p.sst = g.start_state_time; p.ribw = g.ribbon_width;
     p.inv_inc_d = 1.0 / p.inc_d;
     p.cpf = g.collision_penalty_factor; p.tpf = g.time_penalty_factor;
-    p.heuristic = g.heuristic; p.tsp_k = g.tsp_k;
+    p.heuristic = g.heuristic; p.tsp_k = g.tsp_k; p.h_rho = g.heuristic_turning_radius;
     p.grid = PPGrid{c->grid.p, c->rows, c->cols, c->wpr, c->res, c->res > 0 ? 1.0 / c->res : 0.0};
     p.obst = c->obst.p; p.n_obst = c->n_obst;
     p.verts = c->verts.p; p.ribbons = c->ribbons.p; p.tgrid = c->tgrid.p; p.ng = c->ng; p.nverts = c->nverts;
@@ -585,7 +586,10 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     }
     p.e_base = 0;
     p.n_edges = total;
-    hipLaunchKernelGGL(pp_k_heuristic, dim3((unsigned)((total + PP_WPB - 1) / PP_WPB)), dim3(PP_WPB * 64), 0, c->stream, p);
+    if (p.heuristic == PPGPU_H_TSP_DUBINS_ALL || p.heuristic == PPGPU_H_TSP_DUBINS_K)
+        hipLaunchKernelGGL(pp_k_heuristic_dubins, dim3((unsigned)((total + PP_WPB - 1) / PP_WPB)), dim3(PP_WPB * 64), 0, c->stream, p);
+    else
+        hipLaunchKernelGGL(pp_k_heuristic, dim3((unsigned)((total + PP_WPB - 1) / PP_WPB)), dim3(PP_WPB * 64), 0, c->stream, p);
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], c->stream)); c->ev_valid = true; }
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;

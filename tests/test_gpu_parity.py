@@ -165,13 +165,13 @@ def test_dubins_lengths_and_nearest_selection(torch_cuda):
 
 
 @pytest.mark.parametrize("case", ["done_at_start", "colocated", "no_grid_no_obst", "many_ribbons_maxdist", "tsp_all_four",
-                                  "equal_speeds", "short_horizon", "wide_ribbons"])
+                                  "equal_speeds", "short_horizon", "wide_ribbons", "tsp_dubins_all", "tsp_dubins_k", "tsp_dubins_k0"])
 def test_edge_cases_match_oracle(torch_cuda, case):
     """Empty ribbon set, co-located target (the reference throws), base Map and base obstacle manager,
     long ribbon lists, the other heuristics, degenerate configuration values."""
     from path_planner_amd import api, workloads
     from path_planner_amd.types import (RESULT_DTYPE, F_THROWS, F_INFEASIBLE, H_MAX_DISTANCE, H_TSP_POINT_ALL, H_TSP_POINT_K,
-                                        edge_pack, make_config)
+                                        H_TSP_DUBINS_ALL, H_TSP_DUBINS_K, edge_pack, make_config)
     from path_planner_amd.workloads import root_vertex
     from parity import compare_results
     import oracle as orc
@@ -192,6 +192,15 @@ def test_edge_cases_match_oracle(torch_cuda, case):
     elif case == "tsp_all_four":
         kw["heuristic"] = H_TSP_POINT_ALL
         rib = [[60, 86 + 6 * i, 100 - 3 * i, 86 + 6 * i] for i in range(6)]
+    elif case == "tsp_dubins_all":
+        # RibbonManager.cpp:97-114: legs are Dubins lengths between oriented endpoints at RibbonManager::m_TurningRadius
+        kw.update(heuristic=H_TSP_DUBINS_ALL, heuristic_turning_radius=8.0)
+    elif case == "tsp_dubins_k":
+        # :116-140: the comparator compares r1 with r1 and the counter never advances => same value as the All variant
+        kw.update(heuristic=H_TSP_DUBINS_K, tsp_k=2, heuristic_turning_radius=5.0)
+        rib = [[60, 86 + 7 * i, 100 - 4 * i, 88 + 6 * i] for i in range(4)]
+    elif case == "tsp_dubins_k0":
+        kw.update(heuristic=H_TSP_DUBINS_K, tsp_k=0, heuristic_turning_radius=8.0)     # loop body never runs: DBL_MAX
     elif case == "equal_speeds":
         kw.update(slow_speed=-1.0, coverage_turning_radius=8.0)
     elif case == "short_horizon":
