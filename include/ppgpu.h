@@ -60,7 +60,8 @@ enum {
  * (path_planner/src/planner/PlannerConfig.h:98-104). */
 enum {
     PPGPU_OBST_NONE = 0,    /* base class: collisionExists == 0 (DynamicObstaclesManager.h:23) */
-    PPGPU_OBST_BINARY = 1   /* BinaryDynamicObstaclesManager.cpp:4-22                           */
+    PPGPU_OBST_BINARY = 1,  /* BinaryDynamicObstaclesManager.cpp:4-22                           */
+    PPGPU_OBST_GAUSSIAN = 2 /* GaussianDynamicObstaclesManager.cpp:3-13 (sum of bivariate normal pdfs, floor 1e-5) */
 };
 
 /* The scalars of PlannerConfig (PlannerConfig.h:179-207) plus the process-global
@@ -182,6 +183,15 @@ int ppgpu_set_grid(ppgpu_ctx* ctx, const uint8_t* h_cells, int32_t rows, int32_t
  * {x, y, heading, speed, time, width, length} exactly as passed to update()
  * (BinaryDynamicObstaclesManager.cpp:24-35, constructor .h:17-19). */
 int ppgpu_set_obstacles(ppgpu_ctx* ctx, int32_t model, int32_t n, const double* h_obstacles7);
+
+/* GaussianDynamicObstaclesManager contents (GaussianDynamicObstaclesManager.h:19-49, .cpp:16-47): n rows of
+ * {x, y, heading, speed, time} as passed to update(mmsi, x, y, heading, speed, time), followed — when
+ * covariance_given != 0 — by the row-major 2x2 covariance {c00, c01, c10, c11} of the second update() overload
+ * (rows of 9 doubles); otherwise rows of 5 doubles and the reference's default covariance [[30,10],[10,30]].
+ * collisionExists then is the sum of the obstacles' pdfs at the pose, 0 when below 1e-5, and the edge's collision
+ * penalty the sum over steps of that value times collision_penalty_factor (Edge.cpp:150-151).
+ * Obstacles whose pdf is below 1e-13 over a whole 64-step chunk are skipped (relative effect < 1e-7). */
+int ppgpu_set_gaussian_obstacles(ppgpu_ctx* ctx, int32_t n, const double* h_obstacles, int32_t covariance_given);
 
 /* The open-vertex array: n vertices and the pool of their ribbons
  * (4 doubles each: startX, startY, endX, endY; Ribbon.h:126).  Also rebuilds the

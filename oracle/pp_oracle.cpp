@@ -664,8 +664,34 @@ bool GridMap::loadText(const std::string& text) {  // GridWorldMap.cpp:10-82
 void Obstacles::update(double x, double y, double heading, double speed, double time, double width, double length) {
     list.push_back(BinaryObstacle{x, y, M_PI_2 - heading, speed, time, width, length});  // .h:17-19
 }
+void Obstacles::updateGaussian(double x, double y, double heading, double speed, double time, const double* cov4) {
+    GaussianObstacle o{x, y, M_PI_2 - heading, speed, time, {{30, 10}, {10, 30}}};  // GaussianDynamicObstaclesManager.h:23-26
+    if (cov4) { o.cov[0][0] = cov4[0]; o.cov[0][1] = cov4[1]; o.cov[1][0] = cov4[2]; o.cov[1][1] = cov4[3]; }  // :28-29
+    gauss.push_back(o);
+}
 double Obstacles::collisionExists(double x, double y, double time, bool strict) const {  // .cpp:4-22
     if (model == 0) return 0;  // DynamicObstaclesManager.h:23
+    if (model == 2) {          // GaussianDynamicObstaclesManager.cpp:3-13
+        double sum = 0;
+        for (GaussianObstacle o : gauss) {
+            double dt = time - o.Time;  // Obstacle::project, .h:31-36
+            double dx = o.Speed * dt * std::cos(o.Yaw);
+            double dy = o.Speed * dt * std::sin(o.Yaw);
+            o.X += dx; o.Y += dy;
+            // Obstacle::pdf, .h:38-43
+            double twoPi = 2 * M_PI;
+            double det = o.cov[0][0] * o.cov[1][1] - o.cov[1][0] * o.cov[0][1];   // Eigen 2x2 determinant
+            double invdet = 1.0 / det;                                            // Eigen compute_inverse, size 2
+            double i00 = o.cov[1][1] * invdet, i10 = -o.cov[1][0] * invdet, i01 = -o.cov[0][1] * invdet, i11 = o.cov[0][0] * invdet;
+            double vx = x - o.X, vy = y - o.Y;
+            double r0 = vx * i00 + vy * i10, r1 = vx * i01 + vy * i11;            // (x - mean)^T * inverse
+            double quadform = r0 * vx + r1 * vy;                                  // ... * (x - mean)
+            double norm = 1.0 / twoPi / std::sqrt(det);
+            sum += norm * std::exp(-0.5 * quadform);
+        }
+        if (sum < 1e-5) return 0;  // "questionable", .cpp:11
+        return sum;
+    }
     double sum = 0;
     for (BinaryObstacle o : list) {
         if (strict) {

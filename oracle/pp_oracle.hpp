@@ -130,11 +130,17 @@ struct GridMap {
 };
 
 struct BinaryObstacle { double X, Y, Yaw, Speed, Time, Width, Length; };  // BinaryDynamicObstaclesManager.h:15-16
+// GaussianDynamicObstaclesManager::Obstacle (GaussianDynamicObstaclesManager.h:19-49).  The reference uses Eigen (absent here):
+// the 2x2 inverse / determinant / quadratic form are written out in Eigen's fixed-size evaluation order.  PARITY
+// UNPINNED for this model: the reference's only test of it prints values without asserting (test_planner.cpp:230-238).
+struct GaussianObstacle { double X, Y, Yaw, Speed, Time; double cov[2][2]; };
 struct Obstacles {
-    int model = 0;   // 0 = base DynamicObstaclesManager (returns 0), 1 = binary
+    int model = 0;   // 0 = base DynamicObstaclesManager (returns 0), 1 = binary, 2 = Gaussian
     std::vector<BinaryObstacle> list;
+    std::vector<GaussianObstacle> gauss;
     void update(double x, double y, double heading, double speed, double time, double width, double length); // .h:17-19
-    double collisionExists(double x, double y, double time, bool strict) const; // BinaryDynamicObstaclesManager.cpp:4-22
+    void updateGaussian(double x, double y, double heading, double speed, double time, const double* cov4);  // Gaussian .cpp:16-26,37-47
+    double collisionExists(double x, double y, double time, bool strict) const; // Binary .cpp:4-22 / Gaussian .cpp:3-13
 };
 
 // ---------------------------------------------------------------- Config

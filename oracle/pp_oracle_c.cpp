@@ -254,6 +254,18 @@ void ppo_world_set_obstacles(void* w, int model, int n, const double* o7) {
     W->obstacles.list.clear();
     for (int i = 0; i < n; i++) W->obstacles.update(o7[7 * i], o7[7 * i + 1], o7[7 * i + 2], o7[7 * i + 3], o7[7 * i + 4], o7[7 * i + 5], o7[7 * i + 6]);
 }
+// Gaussian model: rows {X, Y, heading, Speed, Time, c00, c01, c10, c11}; cov_given = 0 uses the default covariance and rows of 5
+void ppo_world_set_gaussian_obstacles(void* w, int n, const double* o, int cov_given) {
+    World* W = (World*)w;
+    W->obstacles.model = 2;
+    W->obstacles.list.clear();
+    W->obstacles.gauss.clear();
+    const int stride = cov_given ? 9 : 5;
+    for (int i = 0; i < n; i++) {
+        const double* r = o + (size_t)stride * i;
+        W->obstacles.updateGaussian(r[0], r[1], r[2], r[3], r[4], cov_given ? r + 5 : nullptr);
+    }
+}
 double ppo_world_collision_exists(void* w, double x, double y, double t, int strict) {
     return ((World*)w)->obstacles.collisionExists(x, y, t, strict != 0);
 }

@@ -35,6 +35,7 @@ def _load():
         "ppgpu_set_config": (C.c_int, [vp, C.POINTER(PpgpuConfig)]),
         "ppgpu_set_grid": (C.c_int, [vp, vp, i32, i32, dbl]),
         "ppgpu_set_obstacles": (C.c_int, [vp, i32, i32, vp]),
+        "ppgpu_set_gaussian_obstacles": (C.c_int, [vp, i32, vp, i32]),
         "ppgpu_set_vertices": (C.c_int, [vp, i32, vp, i32, vp]),
         "ppgpu_sampler_init": (C.c_int, [vp, vp, u64, i32, vp]),
         "ppgpu_sampler_add": (C.c_int, [vp, i64, C.POINTER(i64)]),
@@ -130,6 +131,15 @@ class Context:
             return
         o = np.ascontiguousarray(obst7, dtype=np.float64).reshape(-1, 7)
         self._ck(LIB.ppgpu_set_obstacles(self._h, model, o.shape[0], _ptr(o)), "ppgpu_set_obstacles")
+
+    def set_gaussian_obstacles(self, rows):
+        """rows: n x 5 {x, y, heading, speed, time} (default covariance) or n x 9 (+ row-major 2x2 covariance)."""
+        o = np.ascontiguousarray(rows, dtype=np.float64)
+        if o.size == 0:
+            self._ck(LIB.ppgpu_set_gaussian_obstacles(self._h, 0, None, 0), "ppgpu_set_gaussian_obstacles")
+            return
+        assert o.ndim == 2 and o.shape[1] in (5, 9)
+        self._ck(LIB.ppgpu_set_gaussian_obstacles(self._h, o.shape[0], _ptr(o), 1 if o.shape[1] == 9 else 0), "ppgpu_set_gaussian_obstacles")
 
     def set_vertices(self, vertices, ribbons4):
         v = np.ascontiguousarray(vertices, dtype=VERTEX_DTYPE)

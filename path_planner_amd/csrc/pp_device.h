@@ -44,6 +44,11 @@ __device__ __forceinline__ double pp_wave_max(double v) {
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, PP_WAVE));
     return v;
 }
+__device__ __forceinline__ double pp_wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, PP_WAVE);
+    return v;
+}
 __device__ __forceinline__ int pp_wave_sum_i(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, PP_WAVE);
@@ -396,7 +401,11 @@ __device__ __forceinline__ bool pp_is_blocked(const PPGrid& g, double x, double 
 // the host libm (ppgpu_set_obstacles): cosYaw/sinYaw = cos/sin(M_PI_2 - heading), halfL/halfW =
 // (Length + 2) / 2, (Width + 2) / 2 for the strict test used by Edge::computeTrueCost (Edge.cpp:151);
 // reach = sqrt(halfL^2 + halfW^2) rounded up: no point farther than that from the centre can hit.
-struct PPObst { double X, Y, cosYaw, sinYaw, Speed, Time, halfL, halfW, reach, pad; };
+struct PPObst { double X, Y, cosYaw, sinYaw, Speed, Time, halfL, halfW, reach, pad[3]; };
+// GaussianDynamicObstaclesManager::Obstacle (.h:19-49): a, b, c, d = the inverse covariance (0,0), (0,1), (1,0), (1,1) and
+// norm = 1 / 2pi / sqrt(det), both computed on the host in Eigen's 2x2 order; reach = distance from the mean beyond which
+// the pdf is below 1e-13.  Same size and leading fields as PPObst so the culling code is shared.
+struct PPGauss { double X, Y, cosYaw, sinYaw, Speed, Time, i00, i01, reach, i10, i11, norm; };
 
 // One obstacle's contribution to BinaryDynamicObstaclesManager::collisionExists(x, y, t, strict=true)
 // (.cpp:4-22): project to t, translate, rotate by +Yaw, strict box test.
@@ -411,6 +420,16 @@ __device__ __forceinline__ int pp_obstacle_hit(const PPObst& o, double x, double
     double rx = tx * o.cosYaw - ty * o.sinYaw;
     double ry = tx * o.sinYaw + ty * o.cosYaw;
     return (fabs(rx) < o.halfL && fabs(ry) < o.halfW) ? 1 : 0;
+}
+// GaussianDynamicObstaclesManager::Obstacle::project + pdf (.h:31-43)
+__device__ __forceinline__ double pp_obstacle_pdf(const PPGauss& o, double x, double y, double t) {
+    const double dt = t - o.Time;
+    const double X = o.X + o.Speed * dt * o.cosYaw;
+    const double Y = o.Y + o.Speed * dt * o.sinYaw;
+    const double vx = x - X, vy = y - Y;
+    const double r0 = vx * o.i00 + vy * o.i10, r1 = vx * o.i01 + vy * o.i11;
+    const double quadform = r0 * vx + r1 * vy;
+    return o.norm * exp(-0.5 * quadform);
 }
 
 // Hit count for this lane's step, for 64 consecutive steps held one per lane.
@@ -443,6 +462,37 @@ __device__ inline int pp_obstacle_hits_chunk(const PPObst* __restrict__ ob, int 
         }
     }
     return sum;
+}
+
+// GaussianDynamicObstaclesManager::collisionExists (.cpp:3-13) for this lane's step: the sum of the pdfs of the obstacles
+// that can matter anywhere in the chunk (same culling as above with reach = the 1e-13 radius), in obstacle order, floored
+// at 1e-5.
+__device__ inline double pp_obstacle_density_chunk(const PPGauss* __restrict__ ob, int n, double x, double y, double t, bool valid,
+                                                   double c0x, double c0y, double t0, double span, double tspan) {
+    double sum = 0;
+    const int lane = pp_lane();
+    for (int b = 0; b < n; b += PP_WAVE) {
+        const int oi = b + lane;
+        bool near = false;
+        if (oi < n) {
+            const PPGauss& o = ob[oi];
+            const double dt = t0 - o.Time;
+            const double X = o.X + o.Speed * dt * o.cosYaw;
+            const double Y = o.Y + o.Speed * dt * o.sinYaw;
+            const double R = o.reach + span + fabs(o.Speed) * tspan + 1e-3;
+            const double dx = c0x - X, dy = c0y - Y;
+            near = !(dx * dx + dy * dy > R * R);
+        }
+        unsigned long long m = __ballot(near);
+        while (m) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const PPGauss& o = ob[b + j];      // wave-uniform address: scalar load
+            sum += pp_obstacle_pdf(o, x, y, t);
+        }
+    }
+    if (sum < 1e-5) sum = 0;                   // "questionable", .cpp:11
+    return valid ? sum : 0.0;
 }
 
 // ----------------------------------------------------------------------------- ribbons (one per lane)

@@ -12,7 +12,7 @@ struct PPParams {
     double h_rho;                        // RibbonManager::m_TurningRadius of the Dubins-TSP heuristics
     // world
     PPGrid grid;
-    const PPObst* obst; int n_obst;
+    const PPObst* obst; int n_obst; int obst_model;   // PPGPU_OBST_BINARY, or PPGPU_OBST_GAUSSIAN (then obst points at PPGauss records)
     // open vertices
     const ppgpu_vertex* verts; const double* ribbons; const double* tgrid; int ng; int nverts;
     // targets
@@ -33,6 +33,8 @@ struct PPParams {
     unsigned short* track_hits;          // [edge][ngp]  dynamic-obstacle boxes hit at step k
     unsigned long long* track_eq;        // [edge][nch]  bit k & 63 of word k >> 6: heading(k) == heading(k - 1)
     unsigned* track_chunk_hits;          // [edge][nch]  hits summed over the chunk's executable steps
+    double* track_pen;                   // Gaussian model only: [edge][ngp] collisionExists(step k) ...
+    double* track_chunk_pen;             // ... and [edge][nch] its sum times the penalty factor over the chunk's executable steps
     struct PPTrackSummary* track_summary;
     int ngp, nch;                        // steps per edge rounded up to whole 64-step chunks, and that many chunks
 };
@@ -184,7 +186,9 @@ struct PPTrackSummary {
     int pad;
 };
 
-// e = the edge's slot in the workspace
+// e = the edge's slot in the workspace.  GAUSSIAN: the dynamic obstacles are GaussianDynamicObstaclesManager's (its own
+// instantiation: exp() and the density bookkeeping would otherwise cost the common kernel registers).
+template <bool GAUSSIAN>
 __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long long e) {
     const int lane = pp_lane();
     const PPEdgeSetup* S = p.setup + e;
@@ -211,6 +215,7 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
     unsigned short* thits = p.track_hits + (size_t)e * p.ngp;
     unsigned long long* teq = p.track_eq + (size_t)e * p.nch;
     unsigned* tch = p.track_chunk_hits + (size_t)e * p.nch;
+    const bool gaussian = GAUSSIAN;
     // bounds used by the obstacle culling: how far the vehicle / time advance over one 64-step chunk
     const double chunkTime = 64.0 * (p.inc_d / p.max_speed);
     const double chunkSpan = 64.0 * (p.inc_d / p.max_speed) * speed;
@@ -290,9 +295,15 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
             blk = valid & pp_is_blocked(p.grid, x, y);                // Edge.cpp:144
 #endif
         }
+        double dens = 0;
 #ifndef PP_ABL_NO_OBST
-        if (anyObstacle)                                              // :150-151
-            hits = pp_obstacle_hits_chunk(p.obst, p.n_obst, x, y, t, valid, pp_readlane(x, 0), pp_readlane(y, 0), tFirst, chunkSpan, chunkTime);
+        if (anyObstacle) {                                            // :150-151
+            if (!gaussian)
+                hits = pp_obstacle_hits_chunk(p.obst, p.n_obst, x, y, t, valid, pp_readlane(x, 0), pp_readlane(y, 0), tFirst, chunkSpan, chunkTime);
+            else
+                dens = pp_obstacle_density_chunk(reinterpret_cast<const PPGauss*>(p.obst), p.n_obst, x, y, t, valid, pp_readlane(x, 0),
+                                                 pp_readlane(y, 0), tFirst, chunkSpan, chunkTime);
+        }
 #endif
         unsigned long long eqMask = ~0ull;
         if (!cov) {
@@ -316,6 +327,14 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
             chunkHits = pp_wave_sum_i(lane < nlim ? hits : 0);
             thits[k] = (unsigned short)(hits > 65535 ? 65535 : hits);
         }
+        if (gaussian) {
+            double chunkPen = 0;
+            if (__ballot(dens != 0.0) != 0ull) {
+                chunkPen = pp_wave_sum_d(lane < nlim ? dens * p.cpf : 0.0);
+                p.track_pen[(size_t)e * p.ngp + k] = dens;
+            }
+            if (lane == 0) p.track_chunk_pen[(size_t)e * p.nch + (base >> 6)] = chunkPen;
+        }
         if (lane == 0) {
             tch[base >> 6] = (unsigned)chunkHits;
             if (!cov) teq[base >> 6] = eqMask;                        // only read for edges that may not cover while turning
@@ -330,6 +349,7 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
 }
 
 // e = the edge's slot in the workspace, eg = its position in the caller's edge list, lds = 256 doubles private to the wave
+template <bool GAUSSIAN>
 __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const long long e, const long long eg, double* lds) {
     const int lane = pp_lane();
 
@@ -558,7 +578,16 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
             hitsTotal = pp_wave_sum_i(acc);
         }
     }
-    const double penalty = (double)hitsTotal * p.cpf;                             // :150-151 summed
+    double penalty = (double)hitsTotal * p.cpf;                                   // :150-151 summed
+    if (GAUSSIAN && !throwsRef && p.n_obst > 0) {
+        // Gaussian model: the per-step values are doubles; whole chunks from the pose sweep's sums, the rest step by step
+        const double* cpn = p.track_chunk_pen + (size_t)e * p.nch;
+        const int cfull = hexec >> 6;
+        double acc = 0;
+        for (int c = lane; c < cfull; c += PP_WAVE) acc += cpn[c];
+        if ((hexec & 63) != 0 && cpn[cfull] != 0.0 && (cfull << 6) + lane < hexec) acc += p.track_pen[(size_t)e * p.ngp + (cfull << 6) + lane] * p.cpf;
+        penalty = pp_wave_sum_d(acc);
+    }
     const double netTime = endTime - srcT;                                        // Edge::netTime
     double tc = fmax(netTime - ((nrib == 0) ? (endTime - (double)rdt) : 0), 0);  // :197
     if (startedDone) tc = 0;                                                      // :198
@@ -623,13 +652,24 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
 __global__ __launch_bounds__(PP_WPB * 64, PP_POSE_MIN_WAVES) void pp_k_pose_sweep(PPParams p) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long idx = (long long)blockIdx.x * PP_WPB + wave;
-    if (idx < p.n_edges) pp_pose_sweep_edge(p, p.ws_base + idx);
+    if (idx < p.n_edges) pp_pose_sweep_edge<false>(p, p.ws_base + idx);
+}
+__global__ __launch_bounds__(PP_WPB * 64, 4) void pp_k_pose_sweep_gaussian(PPParams p) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long idx = (long long)blockIdx.x * PP_WPB + wave;
+    if (idx < p.n_edges) pp_pose_sweep_edge<true>(p, p.ws_base + idx);
 }
 __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep(PPParams p) {
     __shared__ double lds_all[PP_WPB][PP_WAVE * 4];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long idx = (long long)blockIdx.x * PP_WPB + wave;
-    if (idx < p.n_edges) pp_cover_sweep_edge(p, p.ws_base + idx, p.e_base + idx, lds_all[wave]);
+    if (idx < p.n_edges) pp_cover_sweep_edge<false>(p, p.ws_base + idx, p.e_base + idx, lds_all[wave]);
+}
+__global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep_gaussian(PPParams p) {
+    __shared__ double lds_all[PP_WPB][PP_WAVE * 4];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long idx = (long long)blockIdx.x * PP_WPB + wave;
+    if (idx < p.n_edges) pp_cover_sweep_edge<true>(p, p.ws_base + idx, p.e_base + idx, lds_all[wave]);
 }
 
 // ------------------------------------------------------------------------------------------

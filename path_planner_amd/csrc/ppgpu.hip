@@ -67,6 +67,7 @@ struct ppgpu_ctx {
     // dynamic obstacles
     DevBuf<PPObst> obst;
     int n_obst = 0;
+    int obst_model = PPGPU_OBST_NONE;
     // open vertices
     DevBuf<ppgpu_vertex> verts;
     DevBuf<double> ribbons, tgrid;
@@ -94,6 +95,7 @@ struct ppgpu_ctx {
     DevBuf<unsigned long long> track_eq;
     DevBuf<unsigned> track_chunk_hits;
     DevBuf<PPTrackSummary> track_summary;
+    DevBuf<double> track_pen, track_chunk_pen;   // Gaussian obstacle model only
     // optional per-kernel timing of costing launches (ppgpu_enable_timing)
     bool timing = false;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -146,7 +148,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->tmp_edges.release(); c->tmp_wedges.release(); c->partial.release(); c->tmp_results.release(); c->tmp_child.release();
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     c->setup.release(); c->track_pose.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
-    c->track_summary.release();
+    c->track_summary.release(); c->track_pen.release(); c->track_chunk_pen.release();
     for (int i = 0; i < 5; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -229,7 +231,8 @@ int ppgpu_set_grid(ppgpu_ctx* c, const uint8_t* cells, int32_t rows, int32_t col
 int ppgpu_set_obstacles(ppgpu_ctx* c, int32_t model, int32_t n, const double* o7) {
     if (!c) return fail(PPGPU_EINVAL, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    if (model == PPGPU_OBST_NONE || n == 0) { c->n_obst = 0; return PPGPU_OK; }
+    if (model == PPGPU_OBST_NONE || n == 0) { c->n_obst = 0; c->obst_model = PPGPU_OBST_NONE; return PPGPU_OK; }
+    if (model == PPGPU_OBST_GAUSSIAN) return fail(PPGPU_EINVAL, "obstacles: the Gaussian model takes its rows through ppgpu_set_gaussian_obstacles");
     if (model != PPGPU_OBST_BINARY) return fail(PPGPU_EINVAL, "obstacles: unknown model");
     if (n < 0 || !o7) return fail(PPGPU_EINVAL, "obstacles: bad arguments");
     std::vector<PPObst> h((size_t)n);
@@ -244,13 +247,54 @@ int ppgpu_set_obstacles(ppgpu_ctx* c, int32_t model, int32_t n, const double* o7
         h[i].halfW = (o[5] + 2) / 2;
         h[i].halfL = (o[6] + 2) / 2;
         h[i].reach = std::sqrt(h[i].halfW * h[i].halfW + h[i].halfL * h[i].halfL) * (1.0 + 1e-12);
-        h[i].pad = 0;
+        h[i].pad[0] = h[i].pad[1] = h[i].pad[2] = 0;
     }
     int rc = c->obst.reserve((size_t)n, false, c->stream);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(c->obst.p, h.data(), h.size() * sizeof(PPObst), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_obst = n;
+    c->obst_model = PPGPU_OBST_BINARY;
+    return PPGPU_OK;
+}
+
+int ppgpu_set_gaussian_obstacles(ppgpu_ctx* c, int32_t n, const double* rows, int32_t covariance_given) {
+    if (!c) return fail(PPGPU_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (n == 0) { c->n_obst = 0; c->obst_model = PPGPU_OBST_NONE; return PPGPU_OK; }
+    if (n < 0 || !rows) return fail(PPGPU_EINVAL, "gaussian obstacles: bad arguments");
+    static_assert(sizeof(PPGauss) == sizeof(PPObst), "both obstacle records share one buffer and the culling fields");
+    std::vector<PPGauss> h((size_t)n);
+    const int stride = covariance_given ? 9 : 5;
+    for (int i = 0; i < n; i++) {
+        const double* o = rows + (size_t)stride * i;
+        // Obstacle(x, y, heading, speed, time[, covariance]): Yaw = M_PI_2 - heading, default covariance
+        // [[30,10],[10,30]] (GaussianDynamicObstaclesManager.h:23-29)
+        const double yaw = M_PI_2 - o[2];
+        double c00 = 30, c01 = 10, c10 = 10, c11 = 30;
+        if (covariance_given) { c00 = o[5]; c01 = o[6]; c10 = o[7]; c11 = o[8]; }
+        // pdf(): covariance.inverse() and covariance.determinant() of a fixed 2x2 (Eigen's closed forms), norm = 1/2pi/sqrt(det)
+        const double det = c00 * c11 - c10 * c01;
+        const double invdet = 1.0 / det;
+        PPGauss& g = h[i];
+        g.X = o[0]; g.Y = o[1]; g.cosYaw = std::cos(yaw); g.sinYaw = std::sin(yaw); g.Speed = o[3]; g.Time = o[4];
+        g.i00 = c11 * invdet; g.i10 = -c10 * invdet; g.i01 = -c01 * invdet; g.i11 = c00 * invdet;
+        const double twoPi = 2 * M_PI;
+        g.norm = 1.0 / twoPi / std::sqrt(det);
+        // culling radius: pdf <= |norm| exp(-lmin d^2 / 2), lmin = smallest eigenvalue of the symmetric part of the inverse;
+        // beyond reach it is below 1e-13 (collisionExists floors its SUM at 1e-5).  Not positive definite: never culled.
+        const double sa = g.i00, sc = g.i11, sb = 0.5 * (g.i01 + g.i10);
+        const double lmin = 0.5 * (sa + sc) - std::sqrt(0.25 * (sa - sc) * (sa - sc) + sb * sb);
+        if (!(det > 0) || !(lmin > 0) || !std::isfinite(g.norm)) g.reach = 1e300;
+        else if (!(std::fabs(g.norm) > 1e-13)) g.reach = 0;
+        else g.reach = std::sqrt(2.0 * std::log(std::fabs(g.norm) / 1e-13) / lmin) * (1.0 + 1e-9);
+    }
+    int rc = c->obst.reserve((size_t)n, false, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->obst.p, h.data(), h.size() * sizeof(PPGauss), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n_obst = n;
+    c->obst_model = PPGPU_OBST_GAUSSIAN;
     return PPGPU_OK;
 }
 
@@ -487,7 +531,7 @@ static void fill_params(ppgpu_ctx* c, PPParams& p) {
     p.cpf = g.collision_penalty_factor; p.tpf = g.time_penalty_factor;
     p.heuristic = g.heuristic; p.tsp_k = g.tsp_k; p.h_rho = g.heuristic_turning_radius;
     p.grid = PPGrid{c->grid.p, c->rows, c->cols, c->wpr, c->res, c->res > 0 ? 1.0 / c->res : 0.0};
-    p.obst = c->obst.p; p.n_obst = c->n_obst;
+    p.obst = c->obst.p; p.n_obst = c->n_obst; p.obst_model = c->obst_model;
     p.verts = c->verts.p; p.ribbons = c->ribbons.p; p.tgrid = c->tgrid.p; p.ng = c->ng; p.nverts = c->nverts;
     p.sx = c->sx.p; p.sy = c->sy.p; p.sh = c->sh.p; p.n_samples = c->n_samples + c->n_extra;
 }
@@ -556,7 +600,8 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     if (p.nch < 1) p.nch = 1;
     p.ngp = p.nch * PP_WAVE;
     const size_t per_edge = sizeof(PPEdgeSetup) + (size_t)p.ngp * (sizeof(double2) + sizeof(unsigned short)) +
-                            (size_t)p.nch * (sizeof(unsigned long long) + sizeof(unsigned)) + sizeof(PPTrackSummary);
+                            (size_t)p.nch * (sizeof(unsigned long long) + sizeof(unsigned)) + sizeof(PPTrackSummary) +
+                            ((p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN) ? (size_t)(p.ngp + p.nch) * sizeof(double) : 0);
     long long slice = (long long)(c->slice_bytes / per_edge);
     if (slice < PP_WPB) slice = PP_WPB;
     if (slice > total) slice = total;
@@ -570,18 +615,28 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
             (rc = c->track_chunk_hits.reserve(ws * p.nch, false, c->stream)) ||
             (rc = c->track_summary.reserve(ws, false, c->stream)))
             return rc;
+        if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN &&
+            ((rc = c->track_pen.reserve(ws * p.ngp, false, c->stream)) || (rc = c->track_chunk_pen.reserve(ws * p.nch, false, c->stream))))
+            return rc;
     }
     p.setup = c->setup.p; p.track_pose = c->track_pose.p; p.track_hits = c->track_hits.p; p.track_eq = c->track_eq.p;
     p.track_chunk_hits = c->track_chunk_hits.p; p.track_summary = c->track_summary.p;
+    p.track_pen = c->track_pen.p; p.track_chunk_pen = c->track_chunk_pen.p;
     for (long long e0 = 0; e0 < total; e0 += slice) {
         p.e_base = e0; p.ws_base = 0; p.n_edges = (total - e0 < slice) ? (total - e0) : slice;
         const unsigned blocks = (unsigned)((p.n_edges + PP_WPB - 1) / PP_WPB);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(pp_k_solve_edges, dim3((unsigned)((p.n_edges + 255) / 256)), dim3(256), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-        hipLaunchKernelGGL(pp_k_pose_sweep, dim3(blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+        if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN)
+            hipLaunchKernelGGL(pp_k_pose_sweep_gaussian, dim3(blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+        else
+            hipLaunchKernelGGL(pp_k_pose_sweep, dim3(blocks), dim3(PP_WPB * 64), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-        hipLaunchKernelGGL(pp_k_cover_sweep, dim3(blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+        if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN)
+            hipLaunchKernelGGL(pp_k_cover_sweep_gaussian, dim3(blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+        else
+            hipLaunchKernelGGL(pp_k_cover_sweep, dim3(blocks), dim3(PP_WPB * 64), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     }
     p.e_base = 0;

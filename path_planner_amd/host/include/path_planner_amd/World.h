@@ -1,6 +1,7 @@
-// Map / GridWorldMap / DynamicObstaclesManager / BinaryDynamicObstaclesManager / PlannerConfig — host mirrors of
+// Map / GridWorldMap / DynamicObstaclesManager / Binary- and GaussianDynamicObstaclesManager / PlannerConfig — host mirrors of
 //   /root/reference/path_planner/src/common/map/{Map,GridWorldMap}.{h,cpp}
-//   /root/reference/path_planner/src/common/dynamic_obstacles/{DynamicObstaclesManager,BinaryDynamicObstaclesManager}.{h,cpp}
+//   /root/reference/path_planner/src/common/dynamic_obstacles/{DynamicObstaclesManager,BinaryDynamicObstaclesManager,
+//       GaussianDynamicObstaclesManager}.{h,cpp}
 //   /root/reference/path_planner/src/planner/PlannerConfig.h
 // The planner uploads snapshots of them to the device at the start of every plan() call.
 #pragma once
@@ -56,9 +57,10 @@ public:
     virtual ~DynamicObstaclesManager() = default;
     virtual double collisionExists(double x, double y, double time, bool strict) const { return 0; }
     double collisionExists(const State& s, bool strict) const { return collisionExists(s.x(), s.y(), s.time(), strict); }
-    // device snapshot: model id (PPGPU_OBST_*) and rows of {x, y, heading, speed, time, width, length}
+    // device snapshot: model id (PPGPU_OBST_*) and rows of {x, y, heading, speed, time, width, length} (binary) or
+    // {x, y, heading, speed, time, c00, c01, c10, c11} (Gaussian)
     virtual int deviceModel() const { return 0; }
-    virtual void deviceRows(std::vector<double>& rows7) const { rows7.clear(); }
+    virtual void deviceRows(std::vector<double>& rows) const { rows.clear(); }
 };
 
 class BinaryDynamicObstaclesManager : public DynamicObstaclesManager {
@@ -83,6 +85,41 @@ public:
     const std::unordered_map<uint32_t, Obstacle>& get() const { return m_Obstacles; }
     int deviceModel() const override { return 1; }
     void deviceRows(std::vector<double>& rows7) const override;
+
+private:
+    std::unordered_map<uint32_t, Obstacle> m_Obstacles;
+    std::unordered_set<uint32_t> m_Ignored;
+};
+
+// GaussianDynamicObstaclesManager.{h,cpp}, without Eigen: the 2x2 covariance is four doubles (row-major) and inverse /
+// determinant / quadratic form are written out in the order Eigen's fixed-size code evaluates them.
+class GaussianDynamicObstaclesManager : public DynamicObstaclesManager {
+public:
+    typedef std::shared_ptr<GaussianDynamicObstaclesManager> SharedPtr;
+    struct Obstacle {
+        double X, Y, Yaw, Speed, Time, Heading;
+        double covariance[4];
+        Obstacle(double x, double y, double heading, double speed, double time)
+            : X(x), Y(y), Yaw(M_PI_2 - heading), Speed(speed), Time(time), Heading(heading), covariance{30, 10, 10, 30} {}
+        Obstacle(double x, double y, double heading, double speed, double time, const double cov[4])
+            : X(x), Y(y), Yaw(M_PI_2 - heading), Speed(speed), Time(time), Heading(heading), covariance{cov[0], cov[1], cov[2], cov[3]} {}
+        void project(double desiredTime) {
+            double dt = desiredTime - Time;
+            double dx = Speed * dt * std::cos(Yaw);
+            double dy = Speed * dt * std::sin(Yaw);
+            X += dx; Y += dy;
+        }
+        double pdf(double x, double y) const;
+    };
+    void update(uint32_t mmsi, double x, double y, double heading, double speed, double time);
+    void update(uint32_t mmsi, double x, double y, double heading, double speed, double time, const double covariance[4]);
+    void forget(uint32_t mmsi) { m_Obstacles.erase(mmsi); }
+    void addIgnore(uint32_t mmsi) { m_Ignored.emplace(mmsi); }
+    void removeIgnore(uint32_t mmsi) { m_Ignored.erase(mmsi); }
+    double collisionExists(double x, double y, double time, bool strict) const override;   // .cpp:3-13
+    const std::unordered_map<uint32_t, Obstacle>& get() const { return m_Obstacles; }
+    int deviceModel() const override { return 2; }
+    void deviceRows(std::vector<double>& rows9) const override;
 
 private:
     std::unordered_map<uint32_t, Obstacle> m_Obstacles;

@@ -100,11 +100,13 @@ void GpuAStarPlanner::uploadWorld(const State& start) {
     if (m_Config.map()) m_Config.map()->rasterize(cells, rows, cols, res);
     check(ppgpu_set_grid(h, rows ? cells.data() : nullptr, rows, cols, res), "ppgpu_set_grid");
 
-    std::vector<double> rows7;
+    std::vector<double> orows;
     const DynamicObstaclesManager& om = m_Config.obstaclesManager();
-    om.deviceRows(rows7);
-    check(ppgpu_set_obstacles(h, om.deviceModel(), (int32_t)(rows7.size() / 7), rows7.empty() ? nullptr : rows7.data()),
-          "ppgpu_set_obstacles");
+    om.deviceRows(orows);
+    if (om.deviceModel() == PPGPU_OBST_GAUSSIAN)
+        check(ppgpu_set_gaussian_obstacles(h, (int32_t)(orows.size() / 9), orows.empty() ? nullptr : orows.data(), 1), "ppgpu_set_gaussian_obstacles");
+    else
+        check(ppgpu_set_obstacles(h, om.deviceModel(), (int32_t)(orows.size() / 7), orows.empty() ? nullptr : orows.data()), "ppgpu_set_obstacles");
 }
 
 // ------------------------------------------------------------------------------------------------ open list

@@ -107,4 +107,45 @@ void BinaryDynamicObstaclesManager::deviceRows(std::vector<double>& rows7) const
     }
 }
 
+// ---------------------------------------------------------------- GaussianDynamicObstaclesManager
+double GaussianDynamicObstaclesManager::Obstacle::pdf(double x, double y) const {   // .h:38-43
+    const double twoPi = 2 * M_PI;
+    const double det = covariance[0] * covariance[3] - covariance[2] * covariance[1];
+    const double invdet = 1.0 / det;
+    const double i00 = covariance[3] * invdet, i10 = -covariance[2] * invdet, i01 = -covariance[1] * invdet, i11 = covariance[0] * invdet;
+    const double vx = x - X, vy = y - Y;
+    const double r0 = vx * i00 + vy * i10, r1 = vx * i01 + vy * i11;
+    const double quadform = r0 * vx + r1 * vy;
+    const double norm = 1.0 / twoPi / std::sqrt(det);
+    return norm * std::exp(-0.5 * quadform);
+}
+double GaussianDynamicObstaclesManager::collisionExists(double x, double y, double time, bool) const {   // .cpp:3-13
+    double sum = 0;
+    for (auto o : m_Obstacles) {
+        auto& obstacle = o.second;
+        obstacle.project(time);
+        sum += obstacle.pdf(x, y);
+    }
+    if (sum < 1e-5) return 0;
+    return sum;
+}
+void GaussianDynamicObstaclesManager::update(uint32_t mmsi, double x, double y, double heading, double speed, double time) {   // .cpp:15-26
+    if (m_Ignored.count(mmsi)) return;
+    auto result = m_Obstacles.emplace(mmsi, Obstacle(x, y, heading, speed, time));
+    if (!result.second) result.first->second = Obstacle(x, y, heading, speed, time);
+}
+void GaussianDynamicObstaclesManager::update(uint32_t mmsi, double x, double y, double heading, double speed, double time,
+                                             const double covariance[4]) {   // .cpp:36-47
+    if (m_Ignored.count(mmsi)) return;
+    auto result = m_Obstacles.emplace(mmsi, Obstacle(x, y, heading, speed, time, covariance));
+    if (!result.second) result.first->second = Obstacle(x, y, heading, speed, time, covariance);
+}
+void GaussianDynamicObstaclesManager::deviceRows(std::vector<double>& rows9) const {
+    rows9.clear();
+    for (const auto& kv : m_Obstacles) {
+        const Obstacle& o = kv.second;
+        rows9.insert(rows9.end(), {o.X, o.Y, o.Heading, o.Speed, o.Time, o.covariance[0], o.covariance[1], o.covariance[2], o.covariance[3]});
+    }
+}
+
 }  // namespace ppamd

@@ -3,7 +3,7 @@
 // under the same injected clock (PlannerConfig::setNowFunction).
 //
 // Scenario lines:  cfg <key> <value> | start x y heading speed time | ribbon x1 y1 x2 y2 | heuristic H K radius |
-//                  ribbon_width w | obstacle x y heading speed time width length | map_file path | clock t0 dt |
+//                  ribbon_width w | obstacle x y heading speed time width length | gaussian x y heading speed time [c00 c01 c10 c11] | map_file path | clock t0 dt |
 //                  time_remaining T | prev qi0 qi1 qi2 p0 p1 p2 rho type speed start end | repeat n
 #include <cstdio>
 #include <fstream>
@@ -24,7 +24,8 @@ int main(int argc, char** argv) {
     double hr = 8;
     std::vector<std::array<double, 4>> ribs;
     auto obst = std::make_shared<BinaryDynamicObstaclesManager>();
-    bool haveObst = false;
+    auto gauss = std::make_shared<GaussianDynamicObstaclesManager>();
+    bool haveObst = false, haveGauss = false;
     Map::SharedPtr map = std::make_shared<Map>();
     double t0 = 1000, dt = 1e-3, timeRemaining = 0.05;
     DubinsPlan prev;
@@ -56,6 +57,10 @@ int main(int argc, char** argv) {
         } else if (k == "ribbon_width") { double w; s >> w; RibbonManager::setRibbonWidth(w);
         } else if (k == "obstacle") {
             double x, y, h, v, t, w, l; s >> x >> y >> h >> v >> t >> w >> l; obst->update(mmsi++, x, y, h, v, t, w, l); haveObst = true;
+        } else if (k == "gaussian") {      // x y heading speed time [c00 c01 c10 c11]
+            double x, y, h, v, t, c[4]; s >> x >> y >> h >> v >> t;
+            if (s >> c[0] >> c[1] >> c[2] >> c[3]) gauss->update(mmsi++, x, y, h, v, t, c); else gauss->update(mmsi++, x, y, h, v, t);
+            haveGauss = true;
         } else if (k == "map_file") { std::string p; s >> p; map = std::make_shared<GridWorldMap>(p);
         } else if (k == "clock") { s >> t0 >> dt;
         } else if (k == "time_remaining") { s >> timeRemaining;
@@ -73,6 +78,7 @@ int main(int argc, char** argv) {
     for (auto& r : ribs) rm.add(r[0], r[1], r[2], r[3]);
     config.setMap(map);
     if (haveObst) config.setObstaclesManager(obst);
+    if (haveGauss) config.setObstaclesManager(gauss);
     try {
         Planner::Stats st;
         for (int rep = 0; rep < repeat; rep++) {

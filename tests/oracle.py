@@ -80,6 +80,7 @@ for _n, _r, _a in [
     ("ppo_world_is_blocked", i32, [vp, dbl, dbl]),
     ("ppo_world_is_blocked_many", None, [vp, i64, vp, vp, vp]),
     ("ppo_world_set_obstacles", None, [vp, i32, i32, vp]),
+    ("ppo_world_set_gaussian_obstacles", None, [vp, i32, vp, i32]),
     ("ppo_world_collision_exists", dbl, [vp, dbl, dbl, dbl, i32]),
     ("ppo_sampler_generate", None, [vp, u64, i32, vp, i64, i64, vp, vp]),
     ("ppo_add_samples", i64, [vp, vp, u64, i32, vp, i64, i64, vp]),
@@ -105,7 +106,8 @@ def f64(a):
 class World:
     """Grid + obstacles + config of the oracle."""
 
-    def __init__(self, cfg, grid=None, res=0.0, obst=None):
+    def __init__(self, cfg, grid=None, res=0.0, obst=None, gauss=None):
+        """obst: n x 7 binary boxes; gauss: n x 5 / n x 9 Gaussian obstacles (then obst must be None)."""
         self.h = O.ppo_world_create()
         self.cfg = cfg
         O.ppo_world_set_config(self.h, C.byref(cfg))
@@ -115,6 +117,10 @@ class World:
         if obst is not None and len(obst):
             o = f64(obst).reshape(-1, 7)
             O.ppo_world_set_obstacles(self.h, 1, o.shape[0], _p(o))
+        if gauss is not None and len(gauss):
+            o = f64(gauss)
+            assert o.ndim == 2 and o.shape[1] in (5, 9)
+            O.ppo_world_set_gaussian_obstacles(self.h, o.shape[0], _p(o), 1 if o.shape[1] == 9 else 0)
 
     def __del__(self):
         try:

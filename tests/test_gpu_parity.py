@@ -344,3 +344,49 @@ def test_out_of_range_heading_is_refused(torch_cuda):
     res, _ = _dense(torch_cuda, ctx, 1, n, 0xF)
     want = F_DUBINS_ERR | F_THROWS | F_INFEASIBLE
     assert np.all((res["flags"] & want) == want)
+
+
+@pytest.mark.parametrize("cov", ["default", "custom"])
+def test_gaussian_obstacle_model_matches_oracle(torch_cuda, cov):
+    """GaussianDynamicObstaclesManager (sum of bivariate normal pdfs, floored at 1e-5) behind the same edge coster: the
+    collision penalty is a sum of doubles over the steps (Edge.cpp:150-151).  Obstacles whose density is below 1e-13 over a
+    whole chunk are skipped on the device, hence the penalty is compared at the usual 1e-5, not bit for bit."""
+    from path_planner_amd import api, workloads
+    from path_planner_amd.types import edge_pack
+    from parity import compare_results
+    import oracle as orc
+    w = workloads.config2()
+    rng = np.random.default_rng(5)
+    n_ob = 12
+    root = w.root()
+    rows = np.zeros((n_ob, 9 if cov == "custom" else 5))
+    rows[:, 0] = root["x"][0] + rng.uniform(-70, 70, n_ob)
+    rows[:, 1] = root["y"][0] + rng.uniform(-70, 70, n_ob)
+    rows[:, 2] = rng.uniform(0, 2 * np.pi, n_ob)
+    rows[:, 3] = rng.uniform(0, 3, n_ob)
+    rows[:, 4] = root["time"][0] - rng.uniform(0, 5, n_ob)
+    if cov == "custom":
+        for i in range(n_ob):
+            a, b = rng.uniform(4, 60), rng.uniform(4, 60)
+            c = rng.uniform(-0.6, 0.6) * np.sqrt(a * b)
+            rows[i, 5:] = [a, c, c, b]
+    ctx = api.Context(0)
+    ctx.set_config(w.cfg)
+    ctx.set_grid(w.grid, w.res)
+    ctx.set_gaussian_obstacles(rows)
+    ctx.set_vertices(root, w.ribbons4)
+    ctx.sampler_init(w.bounds6, w.seed, w.ribbons4)
+    n = ctx.sampler_add(1024)
+    world = orc.World(w.cfg, w.grid, w.res, gauss=rows)
+    cs = world.add_samples(w.bounds6, w.seed, w.ribbons4, 0, 1024)
+    gpu, gchild = _dense(torch_cuda, ctx, 1, n, 0xF)
+    e = edge_pack(np.zeros(len(gpu), dtype=np.uint64), np.repeat(np.arange(n), 4), np.tile(np.arange(4), n))
+    cpu, cchild = world.cost_edges(root, w.ribbons4, cs[:, 0], cs[:, 1], cs[:, 2], e, stride=8)
+    rep = compare_results(gpu, cpu, gchild, cchild)
+    print(cov, rep, "edges with a penalty:", int(np.count_nonzero(cpu["collision_penalty"] > 0)))
+    assert rep["ok"], rep
+    assert np.count_nonzero(cpu["collision_penalty"] > 0) > 50          # the model is actually exercised
+    # switching back to the binary model on the same handle must not leave Gaussian state behind
+    ctx.set_obstacles(workloads.obstacles(4, 9, 150.0, time=float(root["time"][0]), keep_free=(float(root["x"][0]), float(root["y"][0]), 25)))
+    b1, _ = _dense(torch_cuda, ctx, 1, n, 0xF)
+    assert np.all(b1["collision_penalty"] == np.round(b1["collision_penalty"] / 600.0) * 600.0)
