@@ -168,6 +168,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline_and_parity(ctx, w, res))
+            out.update(first_goal_check())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -205,6 +206,37 @@ def cpu_baseline_and_parity(ctx, w, gpu_res):
                          "single_thread_value": 4 * n_single / t1},
         "parity": {"ok": rep["ok"], "edges_checked": rep["n"], "flags_equal": rep["flags_equal"], "worst_rel": rep["worst_rel"]},
     }
+
+
+def first_goal_check():
+    """BASELINE.json's second metric, iterations-to-first-goal with a fixed seed: one whole plan() of the C++ host planner
+    (path_planner_amd/host/plan_cli, every edge costed on the GPU) and of the CPU oracle's planner on config 2, both driven by
+    the same injected clock.  Not timed; reported next to the throughput line.  Skipped (null) if the CLI is not built."""
+    import tempfile
+    import oracle as orc
+    from path_planner_amd import workloads
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        from test_gpu_host_planner import CLI, _run_cli, _scenario, _write_map
+        if not os.path.exists(CLI):
+            return {"first_goal": None}
+        w2 = workloads.by_name("cfg2")
+        orc.O.ppo_set_ribbon_width(w2.cfg.ribbon_width)
+        world = orc.World(w2.cfg, w2.grid, w2.res, w2.obst)
+        t0, dt, calls, init = 1000.0, 1e-3, 40, 256
+        with tempfile.TemporaryDirectory() as d:
+            mp = os.path.join(d, "grid.map")
+            _write_map(w2.grid, w2.res, mp)
+            sc = os.path.join(d, "s.txt")
+            _scenario(w2, sc, mp, t0, dt, calls, init)
+            host = _run_cli(sc)
+        rc, st, plan, _, _ = world.plan(w2.ribbons4, w2.start5, calls * dt, t0, dt, initial_samples=init)
+        return {"first_goal": {"workload": w2.name, "seed": "fixed by the injected clock", "iteration_gpu": host["first_goal_iteration"],
+                               "iteration_cpu_oracle": int(st.first_goal_iteration), "plan_f_gpu": host["plan_f"], "plan_f_cpu_oracle": float(st.plan_f),
+                               "identical_index": host["first_goal_iteration"] == int(st.first_goal_iteration),
+                               "plan_f_rel_diff": abs(host["plan_f"] - float(st.plan_f)) / max(1.0, abs(float(st.plan_f)))}}
+    except Exception as e:   # the throughput line must not depend on this leg
+        return {"first_goal": {"error": repr(e)}}
 
 
 if __name__ == "__main__":

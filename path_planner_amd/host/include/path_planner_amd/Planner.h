@@ -7,6 +7,7 @@
 // injected clock and seed the same vertices are expanded in the same order.
 #pragma once
 #include <memory>
+#include <unordered_map>
 #include <vector>
 
 #include "DubinsWrapper.h"
@@ -14,6 +15,8 @@
 #include "World.h"
 
 struct ppgpu_ctx;
+
+struct ppgpu_edge_result;   // include/ppgpu.h
 
 namespace ppamd {
 
@@ -88,12 +91,15 @@ private:
     double m_StartStateTime = 0;
     RibbonManager m_RibbonManager;
     long m_NumSamples = 0;
+    std::unordered_map<int, std::vector<Node>> m_Speculated;   // children of open vertices costed ahead of their expansion
 
     void uploadWorld(const State& start);
     void pushVertexQueue(int v);
     int popVertexQueue();
     bool goalCondition(const Node& v) const;
     void expand(int source);
+    void expandBatch(const std::vector<int>& sources);
+    Node makeChild(int source, unsigned cfgBits, const ::ppgpu_edge_result& r, const double* childRibbons);
     int aStar(double endTime);
     void addSamples(long n);
     int depth(int v) const;

@@ -158,11 +158,16 @@ public:
     void setTimeMinimum(double t) { m_TimeMinimum = t; }
     double slowSpeed() const { return m_SlowSpeed <= 0 ? m_MaxSpeed : m_SlowSpeed; }
     void setSlowSpeed(double s) { m_SlowSpeed = s; }
+    // How many open vertices one device round trip expands (this planner only; 1 = one vertex at a time, exactly the
+    // reference's call pattern).  Results do not depend on it, only when the arithmetic happens.
+    int speculation() const { return m_Speculation; }
+    void setSpeculation(int n) { m_Speculation = n < 1 ? 1 : n; }
     // the reference's visualisation stream is not available on the device path
     bool visualizations() const { return false; }
 
 private:
     int m_BranchingFactor = 9;
+    int m_Speculation = 16;
     double m_MaxSpeed = 2.5, m_SlowSpeed = 0.5, m_TurningRadius = 8, m_CoverageTurningRadius = 16;
     double m_TimeHorizon = 30, m_TimeMinimum = 5;
     double m_CollisionCheckingIncrement = 0.05;

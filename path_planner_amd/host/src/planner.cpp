@@ -147,9 +147,35 @@ void GpuAStarPlanner::addSamples(long n) {   // SamplingBasedPlanner::addSamples
         left -= chunk;
     }
     if (n > 0) m_NumSamples = (long)total;
+    m_Speculated.clear();   // children costed ahead were chosen among the old samples
 }
 
 // ------------------------------------------------------------------------------------------------ edges
+// The child Node of one costed edge (what Vertex::connect + Edge::computeTrueCost + Vertex::computeApproxToGo leave behind)
+GpuAStarPlanner::Node GpuAStarPlanner::makeChild(int source, unsigned cfgBits, const ppgpu_edge_result& r, const double* childRibbons) {
+    if (r.flags & PPGPU_F_THROWS) throw std::runtime_error("Edge cost evaluation failed: invalid time in sample for Dubins path");
+    if (r.flags & (PPGPU_F_RIBBON_OVF | PPGPU_F_DUBINS_ERR)) throw std::runtime_error("Edge cost evaluation exceeded a device capacity");
+    const Node& src = m_Nodes[source];
+    Node c;
+    c.parent = source;
+    c.state = State(r.end_x, r.end_y, r.end_heading, r.end_speed, r.end_time);
+    c.coverageAllowed = (cfgBits & PPGPU_EDGE_COVERAGE) != 0;
+    c.infeasible = (r.flags & PPGPU_F_INFEASIBLE) != 0;
+    c.collisionPenalty = r.collision_penalty;
+    c.g = r.g;
+    c.h = r.h;
+    c.ribbons = src.ribbons;   // keeps heuristic, K, turning radius
+    c.ribbons.assign(childRibbons, (int)((r.info >> 8) & 0xff), r.coverage_completed_time);
+    DubinsPath p;
+    p.qi[0] = src.state.x(); p.qi[1] = src.state.y(); p.qi[2] = src.state.yaw();
+    p.param[0] = r.param[0]; p.param[1] = r.param[1]; p.param[2] = r.param[2];
+    p.rho = c.coverageAllowed ? m_Config.coverageTurningRadius() : m_Config.turningRadius();
+    p.type = (DubinsPathType)(r.info & 0xff);
+    c.wrapper.fill(p, r.end_speed, src.state.time());
+    if (!c.infeasible && r.end_time < c.wrapper.getEndTime()) c.wrapper.updateEndTime(r.end_time);   // Edge.cpp:179
+    return c;
+}
+
 // Vertex::connect(source, state, radius, coverageAllowed) + Edge::computeTrueCost for a batch of targets, then
 // pushVertexQueue in the given order.  sampleIndex[i] >= 0 uses a stored sample, otherwise targets[i] is uploaded.
 int GpuAStarPlanner::costStateEdges(int source, const std::vector<State>& targets, const std::vector<unsigned>& cfgBits,
@@ -176,89 +202,132 @@ int GpuAStarPlanner::costStateEdges(int source, const std::vector<State>& target
     std::vector<double> child(n * (size_t)kRibbonStride * 4);
     check(ppgpu_cost_edges_host(h, (int64_t)n, edges.data(), res.data(), child.data(), kRibbonStride), "ppgpu_cost_edges_host");
     m_Stats.EdgesCosted += n;
-    const Node src = m_Nodes[source];
     for (size_t i = 0; i < n; i++) {
-        const ppgpu_edge_result& r = res[i];
-        if (r.flags & PPGPU_F_THROWS) throw std::runtime_error("Edge cost evaluation failed: invalid time in sample for Dubins path");
-        if (r.flags & (PPGPU_F_RIBBON_OVF | PPGPU_F_DUBINS_ERR)) throw std::runtime_error("Edge cost evaluation exceeded a device capacity");
-        Node c;
-        c.parent = source;
-        c.state = State(r.end_x, r.end_y, r.end_heading, r.end_speed, r.end_time);
-        c.coverageAllowed = (cfgBits[i] & PPGPU_EDGE_COVERAGE) != 0;
-        c.infeasible = (r.flags & PPGPU_F_INFEASIBLE) != 0;
-        c.collisionPenalty = r.collision_penalty;
-        c.g = r.g;
-        c.h = r.h;
-        c.ribbons = src.ribbons;   // keeps heuristic, K, turning radius
-        c.ribbons.assign(child.data() + i * (size_t)kRibbonStride * 4, (int)((r.info >> 8) & 0xff), r.coverage_completed_time);
-        DubinsPath p;
-        p.qi[0] = src.state.x(); p.qi[1] = src.state.y(); p.qi[2] = src.state.yaw();
-        p.param[0] = r.param[0]; p.param[1] = r.param[1]; p.param[2] = r.param[2];
-        p.rho = c.coverageAllowed ? m_Config.coverageTurningRadius() : m_Config.turningRadius();
-        p.type = (DubinsPathType)(r.info & 0xff);
-        c.wrapper.fill(p, r.end_speed, src.state.time());
-        if (!c.infeasible && r.end_time < c.wrapper.getEndTime()) c.wrapper.updateEndTime(r.end_time);   // Edge.cpp:179
-        m_Nodes.push_back(std::move(c));
+        m_Nodes.push_back(makeChild(source, cfgBits[i], res[i], child.data() + i * (size_t)kRibbonStride * 4));
         pushVertexQueue((int)m_Nodes.size() - 1);
     }
     return (int)n;
 }
 
-void GpuAStarPlanner::expand(int source) {   // SamplingBasedPlanner::expand (:52-151)
+// SamplingBasedPlanner::expand (:52-151) for several open vertices in ONE device round trip: every vertex's edges are what
+// expand() would build for it alone (nearest ribbon endpoint at each speed and radius, then the k nearest samples per radius
+// at each speed), in that order; the children are kept aside, not pushed.
+void GpuAStarPlanner::expandBatch(const std::vector<int>& sources) {
     ppgpu_ctx* h = m_Ctx->handle();
+    const int M = (int)sources.size();
     const double speeds[2] = {m_Config.maxSpeed(), m_Config.maxSpeed() == m_Config.slowSpeed() ? -1 : m_Config.slowSpeed()};
     const double radii[2] = {m_Config.turningRadius(),
                              m_Config.coverageTurningRadius() == m_Config.turningRadius() ? -1 : m_Config.coverageTurningRadius()};
-    // this vertex becomes the device's open-vertex array (one entry)
+    // these vertices become the device's open-vertex array
     {
-        ppgpu_vertex v = makeVertex(m_Nodes[source]);
-        std::vector<double> rib;
-        ribbonsToArray(m_Nodes[source].ribbons, rib);
-        check(ppgpu_set_vertices(h, 1, &v, v.ribbon_count, rib.empty() ? nullptr : rib.data()), "ppgpu_set_vertices");
+        std::vector<ppgpu_vertex> verts((size_t)M);
+        std::vector<double> pool, rib;
+        for (int i = 0; i < M; i++) {
+            verts[i] = makeVertex(m_Nodes[sources[i]]);
+            verts[i].ribbon_offset = (int32_t)(pool.size() / 4);
+            ribbonsToArray(m_Nodes[sources[i]].ribbons, rib);
+            pool.insert(pool.end(), rib.begin(), rib.end());
+        }
+        check(ppgpu_set_vertices(h, M, verts.data(), (int32_t)(pool.size() / 4), pool.empty() ? nullptr : pool.data()), "ppgpu_set_vertices");
     }
-    std::vector<State> targets;
+    // nearest point to cover (:64-81): one explicit target per vertex that has one
+    std::vector<double> ex, ey, eh;
+    std::vector<long> extraOf((size_t)M, -1);
+    for (int i = 0; i < M; i++) {
+        const Node& n = m_Nodes[sources[i]];
+        if (n.ribbons.done()) continue;
+        State s = n.ribbons.getNearestEndpointAsState(n.state);
+        if (n.state.distanceTo(s) > m_Config.collisionCheckingIncrement()) {
+            extraOf[i] = (long)ex.size();
+            ex.push_back(s.x()); ey.push_back(s.y()); eh.push_back(s.heading());
+        }
+    }
+    int64_t first = m_NumSamples;
+    check(ppgpu_set_extra_targets(h, (int32_t)ex.size(), ex.data(), ey.data(), eh.data(), &first), "ppgpu_set_extra_targets");
+    // k best samples by Dubins length per (vertex, radius) (:85-133)
+    const int k = m_Config.branchingFactor();
+    std::vector<int32_t> idx;
+    if (m_NumSamples > 0 && k > 0) {
+        idx.resize((size_t)M * 2 * k);
+        std::vector<double> len((size_t)M * 2 * k);
+        check(ppgpu_select_nearest(h, 0, M, k, idx.data(), len.data()), "ppgpu_select_nearest");
+    }
+    std::vector<uint64_t> edges;
     std::vector<unsigned> cfg;
-    std::vector<long> sidx;
-    // nearest point to cover (:64-81)
-    if (!m_Nodes[source].ribbons.done()) {
-        State s = m_Nodes[source].ribbons.getNearestEndpointAsState(m_Nodes[source].state);
-        if (m_Nodes[source].state.distanceTo(s) > m_Config.collisionCheckingIncrement()) {
+    std::vector<int> owner;
+    for (int i = 0; i < M; i++) {
+        if (extraOf[i] >= 0) {
             for (int si = 0; si < 2; si++) {
                 if (speeds[si] <= 0) continue;
                 for (int ri = 0; ri < 2; ri++) {
                     if (radii[ri] <= 0) continue;
-                    bool coverageAllowed = radii[ri] == m_Config.coverageTurningRadius();
-                    targets.push_back(s);
-                    cfg.push_back((coverageAllowed ? PPGPU_EDGE_COVERAGE : 0u) | (si == 1 ? PPGPU_EDGE_SLOW : 0u));
-                    sidx.push_back(-1);
+                    const bool coverageAllowed = radii[ri] == m_Config.coverageTurningRadius();
+                    const unsigned c = (coverageAllowed ? PPGPU_EDGE_COVERAGE : 0u) | (si == 1 ? PPGPU_EDGE_SLOW : 0u);
+                    edges.push_back(ppgpu_edge_pack((uint32_t)i, (uint32_t)(first + extraOf[i]), c));
+                    cfg.push_back(c); owner.push_back(i);
+                }
+            }
+        }
+        // every winner at every speed (:134-149)
+        if (!idx.empty()) {
+            for (int ri = 0; ri < 2; ri++) {
+                if (radii[ri] <= 0) continue;
+                const bool coverageAllowed = radii[ri] == m_Config.coverageTurningRadius();
+                // slot 1 of the device result is always the coverage radius; with equal radii slot 0 IS the coverage radius
+                const int slot = (ri == 1) ? 1 : 0;
+                for (int j = 0; j < k; j++) {
+                    const int32_t s = idx[((size_t)i * 2 + slot) * k + j];
+                    if (s < 0) break;
+                    for (int si = 0; si < 2; si++) {
+                        if (speeds[si] <= 0) continue;
+                        const unsigned c = (coverageAllowed ? PPGPU_EDGE_COVERAGE : 0u) | (si == 1 ? PPGPU_EDGE_SLOW : 0u);
+                        edges.push_back(ppgpu_edge_pack((uint32_t)i, (uint32_t)s, c));
+                        cfg.push_back(c); owner.push_back(i);
+                    }
                 }
             }
         }
     }
-    // k best samples by Dubins length per radius (:85-133), then every winner at every speed (:134-149)
-    const int k = m_Config.branchingFactor();
-    if (m_NumSamples > 0 && k > 0) {
-        std::vector<int32_t> idx(2 * (size_t)k);
-        std::vector<double> len(2 * (size_t)k);
-        check(ppgpu_select_nearest(h, 0, 1, k, idx.data(), len.data()), "ppgpu_select_nearest");
-        for (int ri = 0; ri < 2; ri++) {
-            if (radii[ri] <= 0) continue;
-            bool coverageAllowed = radii[ri] == m_Config.coverageTurningRadius();
-            // slot 1 of the device result is always the coverage radius; with equal radii slot 0 IS the coverage radius
-            const int slot = (ri == 1) ? 1 : 0;
-            for (int j = 0; j < k; j++) {
-                int32_t s = idx[(size_t)slot * k + j];
-                if (s < 0) break;
-                for (int si = 0; si < 2; si++) {
-                    if (speeds[si] <= 0) continue;
-                    targets.emplace_back();
-                    cfg.push_back((coverageAllowed ? PPGPU_EDGE_COVERAGE : 0u) | (si == 1 ? PPGPU_EDGE_SLOW : 0u));
-                    sidx.push_back(s);
-                }
-            }
+    for (int i = 0; i < M; i++) m_Speculated[sources[i]];   // an entry even when a vertex has no edges at all
+    const size_t n = edges.size();
+    if (n == 0) return;
+    std::vector<ppgpu_edge_result> res(n);
+    std::vector<double> child(n * (size_t)kRibbonStride * 4);
+    check(ppgpu_cost_edges_host(h, (int64_t)n, edges.data(), res.data(), child.data(), kRibbonStride), "ppgpu_cost_edges_host");
+    m_Stats.EdgesCosted += n;
+    for (size_t e = 0; e < n; e++)
+        m_Speculated[sources[owner[e]]].push_back(makeChild(sources[owner[e]], cfg[e], res[e], child.data() + e * (size_t)kRibbonStride * 4));
+}
+
+// expand(source) as the search sees it.  The device answers for `source` and, speculatively, for the open vertices the
+// search is most likely to pop next (smallest f first), so that most later calls find their children already costed.  What
+// is pushed, and in which order, is exactly what expanding one vertex at a time would push: speculation only changes when
+// the arithmetic happens.  Nothing survives a change of the sample set (m_Speculated is cleared by addSamples).
+void GpuAStarPlanner::expand(int source) {
+    auto it = m_Speculated.find(source);
+    if (it == m_Speculated.end()) {
+        std::vector<int> batch{source};
+        const int want = m_Config.speculation();
+        if (want > 1 && !m_Queue.empty()) {
+            std::vector<int> cand;
+            for (int v : m_Queue)
+                if (!m_Speculated.count(v) && !goalCondition(m_Nodes[v])) cand.push_back(v);
+            const size_t take = std::min(cand.size(), (size_t)(want - 1));
+            std::partial_sort(cand.begin(), cand.begin() + take, cand.end(), [&](int a, int b) {
+                const double fa = m_Nodes[a].f(), fb = m_Nodes[b].f();
+                return fa < fb || (fa == fb && a < b);
+            });
+            batch.insert(batch.end(), cand.begin(), cand.begin() + take);
         }
+        expandBatch(batch);
+        it = m_Speculated.find(source);
     }
-    costStateEdges(source, targets, cfg, sidx);
+    std::vector<Node> children = std::move(it->second);
+    m_Speculated.erase(it);
+    for (Node& c : children) {
+        m_Nodes.push_back(std::move(c));
+        pushVertexQueue((int)m_Nodes.size() - 1);
+    }
     m_Stats.Expanded++;
 }
 
@@ -303,6 +372,7 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
     m_StartStateTime = start.time();
     m_Nodes.clear();
     m_Queue.clear();
+    m_Speculated.clear();
     m_NumSamples = 0;
     ppgpu_ctx* h = m_Ctx->handle();
     uploadWorld(start);

@@ -5,6 +5,9 @@
 // Scenario lines:  cfg <key> <value> | start x y heading speed time | ribbon x1 y1 x2 y2 | heuristic H K radius |
 //                  ribbon_width w | obstacle x y heading speed time width length | gaussian x y heading speed time [c00 c01 c10 c11] | map_file path | clock t0 dt |
 //                  time_remaining T | prev qi0 qi1 qi2 p0 p1 p2 rho type speed start end | repeat n
+#include <algorithm>
+#include <array>
+#include <chrono>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -30,6 +33,7 @@ int main(int argc, char** argv) {
     double t0 = 1000, dt = 1e-3, timeRemaining = 0.05;
     DubinsPlan prev;
     int repeat = 1;
+    bool realClock = false;
     uint32_t mmsi = 1;
     std::string line;
     while (std::getline(in, line)) {
@@ -48,6 +52,7 @@ int main(int argc, char** argv) {
             else if (name == "branching_factor") config.setBranchingFactor((int)v);
             else if (name == "initial_samples") config.setInitialSamples((int)v);
             else if (name == "use_brown_paths") config.setUseBrownPaths(v != 0);
+            else if (name == "speculation") config.setSpeculation((int)v);
             else { std::fprintf(stderr, "unknown cfg %s\n", name.c_str()); return 2; }
         } else if (k == "start") {
             double x, y, h, v, t; s >> x >> y >> h >> v >> t; start = State(x, y, h, v, t);
@@ -65,6 +70,7 @@ int main(int argc, char** argv) {
         } else if (k == "clock") { s >> t0 >> dt;
         } else if (k == "time_remaining") { s >> timeRemaining;
         } else if (k == "repeat") { s >> repeat;
+        } else if (k == "real_clock") { int v; s >> v; realClock = v != 0;   // now() = t0 + wall seconds since plan() began
         } else if (k == "prev") {
             DubinsPath p; double speed, st, en; int type;
             s >> p.qi[0] >> p.qi[1] >> p.qi[2] >> p.param[0] >> p.param[1] >> p.param[2] >> p.rho >> type >> speed >> st >> en;
@@ -81,17 +87,25 @@ int main(int argc, char** argv) {
     if (haveGauss) config.setObstaclesManager(gauss);
     try {
         Planner::Stats st;
+        std::vector<double> wall;
         for (int rep = 0; rep < repeat; rep++) {
             long calls = 0;
-            config.setNowFunction([&]() { return t0 + (double)(calls++) * dt; });
+            const auto w0 = std::chrono::steady_clock::now();
+            if (realClock)
+                config.setNowFunction([&]() { return t0 + std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count(); });
+            else
+                config.setNowFunction([&]() { return t0 + (double)(calls++) * dt; });
             GpuAStarPlanner planner;   // a fresh planner every cycle, like Executive::planLoop (executive.cpp:85-90)
             st = planner.plan(rm, start, config, prev, timeRemaining);
+            wall.push_back(1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count());
         }
+        std::sort(wall.begin(), wall.end());
+        std::fprintf(stderr, "plan() wall ms: min %.3f median %.3f max %.3f over %d calls\n", wall.front(), wall[wall.size() / 2], wall.back(), repeat);
         std::printf("{\"samples\": %lu, \"generated\": %lu, \"expanded\": %lu, \"iterations\": %lu, \"plan_f\": %.17g, "
                     "\"plan_collision_penalty\": %.17g, \"plan_time_penalty\": %.17g, \"plan_h\": %.17g, \"plan_depth\": %lu, "
-                    "\"first_goal_iteration\": %ld, \"edges_costed\": %lu, \"plan\": [",
+                    "\"first_goal_iteration\": %ld, \"edges_costed\": %lu, \"wall_ms_median\": %.4f, \"wall_ms_max\": %.4f, \"plan\": [",
                     st.Samples, st.Generated, st.Expanded, st.Iterations, st.PlanFValue, st.PlanCollisionPenalty, st.PlanTimePenalty,
-                    st.PlanHValue, st.PlanDepth, st.FirstGoalIteration, st.EdgesCosted);
+                    st.PlanHValue, st.PlanDepth, st.FirstGoalIteration, st.EdgesCosted, wall[wall.size() / 2], wall.back());
         bool first = true;
         for (const auto& w : st.Plan.get()) {
             const DubinsPath& p = w.unwrap();

@@ -24,9 +24,11 @@ def _write_map(grid, res, path):
             f.write("".join("#" if c else "." for c in row) + "\n")
 
 
-def _scenario(w, path, map_path, t0, dt, budget_calls, initial_samples, prev=None, start=None, gauss=None):
+def _scenario(w, path, map_path, t0, dt, budget_calls, initial_samples, prev=None, start=None, gauss=None, speculation=None):
     c = w.cfg
     lines = []
+    if speculation is not None:
+        lines.append(f"cfg speculation {speculation}")
     for k in ("max_speed", "slow_speed", "turning_radius", "coverage_turning_radius", "time_horizon", "time_minimum",
               "collision_checking_increment", "branching_factor"):
         lines.append(f"cfg {k} {getattr(c, k)!r}")
@@ -163,3 +165,26 @@ def test_host_planner_with_gaussian_obstacles():
         assert rc == 0
         print({k: host[k] for k in host if k != "plan"})
         _compare(host, st, plan)
+
+
+def test_speculative_expansion_changes_nothing_but_the_round_trips():
+    """GpuAStarPlanner costs the children of the most promising open vertices ahead of their expansion (one device round
+    trip for up to `speculation` vertices).  What the search pushes, pops and returns must not depend on it."""
+    from path_planner_amd import workloads
+    w = workloads.by_name("cfg3")
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        mp = os.path.join(d, "grid.map")
+        _write_map(w.grid, w.res, mp)
+        for spec in (1, 4, 32):
+            sc = os.path.join(d, f"s{spec}.txt")
+            _scenario(w, sc, mp, 1000.0, 1e-3, 60, 512, speculation=spec)
+            outs.append(_run_cli(sc))
+    base = outs[0]
+    for o in outs[1:]:
+        for k in base:
+            if k in ("edges_costed", "wall_ms_median", "wall_ms_max"):
+                continue
+            assert o[k] == base[k], (k, o[k], base[k])
+        assert o["edges_costed"] >= base["edges_costed"]
+    assert base["expanded"] >= 10
