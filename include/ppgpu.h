@@ -103,8 +103,9 @@ typedef struct ppgpu_vertex {
 #define PPGPU_F_THROWS       0x02u /* the reference would throw out of computeTrueCost here
                                       (DubinsWrapper::sample on an uninitialised / out-of-range
                                       wrapper, Edge.cpp:178 / DubinsWrapper.cpp:29-35)            */
-#define PPGPU_F_RIBBON_OVF   0x04u /* child ribbon list exceeded ribbon_stride (or 64, or 8 for the TSP
-                                      heuristics): list truncated, h = 0 and f = g in the record      */
+#define PPGPU_F_RIBBON_OVF   0x04u /* child ribbon list exceeded ribbon_stride or 64, or the heuristic's enumeration limit
+                                      * (8 ribbons for the brute-force TSP heuristics; 12 for TspPointRobotNoSplitKRibbons
+                                      * while its tree has fewer than 2^21 prefixes): h = 0, f = g, never silent */
 #define PPGPU_F_DUBINS_ERR   0x08u /* dubins_path_sample failed twice (DubinsWrapper.cpp:43-45)    */
 #define PPGPU_F_GOAL         0x10u /* SamplingBasedPlanner::goalCondition(child)                   */
 #define PPGPU_F_DONE         0x20u /* child->done()                                                */

@@ -752,7 +752,22 @@ Vertex connectWrapper(const Vertex& start, int startIndex, const DubinsWrapper& 
 }
 
 double computeApproxToGo(Vertex& v, const Config& cfg) {  // Vertex.cpp:49-64 (passes heading as "yaw")
-    if (cfg.tspRibbonLimit > 0 && v.ribbons.heuristic != MaxDistance && (int)v.ribbons.ribbons.size() > cfg.tspRibbonLimit) {
+    // Checker-only: mirror of the device's capacity rule (pp_device.h: pp_tsp_big_ok).  Beyond tspRibbonLimit (8) ribbons
+    // only the K variant of the point-robot heuristic is enumerated, up to 12 ribbons and 2^21 lane-parallel prefixes.
+    auto deviceEnumerates = [&](int n) {
+        if (n <= cfg.tspRibbonLimit) return true;
+        if (v.ribbons.heuristic != TspPointRobotNoSplitKRibbons || n > 12) return false;
+        const int K = v.ribbons.K;
+        if (K <= 0) return true;
+        unsigned long long NP = 1;
+        for (int l = 0; l < n; l++) {
+            int rem = n - l;
+            if (NP >= 64ull && l >= n - 2) break;
+            NP *= (unsigned long long)(2 * (rem < K ? rem : K));
+        }
+        return NP < (1ull << 21);
+    };
+    if (cfg.tspRibbonLimit > 0 && v.ribbons.heuristic != MaxDistance && !deviceEnumerates((int)v.ribbons.ribbons.size())) {
         v.heuristicSkipped = true;
         v.approxToGo = 0;
         return 0;

@@ -4,6 +4,7 @@
 // x86-64 (no FMA), so every product and sum below rounds separately and in the same order
 // as the reference expression it cites.  Wavefront = 64 lanes, hard-coded.
 #pragma once
+#include "../../include/ppgpu.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -752,17 +753,50 @@ __device__ inline int pp_quiet_run(const PPRibbon& r, int n, double w, double x,
 }
 
 // ----------------------------------------------------------------------------- heuristics
-#define PP_TSP_MAX 8      // device limit on ribbons for the brute-force TSP heuristics
-#define PP_H_PTS (2 * PP_TSP_MAX + 1)          // query point + both endpoints of every ribbon
-#define PP_H_LDS (PP_WAVE * 2 + PP_H_PTS * (PP_H_PTS - 1) + PP_H_PTS * PP_TSP_MAX)   // doubles of LDS per wave: points (up to 64 ribbons for
-                                                              // MaxDistance would need 129 points: they use [0, 129*2))
+// Brute-force TSP heuristics: table sizes for at most MAXN ribbons.  MAXN = 8 (remaining ribbons packed 4 bits each in 32
+// bits) is the common kernel; MAXN = 12 (64 bits) serves the K variant on longer lists (see pp_tsp_big_ok).
+#include <type_traits>
+#define PP_TSP_MAX 8
+#define PP_TSP_MAX_BIG 12
+template <int MAXN>
+struct PPTsp {
+    static constexpr int MAX = MAXN;
+    static constexpr int PTS = 2 * MAXN + 1;                                   // query point + both endpoints of every ribbon
+    static constexpr int LDS = PP_WAVE * 2 + PTS * (PTS - 1) + PTS * MAXN;     // doubles of LDS per wave: points (MaxDistance uses up
+                                                                              // to 129 of them: [0, 258)), distance table, KM table
+    typedef typename std::conditional<(MAXN <= 8), unsigned, unsigned long long>::type Ord;
+    static __device__ __forceinline__ Ord identity() { return (Ord)0xBA9876543210ull; }   // ribbon i at position i
+};
 
 // Every distance the heuristics need is between two of the points {query point, ribbon endpoints}; the TSP enumeration
 // only ever stands on one of those points.  So all sqrt() are taken once, lane-parallel, into a table
 //     T[p][q-1] = sqrt((xp - xq)^2 + (yp - yq)^2),   p in [0, 2n], q in [1, 2n]   (point 0 = query, 1+2i / 2+2i = start / end of ribbon i)
 // (the same expression as RibbonManager::distance, RibbonManager.h:285-287, and Ribbon::length(): (a-b)^2 == (b-a)^2 exactly),
 // and the enumeration itself is lookups, adds and compares.
-__device__ __forceinline__ double pp_h_T(const double* T, int p, int q) { return T[p * (PP_H_PTS - 1) + (q - 1)]; }
+template <int MAXN>
+__device__ __forceinline__ double pp_h_T(const double* T, int p, int q) { return T[p * (PPTsp<MAXN>::PTS - 1) + (q - 1)]; }
+
+// Number of lane-parallel prefixes pp_h_tsp_point uses for n ribbons and branching K (and how many levels they span)
+__device__ __forceinline__ unsigned long long pp_tsp_prefixes(int n, int K, int& Ls) {
+    unsigned long long NP = 1;
+    Ls = 0;
+    for (int l = 0; l < n; l++) {
+        const int rem = n - l;
+        if (NP >= 64ull && l >= n - 2) break;
+        NP *= (unsigned long long)(2 * (rem < K ? rem : K));
+        Ls = l + 1;
+    }
+    return NP;
+}
+// Lists of 9..12 ribbons are enumerated (by the MAXN = 12 kernel) only for the K variant of the point-robot heuristic and
+// only while the prefix count stays below 2^21 (K = 2: up to 12 ribbons, K = 3: up to 10); everything else beyond 8 ribbons
+// is reported as PPGPU_F_RIBBON_OVF.  (The All variants would need n! 2^n leaves: 1.9e8 at n = 9.)
+__device__ __forceinline__ bool pp_tsp_big_ok(int heuristic, int K, int n) {
+    if (heuristic != PPGPU_H_TSP_POINT_K || n <= PP_TSP_MAX || n > PP_TSP_MAX_BIG) return false;
+    if (K <= 0) return true;
+    int Ls;
+    return pp_tsp_prefixes(n, K, Ls) < (1ull << 21);
+}
 
 // RibbonManager::maxDistance (RibbonManager.cpp:234-248); pts = x,y of the query point then of every ribbon's start, end
 __device__ inline double pp_h_max_distance(const double* pts, int n, double w) {
@@ -791,18 +825,20 @@ __device__ inline double pp_h_max_distance(const double* pts, int n, double w) {
 // over the lanes — every lane walks ITS prefix with the same control flow, only the digits differ —
 // and the remaining (at most two) levels are enumerated by wave-uniform loops, so that no lane ever
 // waits for another lane's branch.  Each tree node is sorted once.
-struct PPTspNode { double sf; unsigned ord; int pt; };   // accumulated distance, remaining ribbons (4 bits each), current point
+template <int MAXN>
+struct PPTspNode { double sf; typename PPTsp<MAXN>::Ord ord; int pt; };   // accumulated distance, remaining ribbons (4 bits each), current point
 
 // The order list::sort(comp = min1 > min2) leaves: element i goes to position
 //   #{ j : key_j > key_i }  +  #{ j before i : key_j == key_i }          (stable, descending)
 // computed as ranks, so nothing is swapped.  key_i = distance from point `pt` to the nearer endpoint of ribbon i,
 // read from the table KM[pt][i] = fmin(T[pt][start_i], T[pt][end_i]) built next to T.
-template <int REM>
-__device__ __forceinline__ unsigned pp_tsp_sort_n(const double* KM, unsigned ord, int pt) {
+template <int MAXN, int REM>
+__device__ __forceinline__ typename PPTsp<MAXN>::Ord pp_tsp_sort_n(const double* KM, typename PPTsp<MAXN>::Ord ord, int pt) {
+    typedef typename PPTsp<MAXN>::Ord Ord;
     double key[REM];
 #pragma unroll
-    for (int i = 0; i < REM; i++) key[i] = KM[pt * PP_TSP_MAX + (int)((ord >> (4 * i)) & 0xfu)];
-    unsigned o = 0;
+    for (int i = 0; i < REM; i++) key[i] = KM[pt * MAXN + (int)((ord >> (4 * i)) & 0xfu)];
+    Ord o = 0;
 #pragma unroll
     for (int i = 0; i < REM; i++) {
         int rank = 0;
@@ -810,41 +846,65 @@ __device__ __forceinline__ unsigned pp_tsp_sort_n(const double* KM, unsigned ord
         for (int j = 0; j < REM; j++) {
             if (j != i) rank += ((key[j] > key[i]) | ((key[j] == key[i]) & (j < i))) ? 1 : 0;
         }
-        o |= ((ord >> (4 * i)) & 0xfu) << (4 * rank);
+        o |= ((ord >> (4 * i)) & (Ord)0xfu) << (4 * rank);
+    }
+    return o;
+}
+// the same ranks with the keys re-read from the table: only for the rare lists of more than 8 remaining ribbons
+template <int MAXN>
+__device__ __noinline__ typename PPTsp<MAXN>::Ord pp_tsp_sort_loop(const double* KM, typename PPTsp<MAXN>::Ord ord, int rem, int pt) {
+    typedef typename PPTsp<MAXN>::Ord Ord;
+    Ord o = 0;
+    for (int i = 0; i < rem; i++) {
+        const double ki = KM[pt * MAXN + (int)((ord >> (4 * i)) & 0xfu)];
+        int rank = 0;
+        for (int j = 0; j < rem; j++) {
+            const double kj = KM[pt * MAXN + (int)((ord >> (4 * j)) & 0xfu)];
+            if (j != i) rank += ((kj > ki) | ((kj == ki) & (j < i))) ? 1 : 0;
+        }
+        o |= ((ord >> (4 * i)) & (Ord)0xfu) << (4 * rank);
     }
     return o;
 }
 // `rem` is wave-uniform: one branch picks the network of exactly that size (rem * (rem - 1) comparisons instead of 56)
-__device__ __forceinline__ unsigned pp_tsp_sort(const double* KM, unsigned ord, int rem, int pt) {
+template <int MAXN>
+__device__ __forceinline__ typename PPTsp<MAXN>::Ord pp_tsp_sort(const double* KM, typename PPTsp<MAXN>::Ord ord, int rem, int pt) {
     switch (rem) {
-        case 2: return pp_tsp_sort_n<2>(KM, ord, pt);
-        case 3: return pp_tsp_sort_n<3>(KM, ord, pt);
-        case 4: return pp_tsp_sort_n<4>(KM, ord, pt);
-        case 5: return pp_tsp_sort_n<5>(KM, ord, pt);
-        case 6: return pp_tsp_sort_n<6>(KM, ord, pt);
-        case 7: return pp_tsp_sort_n<7>(KM, ord, pt);
-        case 8: return pp_tsp_sort_n<8>(KM, ord, pt);
-        default: return ord;         // 0 or 1 left: nothing to order
+        case 0: case 1: return ord;  // nothing to order
+        case 2: return pp_tsp_sort_n<MAXN, 2>(KM, ord, pt);
+        case 3: return pp_tsp_sort_n<MAXN, 3>(KM, ord, pt);
+        case 4: return pp_tsp_sort_n<MAXN, 4>(KM, ord, pt);
+        case 5: return pp_tsp_sort_n<MAXN, 5>(KM, ord, pt);
+        case 6: return pp_tsp_sort_n<MAXN, 6>(KM, ord, pt);
+        case 7: return pp_tsp_sort_n<MAXN, 7>(KM, ord, pt);
+        case 8: return pp_tsp_sort_n<MAXN, 8>(KM, ord, pt);
+        default: break;
     }
+    if constexpr (MAXN > 8) return pp_tsp_sort_loop<MAXN>(KM, ord, rem, pt);
+    return ord;
 }
 
 // take branch `digit` (ribbon position digit>>1 of `srt`, direction digit&1) from node `a`
 // LEN == nullptr: T holds point-to-point distances and a ribbon's length is T[start][end]; otherwise T holds the Dubins
 // distances between oriented endpoints (RibbonManager::dubinsDistance) and LEN[i] = Ribbon::length() of ribbon i.
-__device__ __forceinline__ PPTspNode pp_tsp_child(const double* T, const double* LEN, const PPTspNode& a, unsigned srt, int digit, double twoW) {
+template <int MAXN>
+__device__ __forceinline__ PPTspNode<MAXN> pp_tsp_child(const double* T, const double* LEN, const PPTspNode<MAXN>& a,
+                                                        typename PPTsp<MAXN>::Ord srt, int digit, double twoW) {
+    typedef typename PPTsp<MAXN>::Ord Ord;
     const int c = digit >> 1, dir = digit & 1;
     const int rid = (int)((srt >> (4 * c)) & 0xfu);
     const int ps = 1 + 2 * rid, pe = 2 + 2 * rid;
-    const double len = LEN ? LEN[rid] : pp_h_T(T, ps, pe);              // Ribbon::length()
-    const double dd = pp_h_T(T, a.pt, dir == 0 ? ps : pe);              // distance(point, r.start()) / (point, r.end())
-    PPTspNode b;
+    const double len = LEN ? LEN[rid] : pp_h_T<MAXN>(T, ps, pe);        // Ribbon::length()
+    const double dd = pp_h_T<MAXN>(T, a.pt, dir == 0 ? ps : pe);        // distance(point, r.start()) / (point, r.end())
+    PPTspNode<MAXN> b;
     b.sf = fmax(a.sf + len - twoW + dd, 0);
     b.pt = dir == 0 ? pe : ps;
-    const unsigned lowmask = (c == 0) ? 0u : ((1u << (4 * c)) - 1u);
+    const Ord lowmask = (c == 0) ? (Ord)0 : ((((Ord)1) << (4 * c)) - (Ord)1);
     b.ord = (srt & lowmask) | ((srt >> 4) & ~lowmask);
     return b;
 }
 
+template <int MAXN>
 __device__ inline double pp_h_tsp_point(const double* T, const double* KM, int n, double w, int K, bool sortK, const double* LEN = nullptr) {
     if (n == 0) return 0;
     if (K <= 0) return PP_DBL_MAX;   // the reference's loop body never runs and it returns DBL_MAX
@@ -853,13 +913,7 @@ __device__ inline double pp_h_tsp_point(const double* T, const double* KM, int n
     // prefix depth Ls: deep enough for >= 64 prefixes when the tree has them, and never leaving more than
     // two suffix levels (those are enumerated by wave-uniform loops below).  All of this is wave-uniform.
     int Ls = 0;
-    unsigned NP = 1;
-    for (int l = 0; l < n; l++) {
-        const int rem = n - l;
-        if (NP >= 64u && l >= n - 2) break;
-        NP *= (unsigned)(2 * (rem < K ? rem : K));
-        Ls = l + 1;
-    }
+    const unsigned NP = (unsigned)pp_tsp_prefixes(n, K, Ls);     // < 2^21 by the callers' limits
     const int nsuf = n - Ls;         // 0, 1 or 2
     double best = PP_DBL_MAX;
     for (unsigned pbase = 0; pbase < NP; pbase += 64u) {
@@ -867,16 +921,16 @@ __device__ inline double pp_h_tsp_point(const double* T, const double* KM, int n
         const bool act = pid < NP;
         unsigned rest = act ? pid : 0u;
         unsigned stride = NP;
-        PPTspNode a;
-        a.pt = 0; a.sf = 0; a.ord = 0x76543210u;
+        PPTspNode<MAXN> a;
+        a.pt = 0; a.sf = 0; a.ord = PPTsp<MAXN>::identity();
         for (int l = 0; l < Ls; l++) {                      // this lane's prefix, level 0 = most significant digit
             const int rem = n - l;
             const unsigned b = (unsigned)(2 * (rem < K ? rem : K));
             stride = pp_udiv_small(stride, b);              // exact: NP is the product of the b's
             const unsigned dg = pp_udiv_small(rest, stride);
             rest -= dg * stride;
-            const unsigned srt = sortK ? pp_tsp_sort(KM, a.ord, rem, a.pt) : a.ord;
-            a = pp_tsp_child(T, LEN, a, srt, (int)dg, twoW);
+            const typename PPTsp<MAXN>::Ord srt = sortK ? pp_tsp_sort<MAXN>(KM, a.ord, rem, a.pt) : a.ord;
+            a = pp_tsp_child<MAXN>(T, LEN, a, srt, (int)dg, twoW);
         }
         double v = PP_DBL_MAX;
         if (nsuf == 0) {
@@ -884,17 +938,17 @@ __device__ inline double pp_h_tsp_point(const double* T, const double* KM, int n
         } else {
             const int remA = n - Ls;
             const int bA = 2 * (remA < K ? remA : K);
-            const unsigned srtA = sortK ? pp_tsp_sort(KM, a.ord, remA, a.pt) : a.ord;
+            const typename PPTsp<MAXN>::Ord srtA = sortK ? pp_tsp_sort<MAXN>(KM, a.ord, remA, a.pt) : a.ord;
             for (int uA = 0; uA < bA; uA++) {
-                const PPTspNode bnode = pp_tsp_child(T, LEN, a, srtA, uA, twoW);
+                const PPTspNode<MAXN> bnode = pp_tsp_child<MAXN>(T, LEN, a, srtA, uA, twoW);
                 if (nsuf == 1) {
                     v = fmin(v, bnode.sf);
                 } else {
                     const int remB = remA - 1;
                     const int bB = 2 * (remB < K ? remB : K);
-                    const unsigned srtB = sortK ? pp_tsp_sort(KM, bnode.ord, remB, bnode.pt) : bnode.ord;
+                    const typename PPTsp<MAXN>::Ord srtB = sortK ? pp_tsp_sort<MAXN>(KM, bnode.ord, remB, bnode.pt) : bnode.ord;
                     for (int uB = 0; uB < bB; uB++) {
-                        const PPTspNode leaf = pp_tsp_child(T, LEN, bnode, srtB, uB, twoW);
+                        const PPTspNode<MAXN> leaf = pp_tsp_child<MAXN>(T, LEN, bnode, srtB, uB, twoW);
                         v = fmin(v, leaf.sf);
                     }
                 }

@@ -1,7 +1,7 @@
 // pp_kernels.h — the gfx950 kernels of the hot path.  Included once by ppgpu.hip.
 #pragma once
-#include "pp_device.h"
 #include "../../include/ppgpu.h"
+#include "pp_device.h"
 
 // Everything a costing launch needs, passed by value (kernarg segment, scalar loads).
 struct PPParams {
@@ -681,22 +681,27 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep_ga
 #endif
 // DUBINS = the two Dubins-TSP heuristics (RibbonManager.cpp:97-140): the same enumeration over a table of Dubins
 // distances between oriented ribbon endpoints.  A separate instantiation so that the six-word solve does not set the
-// register budget of the common kernel.
-template <bool DUBINS>
+// register budget of the common kernel.  MAXN = 8: every edge; MAXN = 12: a second pass that only touches the edges whose
+// 9..12 child ribbons the first pass left for it (pp_tsp_big_ok).
+template <bool DUBINS, int MAXN>
 __device__ __forceinline__ void pp_heuristic_edge(const PPParams& p, const long long e, double* lds_wave) {
+    typedef PPTsp<MAXN> TS;
+    const bool bigPass = MAXN > PP_TSP_MAX;
     const int lane = pp_lane();
     double* pts = lds_wave;                      // x,y of the query point, then start/end of every child ribbon
-    double* T = lds_wave + PP_WAVE * 2;          // distance table of the TSP heuristics (<= 8 ribbons)
-    double* KM = T + PP_H_PTS * (PP_H_PTS - 1);  // KM[p][i] = distance from point p to the nearer endpoint of ribbon i
+    double* T = lds_wave + PP_WAVE * 2;          // distance table of the TSP heuristics
+    double* KM = T + TS::PTS * (TS::PTS - 1);    // KM[p][i] = distance from point p to the nearer endpoint of ribbon i
     ppgpu_edge_result* rec = p.out + e;
     unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)rec->flags);
     if (flags & PPGPU_F_THROWS) return;
     int nrib = (int)((__builtin_amdgcn_readfirstlane((int)rec->info) >> 8) & 0xff);
+    const bool tsp = p.heuristic != PPGPU_H_MAX_DISTANCE;
+    if (bigPass && !(tsp && nrib <= p.stride && pp_tsp_big_ok(p.heuristic, p.tsp_k, nrib))) return;
     const double endX = rec->end_x, endY = rec->end_y, g = rec->g;
     double hdist = 0;
     if (nrib > 0 && nrib <= p.stride) {          // a truncated list (already flagged) carries no heuristic
-        const bool tsp = p.heuristic != PPGPU_H_MAX_DISTANCE;
-        if (tsp && nrib > PP_TSP_MAX) {
+        if (tsp && nrib > MAXN) {
+            if (pp_tsp_big_ok(p.heuristic, p.tsp_k, nrib)) return;            // the MAXN = 12 pass fills it in
             flags |= PPGPU_F_RIBBON_OVF;
         } else if (!tsp && nrib > 31) {
             // MaxDistance over a long list: straight from global memory, no table
@@ -725,21 +730,21 @@ __device__ __forceinline__ void pp_heuristic_edge(const PPParams& p, const long 
             } else if (!DUBINS) {
                 for (int idx = lane; idx < npts * ncol; idx += PP_WAVE) {      // all distances, once
                     const int pp = (int)pp_udiv_small((unsigned)idx, (unsigned)ncol), qq = 1 + (idx - pp * ncol);
-                    T[pp * (PP_H_PTS - 1) + (qq - 1)] = pp_dist(pts[2 * pp], pts[2 * pp + 1], pts[2 * qq], pts[2 * qq + 1]);
+                    T[pp * (TS::PTS - 1) + (qq - 1)] = pp_dist(pts[2 * pp], pts[2 * pp + 1], pts[2 * qq], pts[2 * qq + 1]);
                 }
                 pp_wave_lds_fence();
                 for (int idx = lane; idx < npts * nrib; idx += PP_WAVE) {
                     const int pp = (int)pp_udiv_small((unsigned)idx, (unsigned)nrib), ri = idx - pp * nrib;
-                    KM[pp * PP_TSP_MAX + ri] = fmin(pp_h_T(T, pp, 1 + 2 * ri), pp_h_T(T, pp, 2 + 2 * ri));
+                    KM[pp * MAXN + ri] = fmin(pp_h_T<MAXN>(T, pp, 1 + 2 * ri), pp_h_T<MAXN>(T, pp, 2 + 2 * ri));
                 }
                 pp_wave_lds_fence();
-                if (p.heuristic == PPGPU_H_TSP_POINT_ALL) hdist = pp_h_tsp_point(T, KM, nrib, p.ribw, PP_TSP_MAX, false);
-                else hdist = pp_h_tsp_point(T, KM, nrib, p.ribw, p.tsp_k, true);
+                if (p.heuristic == PPGPU_H_TSP_POINT_ALL) hdist = pp_h_tsp_point<MAXN>(T, KM, nrib, p.ribw, MAXN, false);
+                else hdist = pp_h_tsp_point<MAXN>(T, KM, nrib, p.ribw, p.tsp_k, true);
             } else {
                 // Oriented endpoints (Ribbon::startAsState / endAsState, Ribbon.cpp:60-70: at one end, heading towards the
                 // other); the query pose passes the child's HEADING where the callee says yaw (Vertex.cpp:51) — kept.
                 double* YAW = KM;                        // yaw of point q (q >= 1), then the ribbon lengths
-                double* LEN = KM + PP_H_PTS;
+                double* LEN = KM + TS::PTS;
                 if (lane < nrib) {
                     const double sx = pts[2 * (1 + 2 * lane)], sy = pts[2 * (1 + 2 * lane) + 1];
                     const double ex = pts[2 * (2 + 2 * lane)], ey = pts[2 * (2 + 2 * lane) + 1];
@@ -753,13 +758,13 @@ __device__ __forceinline__ void pp_heuristic_edge(const PPParams& p, const long 
                     const int pp = (int)pp_udiv_small((unsigned)idx, (unsigned)ncol), qq = 1 + (idx - pp * ncol);
                     PPDubins d;
                     pp_dubins_shortest(pts[2 * pp], pts[2 * pp + 1], YAW[pp], pts[2 * qq], pts[2 * qq + 1], YAW[qq], p.h_rho, d);
-                    T[pp * (PP_H_PTS - 1) + (qq - 1)] = pp_dubins_length(d, p.h_rho);
+                    T[pp * (TS::PTS - 1) + (qq - 1)] = pp_dubins_length(d, p.h_rho);
                 }
                 pp_wave_lds_fence();
                 // K variant: its comparator compares r1 with r1 (:121-122), so the sort changes nothing, and its counter is
                 // never incremented (:128), so every ribbon is branched: the All enumeration, unless K <= 0 (nothing runs)
-                const int K = (p.heuristic == PPGPU_H_TSP_DUBINS_K && p.tsp_k <= 0) ? 0 : PP_TSP_MAX;
-                hdist = pp_h_tsp_point(T, KM, nrib, p.ribw, K, false, LEN);
+                const int K = (p.heuristic == PPGPU_H_TSP_DUBINS_K && p.tsp_k <= 0) ? 0 : MAXN;
+                hdist = pp_h_tsp_point<MAXN>(T, KM, nrib, p.ribw, K, false, LEN);
             }
         }
     }
@@ -767,16 +772,23 @@ __device__ __forceinline__ void pp_heuristic_edge(const PPParams& p, const long 
     if (lane == 0) { rec->h = h; rec->f = g + h; rec->flags = flags; }
 }
 __global__ __launch_bounds__(PP_WPB * 64, PP_H_MIN_WAVES) void pp_k_heuristic(PPParams p) {
-    __shared__ double lds_all[PP_WPB][PP_H_LDS];
+    __shared__ double lds_all[PP_WPB][PPTsp<PP_TSP_MAX>::LDS];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long e = (long long)blockIdx.x * PP_WPB + wave;
-    if (e < p.n_edges) pp_heuristic_edge<false>(p, e, lds_all[wave]);
+    if (e < p.n_edges) pp_heuristic_edge<false, PP_TSP_MAX>(p, e, lds_all[wave]);
 }
 __global__ __launch_bounds__(PP_WPB * 64) void pp_k_heuristic_dubins(PPParams p) {
-    __shared__ double lds_all[PP_WPB][PP_H_LDS];
+    __shared__ double lds_all[PP_WPB][PPTsp<PP_TSP_MAX>::LDS];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long e = (long long)blockIdx.x * PP_WPB + wave;
-    if (e < p.n_edges) pp_heuristic_edge<true>(p, e, lds_all[wave]);
+    if (e < p.n_edges) pp_heuristic_edge<true, PP_TSP_MAX>(p, e, lds_all[wave]);
+}
+// TspPointRobotNoSplitKRibbons on child lists of 9..12 ribbons (rare: a vertex whose ribbons were split many times)
+__global__ __launch_bounds__(PP_WPB * 64) void pp_k_heuristic_big(PPParams p) {
+    __shared__ double lds_all[PP_WPB][PPTsp<PP_TSP_MAX_BIG>::LDS];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long e = (long long)blockIdx.x * PP_WPB + wave;
+    if (e < p.n_edges) pp_heuristic_edge<false, PP_TSP_MAX_BIG>(p, e, lds_all[wave]);
 }
 
 // ------------------------------------------------------------------------------------------

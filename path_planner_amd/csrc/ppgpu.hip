@@ -645,6 +645,10 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         hipLaunchKernelGGL(pp_k_heuristic_dubins, dim3((unsigned)((total + PP_WPB - 1) / PP_WPB)), dim3(PP_WPB * 64), 0, c->stream, p);
     else
         hipLaunchKernelGGL(pp_k_heuristic, dim3((unsigned)((total + PP_WPB - 1) / PP_WPB)), dim3(PP_WPB * 64), 0, c->stream, p);
+    // child lists of 9..12 ribbons under the K variant: a second pass that touches only those edges (the others cost it one
+    // 8-byte read each)
+    if (p.heuristic == PPGPU_H_TSP_POINT_K)
+        hipLaunchKernelGGL(pp_k_heuristic_big, dim3((unsigned)((total + PP_WPB - 1) / PP_WPB)), dim3(PP_WPB * 64), 0, c->stream, p);
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], c->stream)); c->ev_valid = true; }
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;

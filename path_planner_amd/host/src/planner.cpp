@@ -154,7 +154,9 @@ void GpuAStarPlanner::addSamples(long n) {   // SamplingBasedPlanner::addSamples
 // The child Node of one costed edge (what Vertex::connect + Edge::computeTrueCost + Vertex::computeApproxToGo leave behind)
 GpuAStarPlanner::Node GpuAStarPlanner::makeChild(int source, unsigned cfgBits, const ppgpu_edge_result& r, const double* childRibbons) {
     if (r.flags & PPGPU_F_THROWS) throw std::runtime_error("Edge cost evaluation failed: invalid time in sample for Dubins path");
-    if (r.flags & (PPGPU_F_RIBBON_OVF | PPGPU_F_DUBINS_ERR)) throw std::runtime_error("Edge cost evaluation exceeded a device capacity");
+    if (r.flags & (PPGPU_F_RIBBON_OVF | PPGPU_F_DUBINS_ERR))
+        throw std::runtime_error("Edge cost evaluation exceeded a device capacity (flags " + std::to_string(r.flags) + ", child ribbons " +
+                                 std::to_string((r.info >> 8) & 0xff) + ", parent ribbons " + std::to_string(m_Nodes[source].ribbons.get().size()) + ")");
     const Node& src = m_Nodes[source];
     Node c;
     c.parent = source;

@@ -34,6 +34,8 @@ int main(int argc, char** argv) {
     DubinsPlan prev;
     int repeat = 1;
     bool realClock = false;
+    int replans = 0;
+    double replanStep = 0.1;
     uint32_t mmsi = 1;
     std::string line;
     while (std::getline(in, line)) {
@@ -70,6 +72,7 @@ int main(int argc, char** argv) {
         } else if (k == "clock") { s >> t0 >> dt;
         } else if (k == "time_remaining") { s >> timeRemaining;
         } else if (k == "repeat") { s >> repeat;
+        } else if (k == "replan") { s >> replans >> replanStep;   // N consecutive cycles, start moved replanStep seconds along the plan
         } else if (k == "real_clock") { int v; s >> v; realClock = v != 0;   // now() = t0 + wall seconds since plan() began
         } else if (k == "prev") {
             DubinsPath p; double speed, st, en; int type;
@@ -88,6 +91,35 @@ int main(int argc, char** argv) {
     try {
         Planner::Stats st;
         std::vector<double> wall;
+        if (replans > 0) {
+            // the 10 Hz loop of Executive::planLoop (executive.cpp:85-305) without ROS: plan, move the start replanStep seconds
+            // along the returned plan, hand the plan back as previousPlan, repeat.  Real clock, fixed budget per cycle.
+            double tNow = t0;
+            State cur = start;
+            unsigned long iters = 0, expanded = 0, failures = 0, samples = 0;
+            for (int cyc = 0; cyc < replans; cyc++) {
+                const auto w0 = std::chrono::steady_clock::now();
+                config.setNowFunction([&]() { return tNow + std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count(); });
+                GpuAStarPlanner planner;
+                st = planner.plan(rm, cur, config, prev, timeRemaining);
+                wall.push_back(1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count());
+                iters += st.Iterations; expanded += st.Expanded; samples += st.Samples;
+                tNow += replanStep;
+                if (st.Plan.empty()) { failures++; cur.time() = tNow; prev = DubinsPlan(); continue; }
+                prev = st.Plan;
+                State nxt; nxt.time() = tNow;
+                if (prev.containsTime(tNow)) { prev.sample(nxt); cur = nxt; } else { cur.time() = tNow; }
+                cur.speed() = config.maxSpeed();
+                rm.cover(cur.x(), cur.y(), false);      // Executive::updateCovered: the vehicle covers as it moves
+            }
+            std::sort(wall.begin(), wall.end());
+            const double p50 = wall[wall.size() / 2], p99 = wall[std::min(wall.size() - 1, (size_t)(0.99 * wall.size()))];
+            std::printf("{\"replans\": %d, \"budget_ms\": %.3f, \"wall_ms_p50\": %.3f, \"wall_ms_p99\": %.3f, \"wall_ms_max\": %.3f, "
+                        "\"mean_iterations\": %.2f, \"mean_expanded\": %.1f, \"mean_samples\": %.1f, \"failed_plans\": %lu}\n",
+                        replans, 1e3 * timeRemaining, p50, p99, wall.back(), (double)iters / replans, (double)expanded / replans,
+                        (double)samples / replans, failures);
+            return 0;
+        }
         for (int rep = 0; rep < repeat; rep++) {
             long calls = 0;
             const auto w0 = std::chrono::steady_clock::now();

@@ -165,7 +165,7 @@ def test_dubins_lengths_and_nearest_selection(torch_cuda):
 
 
 @pytest.mark.parametrize("case", ["done_at_start", "colocated", "no_grid_no_obst", "many_ribbons_maxdist", "tsp_all_four",
-                                  "equal_speeds", "short_horizon", "wide_ribbons", "tsp_dubins_all", "tsp_dubins_k", "tsp_dubins_k0"])
+                                  "equal_speeds", "short_horizon", "wide_ribbons", "tsp_dubins_all", "tsp_dubins_k", "tsp_dubins_k0", "tsp_k_long_lists"])
 def test_edge_cases_match_oracle(torch_cuda, case):
     """Empty ribbon set, co-located target (the reference throws), base Map and base obstacle manager,
     long ribbon lists, the other heuristics, degenerate configuration values."""
@@ -201,6 +201,10 @@ def test_edge_cases_match_oracle(torch_cuda, case):
         rib = [[60, 86 + 7 * i, 100 - 4 * i, 88 + 6 * i] for i in range(4)]
     elif case == "tsp_dubins_k0":
         kw.update(heuristic=H_TSP_DUBINS_K, tsp_k=0, heuristic_turning_radius=8.0)     # loop body never runs: DBL_MAX
+    elif case == "tsp_k_long_lists":
+        # 9 ribbons at the source, children with 9..11: the K variant is enumerated up to 12 ribbons by the second heuristic pass
+        # (pp_k_heuristic_big); 4^(n-1) * 2 leaves per edge on the CPU, hence few samples
+        rib = [[58 + 5 * i, 84 + 3 * (i % 3), 58 + 5 * i, 118 - 2 * (i % 2)] for i in range(9)]
     elif case == "equal_speeds":
         kw.update(slow_speed=-1.0, coverage_turning_radius=8.0)
     elif case == "short_horizon":
@@ -212,7 +216,7 @@ def test_edge_cases_match_oracle(torch_cuda, case):
     rib = np.asarray(rib, dtype=np.float64).reshape(-1, 4)
     cct = 3.0 if case == "done_at_start" else -1.0           # AStarPlanner.cpp:19 sets it when nothing is left
     root = root_vertex(75.0, 75.0, 0.4, 2.5, 3.0, rib, cct=cct)
-    n = 300
+    n = 36 if case == "tsp_k_long_lists" else 300
     sx, sy, sh = rng.uniform(20, 130, n), rng.uniform(20, 130, n), rng.uniform(0, 2 * np.pi, n)
     sx[0], sy[0], sh[0] = 75.0, 75.0, 0.4                    # co-located with the root: reference throws
     # (targets closer than the collision-check increment are never built by the reference, SamplingBasedPlanner.cpp:68,111:
@@ -232,6 +236,13 @@ def test_edge_cases_match_oracle(torch_cuda, case):
     if case == "many_ribbons_maxdist":
         from path_planner_amd.types import F_RIBBON_OVF
         assert np.count_nonzero(gpu["flags"] & F_RIBBON_OVF) > 0
+    if case == "tsp_k_long_lists":
+        from path_planner_amd.types import F_RIBBON_OVF
+        nr = (gpu["info"] >> 8) & 255
+        print("child ribbon counts", np.bincount(nr))
+        assert np.count_nonzero(nr > 8) > 20
+        assert np.array_equal((gpu["flags"] & F_RIBBON_OVF) != 0, nr > 12)        # only lists beyond 12 ribbons are refused
+        assert np.all(gpu["h"][(nr > 8) & (nr <= 12) & ((gpu["flags"] & F_THROWS) == 0)] > 0)
     rep = compare_results(gpu, cpu, gchild, cchild)
     print(case, rep)
     badh = np.nonzero(np.abs(gpu["h"] - cpu["h"]) > 1e-6 * np.maximum(1.0, np.abs(cpu["h"])))[0]
