@@ -656,8 +656,19 @@ __device__ inline int pp_ribbons_event(PPRibbon& r, int n, double w, double x, d
 // moveEnd = false: the piece's START follows the vehicle (front part vanishes each step); true: its END does (the
 // vehicle travels towards the piece's start and the remainder vanishes each step).
 // Returns the run length L (0 = none) and the new position of the moving endpoint of piece `adv` (wave-uniform).
+// Pieces no step of the window can reach, decided once with one piece per lane: every step of the window lies within `span`
+// (64 steps of at most one increment each) of step `first`, so a piece whose midpoint is farther than its own reach + span
+// from that step is `far` (in the sense of the per-step test in the runs below) for all of them.
+__device__ __forceinline__ unsigned long long pp_pieces_in_reach(const PPRibbon& r, int n, double w, double x0, double y0, double span) {
+    const int lane = pp_lane();
+    const double mx = 0.5 * (r.sx + r.ex), my = 0.5 * (r.sy + r.ey);
+    const double ql = pp_sq_len(r.sx, r.sy, r.ex, r.ey);
+    const double reach = 0.5 * sqrt(ql) + w + 1e-3 + span;
+    return __ballot((lane < n) & !(pp_sq_len(mx, my, x0, y0) > reach * reach));
+}
+
 __device__ inline int pp_corridor_run(const PPRibbon& r, int n, double w, int adv, bool moveEnd, double x, double y, bool stepOk,
-                                      unsigned long long coverMask, int first, double& newX, double& newY) {
+                                      unsigned long long coverMask, int first, double span, double& newX, double& newY) {
     const int lane = pp_lane();
     const double Sx = pp_readlane(r.sx, adv), Sy = pp_readlane(r.sy, adv), Ex = pp_readlane(r.ex, adv), Ey = pp_readlane(r.ey, adv);
     const double g = 1e-9;
@@ -687,8 +698,10 @@ __device__ inline int pp_corridor_run(const PPRibbon& r, int n, double w, int ad
     // + w from its midpoint: cheap), or — for the near ones, typically the sibling the first split left behind —
     // the reference's own test must fail with the guard: projection clearly outside the piece, or clearly outside
     // its strict corridor
-    for (int q = 0; q < n; q++) {
-        if (q == adv) continue;
+    unsigned long long others = pp_pieces_in_reach(r, n, w, pp_readlane(x, first), pp_readlane(y, first), span) & ~(1ull << adv);
+    while (others) {
+        const int q = __ffsll((long long)others) - 1;
+        others &= others - 1;
         const double sx = pp_readlane(r.sx, q), sy = pp_readlane(r.sy, q), ex = pp_readlane(r.ex, q), ey = pp_readlane(r.ey, q);
         const double mx = 0.5 * (sx + ex), my = 0.5 * (sy + ey);
         const double ql = pp_sq_len(sx, sy, ex, ey);
@@ -721,12 +734,15 @@ __device__ inline int pp_corridor_run(const PPRibbon& r, int n, double w, int ad
 // or cover() is not enabled at that step (Edge.cpp:159).  Same guarded, lanes-as-steps evaluation as the corridor run:
 // a step joins the run only if "inside" is certain and "nothing splits" is certain.  Returns the run length.
 __device__ inline int pp_quiet_run(const PPRibbon& r, int n, double w, double x, double y, bool stepOk,
-                                   unsigned long long coverMask, int first) {
+                                   unsigned long long coverMask, int first, double span) {
     const int lane = pp_lane();
     const double g = 1e-9;
     const bool cand = stepOk & (lane >= first);
     bool inside = false, maySplit = false;
-    for (int q = 0; q < n; q++) {
+    unsigned long long pieces = pp_pieces_in_reach(r, n, w, pp_readlane(x, first), pp_readlane(y, first), span);
+    while (pieces) {
+        const int q = __ffsll((long long)pieces) - 1;
+        pieces &= pieces - 1;
         const double sx = pp_readlane(r.sx, q), sy = pp_readlane(r.sy, q), ex = pp_readlane(r.ex, q), ey = pp_readlane(r.ey, q);
         const double mx = 0.5 * (sx + ex), my = 0.5 * (sy + ey);
         const double ql = pp_sq_len(sx, sy, ex, ey);

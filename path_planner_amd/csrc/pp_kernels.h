@@ -399,11 +399,18 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
 #ifdef PP_DBG_EVENTS
     int dbgEvents = 0;
 #endif
+#ifdef PP_DBG_COUNTS
+    int dbgWindows = 0, dbgCorr = 0, dbgQuiet = 0, dbgGeneric = 0, dbgCorrLen = 0, dbgQuietLen = 0;
+#define PP_CNT(x) x
+#else
+#define PP_CNT(x)
+#endif
     int rdt = -1;                       // `auto ribbonsDoneTime = -1;` is an int (Edge.cpp:92)
     int nextEvent = 0;                  // toCoverDistance starts at 0: step 0 is an event
     int lastEv = -1;
     const double w = p.ribw;
     const double inc_d = p.inc_d;
+    const double runSpan = 64.0 * (p.inc_d / p.max_speed) * speed * (1.0 + 1e-9) + 1e-6;   // how far 64 steps can take the vehicle
 
     // ---- phase B: coverage events among steps [0, limit)
 #ifdef PP_ABL_NO_EVENTS
@@ -411,17 +418,26 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
 #endif
     if (!throwsRef) {
         bool ended = false;
+        int cont = 0, contPiece = 0;        // 1 / 2: the last window ended inside a corridor / quiet run (of piece contPiece)
+        bool contMoveEnd = false;
         while (!ended) {
             if (nextEvent >= limit) break;
-            // the 64-step chunk of the track that holds the next event, one step per lane (chunks without events are
+            // a window of 64 steps of the track starting AT the next event, one step per lane (stretches without events are
             // never loaded)
-            const int base = nextEvent & ~(PP_WAVE - 1);
+            const int base = nextEvent;
+            PP_CNT(dbgWindows++);
             const int k = base + lane;
             const double t = (k < p.ng) ? tg[k] : INFINITY;
             double2 q = make_double2(0.0, 0.0);
             if (k < limit) q = track[k];
             // Edge.cpp:159: cover only when coverage is allowed on this edge or the heading did not change since the last step
-            const unsigned long long coverMask = cov ? ~0ull : pp_const_u64(teq + (base >> 6))[0];
+            unsigned long long coverMask = ~0ull;
+            if (!cov) {
+                const int c0 = base >> 6, sh = base & 63;
+                const unsigned long long lo = pp_const_u64(teq + c0)[0];
+                const unsigned long long hi = (sh != 0 && c0 + 1 < p.nch) ? pp_const_u64(teq + c0 + 1)[0] : 0ull;
+                coverMask = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+            }
             const int climit = (limit - base) < PP_WAVE ? (limit - base) : PP_WAVE;
             bool runFailed = false, quietFailed = false;
             while (true) {
@@ -429,9 +445,36 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                 if (j >= climit) break;
                 const double tj = pp_readlane(t, j);
                 if (!(tj < endTime)) { ended = true; break; }         // `while (intermediate.time() < endTime)`
+#ifndef PP_NO_CORRIDOR_RUN
+                if (j == 0 && cont != 0) {
+                    // the previous window ended inside a run: this step is an event of the same kind, very likely the whole
+                    // window is.  The run's own guarded checks decide; if its first step does not pass, the step goes
+                    // through the one-at-a-time code below like any other.
+                    int L = 0;
+                    double nsx = 0, nsy = 0;
+                    const bool stepOk = (lane < climit) & (t < endTime);
+                    PP_CNT(if (cont == 1) dbgCorr++; else dbgQuiet++);
+                    if (cont == 1) L = pp_corridor_run(rib, nrib, w, contPiece, contMoveEnd, q.x, q.y, stepOk, coverMask, 0, runSpan, nsx, nsy);
+#ifndef PP_NO_QUIET_RUN
+                    else L = pp_quiet_run(rib, nrib, w, q.x, q.y, stepOk, coverMask, 0, runSpan);
+#endif
+                    if (L > 0) {
+                        if (cont == 1 && lane == contPiece) {
+                            if (contMoveEnd) { rib.ex = nsx; rib.ey = nsy; } else { rib.sx = nsx; rib.sy = nsy; }
+                        }
+                        PP_CNT(if (cont == 1) dbgCorrLen += L; else dbgQuietLen += L);
+                        lastEv = base + L - 1;
+                        nextEvent = base + L;
+                        if (L < climit) cont = 0;              // the run ended inside the window: something else happens next
+                        continue;
+                    }
+                    cont = 0;
+                }
+#endif
                 const double xj = pp_readlane(q.x, j), yj = pp_readlane(q.y, j);
                 double D;                                             // Edge.cpp:158-161
                 int adv;
+                PP_CNT(dbgGeneric++);
                 nrib = pp_ribbons_event(rib, nrib, w, xj, yj, ((coverMask >> j) & 1ull) != 0ull, lds, D, adv);
                 if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
 #ifndef PP_NO_CORRIDOR_RUN
@@ -440,7 +483,8 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                     double nsx, nsy;
                     const bool moveEnd = (adv & 0x100) != 0;
                     const int piece = adv & 0xff;
-                    const int L = pp_corridor_run(rib, nrib, w, piece, moveEnd, q.x, q.y, (lane < climit) & (t < endTime), coverMask, j + 1, nsx, nsy);
+                    const int L = pp_corridor_run(rib, nrib, w, piece, moveEnd, q.x, q.y, (lane < climit) & (t < endTime), coverMask, j + 1, runSpan, nsx, nsy);
+                    PP_CNT(dbgCorr++; dbgCorrLen += L);
                     runFailed = (L == 0);                  // do not keep paying for attempts that do not start
                     if (L > 0) {
                         if (lane == piece) {
@@ -448,17 +492,20 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                         }
                         lastEv = base + j + L;
                         nextEvent = base + j + L + 1;      // inside the corridor minDistanceFrom is 0: the next step is an event too
+                        if (j + L + 1 >= climit) { cont = 1; contPiece = piece; contMoveEnd = moveEnd; }   // cut by the window, not by a guard
                         continue;
                     }
                 }
 #ifndef PP_NO_QUIET_RUN
                 else if (adv == -2 && D == 0 && nrib > 0 && j + 1 < climit && !quietFailed) {
                     // inside a corridor, nothing changed: the following steps are very likely the same kind of event
-                    const int L = pp_quiet_run(rib, nrib, w, q.x, q.y, (lane < climit) & (t < endTime), coverMask, j + 1);
+                    const int L = pp_quiet_run(rib, nrib, w, q.x, q.y, (lane < climit) & (t < endTime), coverMask, j + 1, runSpan);
+                    PP_CNT(dbgQuiet++; dbgQuietLen += L);
                     quietFailed = (L == 0);
                     if (L > 0) {
                         lastEv = base + j + L;
                         nextEvent = base + j + L + 1;
+                        if (j + L + 1 >= climit) cont = 2;
                         continue;
                     }
                 }
@@ -629,9 +676,15 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
             case 10: v = h; break;
             case 11: v = g + h; break;
             case 12: v = cct; break;
+#ifdef PP_DBG_COUNTS
+            case 13: v = (double)dbgWindows * 1e6 + (double)dbgGeneric; break;
+            case 14: v = (double)dbgCorr * 1e6 + (double)dbgCorrLen; break;
+            default: v = (double)dbgQuiet * 1e6 + (double)dbgQuietLen; break;
+#else
             case 13: v = PP_SF64(p0); break;
             case 14: v = PP_SF64(p1); break;
             default: v = PP_SF64(p2); break;
+#endif
         }
         if (throwsRef && lane != 0) v = 0;
         if (lane < 16) reinterpret_cast<double*>(rec)[lane] = v;
