@@ -316,7 +316,7 @@ int ppgpu_set_vertices(ppgpu_ctx* c, int32_t n, const ppgpu_vertex* hv, int32_t 
     HIP_TRY(hipMemcpyAsync(c->verts.p, hv, (size_t)n * sizeof(ppgpu_vertex), hipMemcpyHostToDevice, c->stream));
     if (n_ribbons > 0)
         HIP_TRY(hipMemcpyAsync(c->ribbons.p, hr, (size_t)n_ribbons * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(pp_k_time_grid, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->verts.p, n, c->cfg.start_state_time,
+    hipLaunchKernelGGL(pp_k_time_grid, dim3((unsigned)n), dim3(64), 0, c->stream, c->verts.p, n, c->cfg.start_state_time,
                        c->cfg.collision_checking_increment, c->cfg.max_speed, c->ng, c->tgrid.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));  // the host arrays may go away after return

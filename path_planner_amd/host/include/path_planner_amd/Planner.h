@@ -99,6 +99,7 @@ private:
     bool goalCondition(const Node& v) const;
     void expand(int source);
     void expandBatch(const std::vector<int>& sources);
+    int costEdgeList(const std::vector<uint64_t>& edges, int maxParentRibbons, std::vector<::ppgpu_edge_result>& res, std::vector<double>& child);
     Node makeChild(int source, unsigned cfgBits, const ::ppgpu_edge_result& r, const double* childRibbons);
     int aStar(double endTime);
     void addSamples(long n);

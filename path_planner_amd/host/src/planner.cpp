@@ -178,6 +178,27 @@ GpuAStarPlanner::Node GpuAStarPlanner::makeChild(int source, unsigned cfgBits, c
     return c;
 }
 
+// ppgpu_cost_edges_host with a child-ribbon stride sized for the parents at hand: children rarely carry more than a few
+// ribbons more than their parent, and the child buffer is what crosses PCIe (a 64-ribbon stride is 2 KB per edge).  If some
+// child does not fit, the batch is costed again at the device's full per-vertex capacity.
+int GpuAStarPlanner::costEdgeList(const std::vector<uint64_t>& edges, int maxParentRibbons, std::vector<ppgpu_edge_result>& res,
+                                  std::vector<double>& child) {
+    const size_t n = edges.size();
+    int stride = std::min(kRibbonStride, maxParentRibbons + 6);
+    for (;;) {
+        res.resize(n);
+        child.assign(n * (size_t)stride * 4, 0.0);
+        check(ppgpu_cost_edges_host(m_Ctx->handle(), (int64_t)n, edges.data(), res.data(), child.data(), stride), "ppgpu_cost_edges_host");
+        m_Stats.EdgesCosted += n;
+        bool retry = false;
+        if (stride < kRibbonStride)
+            for (size_t i = 0; i < n && !retry; i++)
+                retry = (res[i].flags & PPGPU_F_RIBBON_OVF) && (int)((res[i].info >> 8) & 0xff) > stride;
+        if (!retry) return stride;
+        stride = kRibbonStride;
+    }
+}
+
 // Vertex::connect(source, state, radius, coverageAllowed) + Edge::computeTrueCost for a batch of targets, then
 // pushVertexQueue in the given order.  sampleIndex[i] >= 0 uses a stored sample, otherwise targets[i] is uploaded.
 int GpuAStarPlanner::costStateEdges(int source, const std::vector<State>& targets, const std::vector<unsigned>& cfgBits,
@@ -200,12 +221,11 @@ int GpuAStarPlanner::costStateEdges(int source, const std::vector<State>& target
         uint32_t tgt = (uint32_t)(sampleIndex[i] >= 0 ? sampleIndex[i] : first + extraSlot[i]);
         edges[i] = ppgpu_edge_pack(0, tgt, cfgBits[i]);
     }
-    std::vector<ppgpu_edge_result> res(n);
-    std::vector<double> child(n * (size_t)kRibbonStride * 4);
-    check(ppgpu_cost_edges_host(h, (int64_t)n, edges.data(), res.data(), child.data(), kRibbonStride), "ppgpu_cost_edges_host");
-    m_Stats.EdgesCosted += n;
+    std::vector<ppgpu_edge_result> res;
+    std::vector<double> child;
+    const int stride = costEdgeList(edges, (int)m_Nodes[source].ribbons.get().size(), res, child);
     for (size_t i = 0; i < n; i++) {
-        m_Nodes.push_back(makeChild(source, cfgBits[i], res[i], child.data() + i * (size_t)kRibbonStride * 4));
+        m_Nodes.push_back(makeChild(source, cfgBits[i], res[i], child.data() + i * (size_t)stride * 4));
         pushVertexQueue((int)m_Nodes.size() - 1);
     }
     return (int)n;
@@ -293,12 +313,13 @@ void GpuAStarPlanner::expandBatch(const std::vector<int>& sources) {
     for (int i = 0; i < M; i++) m_Speculated[sources[i]];   // an entry even when a vertex has no edges at all
     const size_t n = edges.size();
     if (n == 0) return;
-    std::vector<ppgpu_edge_result> res(n);
-    std::vector<double> child(n * (size_t)kRibbonStride * 4);
-    check(ppgpu_cost_edges_host(h, (int64_t)n, edges.data(), res.data(), child.data(), kRibbonStride), "ppgpu_cost_edges_host");
-    m_Stats.EdgesCosted += n;
+    std::vector<ppgpu_edge_result> res;
+    std::vector<double> child;
+    int maxParent = 0;
+    for (int i = 0; i < M; i++) maxParent = std::max(maxParent, (int)m_Nodes[sources[i]].ribbons.get().size());
+    const int stride = costEdgeList(edges, maxParent, res, child);
     for (size_t e = 0; e < n; e++)
-        m_Speculated[sources[owner[e]]].push_back(makeChild(sources[owner[e]], cfg[e], res[e], child.data() + e * (size_t)kRibbonStride * 4));
+        m_Speculated[sources[owner[e]]].push_back(makeChild(sources[owner[e]], cfg[e], res[e], child.data() + e * (size_t)stride * 4));
 }
 
 // expand(source) as the search sees it.  The device answers for `source` and, speculatively, for the open vertices the
