@@ -127,8 +127,9 @@ def main():
         flops_per_edge = 1000 + steps_mean * (70 + 21 * M)               # pose + cover sweeps; the heuristic kernel is ~4e4 more
         ach_gbs = bytes_per_edge * n_edges_launch / (kern_ms * 1e-3) / 1e9
         ach_tf = flops_per_edge * n_edges_launch / ((pose_ms + cover_ms) * 1e-3) / 1e12
-        # what the split into two sweeps costs: the track that goes through HBM between them
-        track_bytes_per_edge = 16.0 * steps_mean + 12.0 * (steps_mean / 64.0) + 384 + 16
+        # what goes through HBM between the kernels of one launch: the solved curve (384 B), the pose
+        # sweep's summary (16 B) and its per-chunk words (12 B per 64 steps); poses are recomputed, not stored
+        workspace_bytes_per_edge = 384 + 16 + 12.0 * (steps_mean / 64.0)
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")   # written from a separate rocprofv3 --pmc pass
         if os.path.exists(tp):
@@ -157,8 +158,7 @@ def main():
                          "traffic": traffic, "kernel": "pp_k_cover_sweep", "kernel_ms": kern_ms,
                          "kernels_ms": {"pp_k_solve_edges": solve_ms, "pp_k_pose_sweep": pose_ms, "pp_k_cover_sweep": cover_ms,
                                         "pp_k_heuristic": heur_ms},
-                         "algorithmic_bytes_per_edge": bytes_per_edge, "track_bytes_per_edge": track_bytes_per_edge,
-                         "pose_sweep_track_write_GBps": 16.0 * steps_mean * n_edges_launch / (pose_ms * 1e-3) / 1e9,
+                         "algorithmic_bytes_per_edge": bytes_per_edge, "workspace_bytes_per_edge": workspace_bytes_per_edge,
                          "note": "all four kernels are fp64-VALU bound, not HBM bound (SURVEY 8d): see valu_fp64"},
             "valu_fp64": {"achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TFLOPS,
                           "algorithmic_flops_per_edge": flops_per_edge},

@@ -29,7 +29,6 @@ struct PPParams {
     long long e_base, ws_base;
     // workspace: one PPEdgeSetup per edge from pp_k_solve_edges, then the pose sweep's track of each edge
     struct PPEdgeSetup* setup;
-    double2* track_pose;                 // [edge][ngp]  x, y of step k
     unsigned short* track_hits;          // [edge][ngp]  dynamic-obstacle boxes hit at step k
     unsigned long long* track_eq;        // [edge][nch]  bit k & 63 of word k >> 6: heading(k) == heading(k - 1)
     unsigned* track_chunk_hits;          // [edge][nch]  hits summed over the chunk's executable steps
@@ -187,7 +186,8 @@ __global__ __launch_bounds__(256) void pp_k_solve_edges(PPParams p) {
 #define PP_WPB 4   // wavefronts (= edges) per workgroup of the per-edge kernels
 #endif
 #ifndef PP_MIN_WAVES
-#define PP_MIN_WAVES 6   // cover sweep: waves per SIMD the register allocator must leave room for
+#define PP_MIN_WAVES 4   // cover sweep: waves per SIMD the register allocator must leave room for (4 = 128 VGPRs: no spills;
+                         // 6 measures 5 % faster but turns 43 spilled registers into 5 GB of scratch traffic per launch)
 #endif
 #define PP_SF64(field) (pp_const_f64(&S->field)[0])
 #define PP_SI32(field) (pp_const_i32(&S->field)[0])
@@ -200,6 +200,62 @@ struct PPTrackSummary {
     int pad;
 };
 
+// DubinsWrapper::sample (DubinsWrapper.cpp:29-49) -> dubins_path_sample for the 64 steps of one window, one step per lane:
+// x, y and the un-normalised yaw.  Used by BOTH sweeps with the same arithmetic, so the cover sweep sees exactly the poses the
+// pose sweep tested (it recomputes them for the few windows that hold coverage events instead of reading them back from HBM).
+// The constants of the segment the caller is on (cur / cs) live in scalar registers and are swapped when the window moved on.
+struct PPCurveHot { double wStart, speed, length, rho, rho_inv, qx, qy; };
+__device__ __forceinline__ PPCurveHot pp_curve_hot(const PPEdgeSetup* S) {
+    PPCurveHot h;
+    h.wStart = PP_SF64(wStart); h.speed = PP_SF64(speed); h.length = PP_SF64(length); h.rho = PP_SF64(rho); h.rho_inv = PP_SF64(rho_inv);
+    h.qx = PP_SF64(qx); h.qy = PP_SF64(qy);
+    return h;
+}
+__device__ __forceinline__ void pp_window_pose(const PPEdgeSetup* S, const PPCurveHot& c, int& cur, PPSeg& cs, double t, double tFirst, bool valid,
+                                               double& x, double& y, double& uth, bool& dubErr) {
+    // lanes past the end of the sweep redo lane 0's step (benign arithmetic, uniform control flow); the caller masks them
+    const double tl = valid ? t : tFirst;
+    double dist = (tl - c.wStart) * c.speed;                          // DubinsWrapper.cpp:36
+    if (__ballot((dist < 0) | (dist > c.length)) != 0ull) {           // rare: the first / last step of a curve
+        if (dist < 0 || dist > c.length) dist = dist - 1e-5;          // EDUBPARAM retry, :39-42
+        if (dist < 0 || dist > c.length) { dubErr = true; dist = fmin(fmax(dist, 0.0), c.length); }
+    }
+    // dubins_path_sample(): 64 consecutive arc lengths almost always fall on one segment, which is then advanced with
+    // wave-uniform constants
+    const double tprime = (c.rho_inv != 0.0) ? dist * c.rho_inv : dist / c.rho;
+    double ux, uy;
+    bool uniformSeg = __ballot(!((tprime >= cs.lo) & (tprime < cs.hi))) == 0ull;
+    if (!uniformSeg) {
+        const double hi0 = PP_SF64(seg[0].hi), hi1 = PP_SF64(seg[1].hi);
+        const int mine = pp_seg_of(tprime, hi0, hi1);
+        const int firstSeg = __builtin_amdgcn_readfirstlane(mine);
+        const int lastSeg = __builtin_amdgcn_readlane(mine, 63 - __clzll((long long)__ballot(valid)));
+        if (__ballot(mine != firstSeg) != 0ull) {
+            // the window straddles a junction: every lane takes its own segment's constants from memory
+            const PPSeg* g = &S->seg[mine];
+            pp_curve_seg(g->type, (tprime - g->o1) - g->o2, g->bx, g->by, g->bth, g->sb, g->cb, ux, uy, uth);
+        } else {
+            uniformSeg = true;
+            if (cur != firstSeg) { cur = firstSeg; cs = pp_seg_load_uniform(&S->seg[cur]); }
+        }
+        if (cur != lastSeg && !uniformSeg) { cur = lastSeg; cs = pp_seg_load_uniform(&S->seg[cur]); }
+    }
+    if (uniformSeg) pp_curve_seg(cs.type, (tprime - cs.o1) - cs.o2, cs.bx, cs.by, cs.bth, cs.sb, cs.cb, ux, uy, uth);
+    x = ux * c.rho + c.qx;
+    y = uy * c.rho + c.qy;
+}
+
+// The cover sweep samples poses only when it loads a window: it re-reads the curve constants there (scalar loads, kept
+// inside the loop by laundering the pointer) rather than carrying 33 scalar registers of them through the event loop.
+#define PP_WINDOW_POSE(S, t, t0, valid, x, y) do {                                                         \
+        const PPEdgeSetup* _S = (S);                                                                       \
+        asm volatile("" : "+s"(_S));                                                                       \
+        const PPCurveHot _hot = pp_curve_hot(_S);                                                          \
+        int _cur = -1;                                                                                     \
+        PPSeg _cs = PPSeg{0, 0, 0, 0, 0, INFINITY, -INFINITY, 0, 0, 1, 0};   /* matches nothing: the first use loads a segment */ \
+        double _u; bool _e = false;                                                                        \
+        pp_window_pose(_S, _hot, _cur, _cs, t, t0, valid, x, y, _u, _e);                                   \
+    } while (0)
 // e = the edge's slot in the workspace.  GAUSSIAN: the dynamic obstacles are GaussianDynamicObstaclesManager's (its own
 // instantiation: exp() and the density bookkeeping would otherwise cost the common kernel registers).
 template <bool GAUSSIAN>
@@ -217,15 +273,14 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
     const bool cov = (((unsigned)PP_SI32(cbits)) & PPGPU_EDGE_COVERAGE) != 0;
     const ppgpu_vertex* V = p.verts + vi;
     const double srcH = pp_sgpr(V->heading);
-    const double wEnd = PP_SF64(wEnd), wStart = PP_SF64(wStart), speed = PP_SF64(speed);
-    const double cvLength = PP_SF64(length), cvRho = PP_SF64(rho), cvRhoInv = PP_SF64(rho_inv), cvQx = PP_SF64(qx), cvQy = PP_SF64(qy);
+    const PPCurveHot hot = pp_curve_hot(S);
+    const double wEnd = PP_SF64(wEnd), wStart = hot.wStart, speed = hot.speed, cvLength = hot.length, cvQx = hot.qx, cvQy = hot.qy;
     const double endTime = fmin(p.horizon + 1e-12 + p.sst, wEnd);    // Edge.cpp:90 (the cover sweep may end the edge earlier)
     // the segment of the curve the sweep is on: its constants live in scalar registers, the other two stay in memory
     int cur = 0;
     PPSeg cs = pp_seg_load_uniform(&S->seg[0]);
 
     const double* tg = p.tgrid + (size_t)vi * p.ng;
-    double2* track = p.track_pose + (size_t)e * p.ngp;
     unsigned short* thits = p.track_hits + (size_t)e * p.ngp;
     unsigned long long* teq = p.track_eq + (size_t)e * p.nch;
     unsigned* tch = p.track_chunk_hits + (size_t)e * p.nch;
@@ -272,36 +327,8 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
         bool blk = false;
         int hits = 0;
         {
-            // lanes past the end of the sweep redo lane 0's step (benign arithmetic, uniform control flow); masked below
-            const double tl = valid ? t : tFirst;
-            double dist = (tl - wStart) * speed;                      // DubinsWrapper.cpp:36
-            if (__ballot((dist < 0) | (dist > cvLength)) != 0ull) {   // rare: the first / last step of a curve
-                if (dist < 0 || dist > cvLength) dist = dist - 1e-5;  // EDUBPARAM retry, :39-42
-                if (dist < 0 || dist > cvLength) { dubErr = true; dist = fmin(fmax(dist, 0.0), cvLength); }
-            }
-            // dubins_path_sample(): 64 consecutive arc lengths almost always fall on the segment the previous chunk
-            // ended on, which is then advanced with wave-uniform constants
-            const double tprime = (cvRhoInv != 0.0) ? dist * cvRhoInv : dist / cvRho;
-            double ux, uy, uth;
-            bool uniformSeg = __ballot(!((tprime >= cs.lo) & (tprime < cs.hi))) == 0ull;
-            if (!uniformSeg) {
-                const double hi0 = PP_SF64(seg[0].hi), hi1 = PP_SF64(seg[1].hi);
-                const int mine = pp_seg_of(tprime, hi0, hi1);
-                const int firstSeg = __builtin_amdgcn_readfirstlane(mine);
-                const int lastSeg = __builtin_amdgcn_readlane(mine, 63 - __clzll((long long)__ballot(valid)));
-                if (__ballot(mine != firstSeg) != 0ull) {
-                    // the chunk straddles a junction: every lane takes its own segment's constants from memory
-                    const PPSeg* g = &S->seg[mine];
-                    pp_curve_seg(g->type, (tprime - g->o1) - g->o2, g->bx, g->by, g->bth, g->sb, g->cb, ux, uy, uth);
-                } else {
-                    uniformSeg = true;
-                    if (cur != firstSeg) { cur = firstSeg; cs = pp_seg_load_uniform(&S->seg[cur]); }
-                }
-                if (cur != lastSeg && !uniformSeg) { cur = lastSeg; cs = pp_seg_load_uniform(&S->seg[cur]); }
-            }
-            if (uniformSeg) pp_curve_seg(cs.type, (tprime - cs.o1) - cs.o2, cs.bx, cs.by, cs.bth, cs.sb, cs.cb, ux, uy, uth);
-            x = ux * cvRho + cvQx;
-            y = uy * cvRho + cvQy;
+            double uth;
+            pp_window_pose(S, hot, cur, cs, t, tFirst, valid, x, y, uth, dubErr);
             // the heading itself (:47) only matters for "unchanged since the last step" (Edge.cpp:159), which only matters
             // on edges that may not cover while turning
             heading = cov ? 0.0 : pp_heading_from_yaw(pp_mod2pi(uth));
@@ -332,9 +359,6 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
         const int nvalid = __popcll(__ballot(valid));
         const int nlim = fb < nvalid ? fb : nvalid;
 
-#ifndef PP_ABL_NO_TRACK_STORE
-        track[k] = make_double2(x, y);                                // k < ngp: ngp is ng rounded up to whole chunks
-#endif
         int chunkHits = 0;
         if (__ballot(hits != 0) != 0ull) {
             // per-step counts are only ever read for a chunk whose sum is not zero
@@ -406,7 +430,6 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
     const int limit = pp_const_i32(&sum->limit)[0];
     const bool blockedAtLimit = pp_const_i32(&sum->blocked)[0] != 0;
     if (pp_const_i32(&sum->dub_err)[0]) flags |= PPGPU_F_DUBINS_ERR;
-    const double2* track = p.track_pose + (size_t)e * p.ngp;
     const unsigned long long* teq = p.track_eq + (size_t)e * p.nch;
     const double* tg = p.tgrid + (size_t)vi * p.ng;
 
@@ -442,8 +465,12 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
             PP_CNT(dbgWindows++);
             const int k = base + lane;
             const double t = (k < p.ng) ? tg[k] : INFINITY;
-            double2 q = make_double2(0.0, 0.0);
-            if (k < limit) q = track[k];
+            // the poses of the window, recomputed with the pose sweep's own arithmetic (pp_window_pose)
+            double2 q;
+            {
+                PP_WINDOW_POSE(S, t, pp_readlane(t, 0), k < limit, q.x, q.y);
+                if (k >= limit) { q.x = 0.0; q.y = 0.0; }
+            }
             // Edge.cpp:159: cover only when coverage is allowed on this edge or the heading did not change since the last step
             unsigned long long coverMask = ~0ull;
             if (!cov) {
@@ -563,6 +590,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
     double tfinal = (p.ng > 0) ? pp_const_f64(tg)[0] : INFINITY;
     bool coverFinal = true;             // `lastHeading == intermediate.heading()` unless the loop broke at a blocked step
     int hexec = 0;                      // steps whose obstacle hits count
+    int lastIdx = -1;                   // the step whose pose `intermediate` holds when the loop stops (-1: the source pose)
     if (!throwsRef) {
         // cnt = steps k < limit with t_k < endTime (the time grid is non-decreasing)
         int cnt = limit;
@@ -585,17 +613,23 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
         nexec = nexec < limit ? nexec : limit;
         if (blockedAtLimit && nexec == limit) {             // reached the blocked step: `break` at :146
             infeasible = true;
-            ix = pp_const_f64(&track[limit].x)[0]; iy = pp_const_f64(&track[limit].y)[0];
+            lastIdx = limit;
             coverFinal = cov || (((pp_const_u64(teq + (limit >> 6))[0] >> (limit & 63)) & 1ull) != 0ull);
             tfinal = pp_const_f64(tg + limit)[0];
             steps = limit + 1;
             hexec = limit;
         } else {                                            // loop condition failed
-            if (nexec > 0) { ix = pp_const_f64(&track[nexec - 1].x)[0]; iy = pp_const_f64(&track[nexec - 1].y)[0]; }
+            lastIdx = nexec - 1;
             tfinal = (nexec < p.ng) ? pp_const_f64(tg + nexec)[0] : INFINITY;
             steps = nexec;
             hexec = nexec;
         }
+    }
+
+    if (lastIdx >= 0) {
+        // `intermediate`'s position at that step: the same sample, every lane on the same step
+        const double tl = pp_const_f64(tg + lastIdx)[0];
+        PP_WINDOW_POSE(S, tl, tl, true, ix, iy);
     }
 
     // ---- phase C

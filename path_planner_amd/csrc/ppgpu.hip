@@ -90,8 +90,7 @@ struct ppgpu_ctx {
     DevBuf<double> tmp_child, tmp_lengths, tmp_len_out, int_child;
     size_t slice_bytes = PP_SLICE_BYTES; // workspace budget of one costing slice (env PPGPU_SLICE_BYTES overrides: tests)
     DevBuf<PPEdgeSetup> setup;          // workspace of the current costing slice: phase-0 records ...
-    DevBuf<double2> track_pose;         // ... and the pose sweep's track (see PPParams)
-    DevBuf<unsigned short> track_hits;
+    DevBuf<unsigned short> track_hits;  // ... and the pose sweep's track (see PPParams)
     DevBuf<unsigned long long> track_eq;
     DevBuf<unsigned> track_chunk_hits;
     DevBuf<PPTrackSummary> track_summary;
@@ -147,7 +146,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->s_bytes.release(); c->s_u64.release(); c->s_u32a.release(); c->s_u32b.release(); c->s_cand.release();
     c->tmp_edges.release(); c->tmp_wedges.release(); c->partial.release(); c->tmp_results.release(); c->tmp_child.release();
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
-    c->setup.release(); c->track_pose.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
+    c->setup.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
     c->track_summary.release(); c->track_pen.release(); c->track_chunk_pen.release();
     for (int i = 0; i < 5; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -599,7 +598,7 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     p.nch = (p.ng + PP_WAVE - 1) / PP_WAVE;
     if (p.nch < 1) p.nch = 1;
     p.ngp = p.nch * PP_WAVE;
-    const size_t per_edge = sizeof(PPEdgeSetup) + (size_t)p.ngp * (sizeof(double2) + sizeof(unsigned short)) +
+    const size_t per_edge = sizeof(PPEdgeSetup) + (size_t)p.ngp * sizeof(unsigned short) +
                             (size_t)p.nch * (sizeof(unsigned long long) + sizeof(unsigned)) + sizeof(PPTrackSummary) +
                             ((p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN) ? (size_t)(p.ngp + p.nch) * sizeof(double) : 0);
     long long slice = (long long)(c->slice_bytes / per_edge);
@@ -609,7 +608,6 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     {
         int rc;
         if ((rc = c->setup.reserve(ws, false, c->stream)) ||
-            (rc = c->track_pose.reserve(ws * p.ngp, false, c->stream)) ||
             (rc = c->track_hits.reserve(ws * p.ngp, false, c->stream)) ||
             (rc = c->track_eq.reserve(ws * p.nch, false, c->stream)) ||
             (rc = c->track_chunk_hits.reserve(ws * p.nch, false, c->stream)) ||
@@ -619,7 +617,7 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
             ((rc = c->track_pen.reserve(ws * p.ngp, false, c->stream)) || (rc = c->track_chunk_pen.reserve(ws * p.nch, false, c->stream))))
             return rc;
     }
-    p.setup = c->setup.p; p.track_pose = c->track_pose.p; p.track_hits = c->track_hits.p; p.track_eq = c->track_eq.p;
+    p.setup = c->setup.p; p.track_hits = c->track_hits.p; p.track_eq = c->track_eq.p;
     p.track_chunk_hits = c->track_chunk_hits.p; p.track_summary = c->track_summary.p;
     p.track_pen = c->track_pen.p; p.track_chunk_pen = c->track_chunk_pen.p;
     for (long long e0 = 0; e0 < total; e0 += slice) {
