@@ -778,7 +778,7 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep_ga
 // child ribbons) / maxSpeed, f = g + h, patched into the edge's record.  Its own kernel so that the
 // sweep kernel's register budget is not set by the TSP enumeration.  One wavefront per edge.
 #ifndef PP_H_MIN_WAVES
-#define PP_H_MIN_WAVES 1
+#define PP_H_MIN_WAVES 6   // measured: 1 (87 VGPRs, 5 waves) 1.12 ms, 6 (72 VGPRs) 1.06 ms, 8 (63 VGPRs) 1.09 ms
 #endif
 // DUBINS = the two Dubins-TSP heuristics (RibbonManager.cpp:97-140): the same enumeration over a table of Dubins
 // distances between oriented ribbon endpoints.  A separate instantiation so that the six-word solve does not set the

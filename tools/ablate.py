@@ -16,6 +16,9 @@ VARIANTS = {
     "h3": ["-DPP_H_MIN_WAVES=3"],
     "h4": ["-DPP_H_MIN_WAVES=4"],
     "h5": ["-DPP_H_MIN_WAVES=5"],
+    "h6": ["-DPP_H_MIN_WAVES=6"],
+    "h7": ["-DPP_H_MIN_WAVES=7"],
+    "h8": ["-DPP_H_MIN_WAVES=8"],
     "occ1": ["-DPP_MIN_WAVES=1"],
     "occ4": ["-DPP_MIN_WAVES=4"],
     "occ5": ["-DPP_MIN_WAVES=5"],
