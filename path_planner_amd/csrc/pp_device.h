@@ -564,6 +564,24 @@ __device__ inline int pp_ribbons_event(PPRibbon& r, int n, double w, double x, d
     if (n == 0) return 0;
     const int lane = pp_lane();
     const bool act = lane < n;
+    {
+        // Most events happen on the approach, far from every ribbon.  Ribbon::contains needs the projection inside the
+        // segment (+-1e-5 per coordinate) and a perpendicular distance below w, so a point outside a ribbon's bounding box
+        // grown by w (+1e-3 slack) cannot be contained in it: nothing contains, nothing splits, and unless some piece is
+        // short enough to be erased as covered (Ribbon::covered, checked by cover() for every ribbon) the event only
+        // measures the distance to the nearest endpoint.
+        const double grow = w + 1e-3;
+        const bool inBox = (x >= fmin(r.sx, r.ex) - grow) & (x <= fmax(r.sx, r.ex) + grow) & (y >= fmin(r.sy, r.ey) - grow) & (y <= fmax(r.sy, r.ey) + grow);
+        const double minLength0 = 2 * w;
+        const bool tiny = pp_sq_len(r.sx, r.sy, r.ex, r.ey) < minLength0 * minLength0 / (2.0 * 2.0);
+        if (__ballot(act & (inBox | tiny)) == 0ull) {
+            const double qS = (r.sx - x) * (r.sx - x) + (r.sy - y) * (r.sy - y);
+            const double qE = (r.ex - x) * (r.ex - x) + (r.ey - y) * (r.ey - y);
+            D = fmin(PP_DBL_MAX, sqrt(pp_min_first_n(act ? fmin(qE, qS) : PP_DBL_MAX, n)));
+            adv = -2;
+            return n;
+        }
+    }
     // Straight-line code on purpose (bitwise &,| instead of &&,||; inactive lanes hold a zero ribbon and are masked
     // out at the ballots): the event loop is the serial part of the kernel and every branch in it costs.
     // Ribbon::getProjection (Ribbon.cpp:72-78)
