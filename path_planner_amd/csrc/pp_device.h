@@ -379,20 +379,21 @@ struct PPGrid {
 // where that product is within 1e-9 of an integer (relative), i.e. where the division's rounding could matter.
 __device__ __forceinline__ bool pp_is_blocked(const PPGrid& g, double x, double y) {
     if (g.rows == 0) return false;
-    double cx = x * g.inv_res;
-    double cy = y * g.inv_res;
-    {
-        const double fx = cx - floor(cx), fy = cy - floor(cy);
-        const double mx = 1e-9 * fmax(1.0, fabs(cx)), my = 1e-9 * fmax(1.0, fabs(cy));
-        if (__ballot(!((fx > mx) & (fx < 1.0 - mx) & (fy > my) & (fy < 1.0 - my))) != 0ull) {
-            cx = x / g.res;
-            cy = y / g.res;
-        }
+    // size_t(x / res): the product x * (1 / res) is within a few ulp of the quotient, so if truncating it a little below and a
+    // little above (4e-9 relative) gives the same cell, the quotient truncates to that cell too, and `x / res >= cols` is
+    // `cell >= cols`; only when some lane sits that close to a cell boundary are the true divisions done (for all lanes).
+    const double cx = x * g.inv_res, cy = y * g.inv_res;
+    const unsigned cxl = (unsigned)(cx * (1.0 - 4e-9)), cxh = (unsigned)(cx * (1.0 + 4e-9));
+    const unsigned cyl = (unsigned)(cy * (1.0 - 4e-9)), cyh = (unsigned)(cy * (1.0 + 4e-9));
+    unsigned r = cyl, c = cxl;
+    bool outside = (x < 0) | (cxl >= (unsigned)g.cols) | (y < 0) | (cyl >= (unsigned)g.rows);
+    if (__ballot((cxl != cxh) | (cyl != cyh)) != 0ull) {
+        const double qx = x / g.res, qy = y / g.res;                  // GridWorldMap.cpp:85-88, literally
+        outside = (x < 0) | (qx >= (double)g.cols) | (y < 0) | (qy >= (double)g.rows);
+        r = (unsigned)qy;
+        c = (unsigned)qx;
     }
-    if (x < 0 || cx >= (double)g.cols) return true;
-    if (y < 0 || cy >= (double)g.rows) return true;
-    unsigned r = (unsigned)cy;
-    unsigned c = (unsigned)cx;
+    if (outside) return true;
     uint32_t w = g.bits[(size_t)r * g.wpr + (c >> 5)];
     return (w >> (c & 31)) & 1u;
 }
