@@ -295,9 +295,15 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
     // the curve) of the curve's first point, and an obstacle moves at most |Speed| * duration during the sweep: the same
     // kind of exact bound as the per-chunk culling, applied once.
     bool anyObstacle = false;
+    // Up to 64 obstacles: lane i keeps obstacle i's motion for the whole sweep (position at the first step's time, velocity,
+    // squared culling radius), so the per-chunk culling below is a dozen instructions and no loads.  The bound is the one
+    // pp_obstacle_hits_chunk uses (reach + chunk span + |Speed| * chunk time + slack); it only has to be conservative.
+    const bool laneCull = p.n_obst <= PP_WAVE;
+    double oX0 = 0, oY0 = 0, oVx = 0, oVy = 0, oR2 = -1.0, cullT0 = 0;
 #ifndef PP_ABL_NO_OBST
     if (p.n_obst > 0 && p.ng > 0) {
         const double t0 = pp_const_f64(tg)[0];
+        cullT0 = t0;
         const double duration = fmax(endTime - t0, 0.0) + chunkTime;
         const double travel = fmin(cvLength, fmax(endTime - wStart, 0.0) * speed) + 1e-3;
         for (int b = 0; b < p.n_obst && !anyObstacle; b += PP_WAVE) {
@@ -309,6 +315,11 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
                 const double R = o.reach + travel + fabs(o.Speed) * duration + 1e-3;
                 const double dx = cvQx - X, dy = cvQy - Y;
                 near = !(dx * dx + dy * dy > R * R);
+                if (laneCull) {
+                    oX0 = X; oY0 = Y; oVx = o.Speed * o.cosYaw; oVy = o.Speed * o.sinYaw;
+                    const double Rc = o.reach + chunkSpan + fabs(o.Speed) * chunkTime + 2e-3;
+                    oR2 = Rc * Rc;
+                }
             }
             anyObstacle = __ballot(near) != 0ull;
         }
@@ -338,7 +349,19 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
         }
         double dens = 0;
 #ifndef PP_ABL_NO_OBST
-        if (anyObstacle) {                                            // :150-151
+        if (anyObstacle && laneCull) {                                // :150-151
+            // which obstacles can come near this chunk: lane i answers for obstacle i from its registers
+            const double dtc = tFirst - cullT0;
+            const double ddx = pp_readlane(x, 0) - (oX0 + oVx * dtc), ddy = pp_readlane(y, 0) - (oY0 + oVy * dtc);
+            unsigned long long m = __ballot(!(ddx * ddx + ddy * ddy > oR2));      // oR2 = -1 in lanes without an obstacle
+            while (m) {
+                const int j = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (!gaussian) { if (valid) hits += pp_obstacle_hit(p.obst[j], x, y, t); }
+                else dens += pp_obstacle_pdf(reinterpret_cast<const PPGauss*>(p.obst)[j], x, y, t);
+            }
+            if (gaussian) { if (dens < 1e-5) dens = 0; if (!valid) dens = 0; }   // GaussianDynamicObstaclesManager.cpp:11
+        } else if (anyObstacle) {
             if (!gaussian)
                 hits = pp_obstacle_hits_chunk(p.obst, p.n_obst, x, y, t, valid, pp_readlane(x, 0), pp_readlane(y, 0), tFirst, chunkSpan, chunkTime);
             else
@@ -747,7 +770,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
 }
 
 #ifndef PP_POSE_MIN_WAVES
-#define PP_POSE_MIN_WAVES 7
+#define PP_POSE_MIN_WAVES 6
 #endif
 // n_edges = slice size (ppgpu.hip: launch_cost)
 __global__ __launch_bounds__(PP_WPB * 64, PP_POSE_MIN_WAVES) void pp_k_pose_sweep(PPParams p) {
