@@ -401,3 +401,41 @@ def test_gaussian_obstacle_model_matches_oracle(torch_cuda, cov):
     ctx.set_obstacles(workloads.obstacles(4, 9, 150.0, time=float(root["time"][0]), keep_free=(float(root["x"][0]), float(root["y"][0]), 25)))
     b1, _ = _dense(torch_cuda, ctx, 1, n, 0xF)
     assert np.all(b1["collision_penalty"] == np.round(b1["collision_penalty"] / 600.0) * 600.0)
+
+
+@pytest.mark.parametrize("model", ["binary", "gaussian"])
+def test_more_than_64_obstacles(torch_cuda, model):
+    """Up to 64 obstacles live one per lane in the pose sweep's registers; beyond that the culling walks the list in groups of
+    64 from memory.  Same results either way."""
+    from path_planner_amd import api, workloads
+    from path_planner_amd.types import edge_pack
+    from parity import compare_results
+    import oracle as orc
+    w = workloads.config2()
+    root = w.root()
+    x0, y0, t0 = float(root["x"][0]), float(root["y"][0]), float(root["time"][0])
+    n_ob = 150
+    ctx = api.Context(0)
+    ctx.set_config(w.cfg)
+    ctx.set_grid(w.grid, w.res)
+    if model == "binary":
+        ob = workloads.obstacles(n_ob, 21, 204.8, time=t0, width=4.0, length=9.0, keep_free=(x0, y0, 12))
+        ctx.set_obstacles(ob)
+        world = orc.World(w.cfg, w.grid, w.res, ob)
+    else:
+        rng = np.random.default_rng(23)
+        ob = np.column_stack([x0 + rng.uniform(-90, 90, n_ob), y0 + rng.uniform(-90, 90, n_ob), rng.uniform(0, 2 * np.pi, n_ob),
+                              rng.uniform(0, 3, n_ob), np.full(n_ob, t0)])
+        ctx.set_gaussian_obstacles(ob)
+        world = orc.World(w.cfg, w.grid, w.res, gauss=ob)
+    ctx.set_vertices(root, w.ribbons4)
+    ctx.sampler_init(w.bounds6, w.seed, w.ribbons4)
+    n = ctx.sampler_add(512)
+    cs = world.add_samples(w.bounds6, w.seed, w.ribbons4, 0, 512)
+    gpu, gchild = _dense(torch_cuda, ctx, 1, n, 0xF)
+    e = edge_pack(np.zeros(len(gpu), dtype=np.uint64), np.repeat(np.arange(n), 4), np.tile(np.arange(4), n))
+    cpu, cchild = world.cost_edges(root, w.ribbons4, cs[:, 0], cs[:, 1], cs[:, 2], e, stride=8)
+    rep = compare_results(gpu, cpu, gchild, cchild)
+    print(model, rep, "edges with a penalty:", int(np.count_nonzero(cpu["collision_penalty"] > 0)))
+    assert rep["ok"], rep
+    assert np.count_nonzero(cpu["collision_penalty"] > 0) > 50
