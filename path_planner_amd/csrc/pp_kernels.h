@@ -19,7 +19,8 @@ struct PPParams {
     const double* sx; const double* sy; const double* sh; long long n_samples;
     // edges: explicit list, or dense enumeration when edges == nullptr; wedges: edges whose curve is given
     // (Vertex::connect(start, DubinsWrapper, coverageAllowed), Vertex.cpp:28-36) instead of solved
-    const unsigned long long* edges; long long n_edges;
+    const unsigned long long* edges; long long n_edges;   // n_edges: of the current slice; total_edges: of the whole launch
+    long long total_edges;
     const ppgpu_wrapper_edge* wedges;
     int v0, nv; long long s0, ns; unsigned cfg_mask; int per;
     // outputs
@@ -88,6 +89,17 @@ __global__ __launch_bounds__(64) void pp_k_time_grid(const ppgpu_vertex* verts, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Work item w of a launch -> position in the caller's edge list.  Explicit lists are taken in order.  The dense enumeration
+// is walked configuration-major, highest configuration first: the slow-speed configurations are the long edges (most
+// collision-check steps), so the long work is dispatched first and the grid drains on short edges, and the wavefronts of one
+// workgroup get edges of similar length.  Records still land at the position the C ABI documents.
+__device__ __forceinline__ long long pp_edge_position(const PPParams& p, long long w) {
+    if (p.wedges || p.edges) return w;
+    const long long Q = p.total_edges / p.per;          // (vertex, sample) pairs
+    const long long r = w / Q;
+    return (w - r * Q) * p.per + (p.per - 1 - r);
+}
+
 // Which (vertex, target, configuration) edge `e` of the launch is: wrapper list, explicit list or dense enumeration.
 __device__ __forceinline__ void pp_edge_decode(const PPParams& p, long long e, unsigned& vi, unsigned& target, unsigned& cbits) {
     if (p.wedges) {
@@ -117,7 +129,7 @@ __global__ __launch_bounds__(256) void pp_k_solve_edges(PPParams p) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= p.n_edges) return;
     unsigned vi, target, cbits;
-    const long long eg = p.e_base + e;            // position in the caller's edge list; e = position in this slice
+    const long long eg = pp_edge_position(p, p.e_base + e);   // position in the caller's edge list; e = position in this slice
     pp_edge_decode(p, eg, vi, target, cbits);
     PPEdgeSetup* __restrict__ O = p.setup + p.ws_base + e;
     PPCurve cv;
@@ -787,13 +799,13 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep(PP
     __shared__ double lds_all[PP_WPB][PP_WAVE * 4];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long idx = (long long)blockIdx.x * PP_WPB + wave;
-    if (idx < p.n_edges) pp_cover_sweep_edge<false>(p, p.ws_base + idx, p.e_base + idx, lds_all[wave]);
+    if (idx < p.n_edges) pp_cover_sweep_edge<false>(p, p.ws_base + idx, pp_edge_position(p, p.e_base + idx), lds_all[wave]);
 }
 __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep_gaussian(PPParams p) {
     __shared__ double lds_all[PP_WPB][PP_WAVE * 4];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long idx = (long long)blockIdx.x * PP_WPB + wave;
-    if (idx < p.n_edges) pp_cover_sweep_edge<true>(p, p.ws_base + idx, p.e_base + idx, lds_all[wave]);
+    if (idx < p.n_edges) pp_cover_sweep_edge<true>(p, p.ws_base + idx, pp_edge_position(p, p.e_base + idx), lds_all[wave]);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -585,6 +585,7 @@ int64_t ppgpu_dense_edge_count(int32_t nv, int64_t ns, uint32_t cfg_mask) {
 static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     if (p.n_edges <= 0) return PPGPU_OK;
     const long long total = p.n_edges;
+    p.total_edges = total;
     if ((total + PP_WPB - 1) / PP_WPB > 0x3fffffffll) return fail(PPGPU_ECAPACITY, "cost_edges: too many edges for one launch");
     if (!p.child) {
         // the heuristic kernel reads the child ribbon lists: keep them in a scratch the caller never sees
