@@ -762,7 +762,7 @@ double computeApproxToGo(Vertex& v, const Config& cfg) {  // Vertex.cpp:49-64 (p
         unsigned long long NP = 1;
         for (int l = 0; l < n; l++) {
             int rem = n - l;
-            if (NP >= 64ull && l >= n - 2) break;
+            if (NP >= 64ull && l >= n - 3) break;
             NP *= (unsigned long long)(2 * (rem < K ? rem : K));
         }
         return NP < (1ull << 21);

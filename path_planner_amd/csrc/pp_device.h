@@ -817,7 +817,7 @@ __device__ __forceinline__ unsigned long long pp_tsp_prefixes(int n, int K, int&
     Ls = 0;
     for (int l = 0; l < n; l++) {
         const int rem = n - l;
-        if (NP >= 64ull && l >= n - 2) break;
+        if (NP >= 64ull && l >= n - 3) break;
         NP *= (unsigned long long)(2 * (rem < K ? rem : K));
         Ls = l + 1;
     }
@@ -858,7 +858,7 @@ __device__ inline double pp_h_max_distance(const double* pts, int n, double w) {
 // fmin/fmax are exact, so any evaluation order gives the same bits.  Here the first Ls levels
 // (the "prefix", chosen so that there are >= 64 prefixes when the tree is that large) are spread
 // over the lanes — every lane walks ITS prefix with the same control flow, only the digits differ —
-// and the remaining (at most two) levels are enumerated by wave-uniform loops, so that no lane ever
+// and the remaining (at most three) levels are enumerated by wave-uniform loops, so that no lane ever
 // waits for another lane's branch.  Each tree node is sorted once.
 template <int MAXN>
 struct PPTspNode { double sf; typename PPTsp<MAXN>::Ord ord; int pt; };   // accumulated distance, remaining ribbons (4 bits each), current point
@@ -949,7 +949,7 @@ __device__ inline double pp_h_tsp_point(const double* T, const double* KM, int n
     // two suffix levels (those are enumerated by wave-uniform loops below).  All of this is wave-uniform.
     int Ls = 0;
     const unsigned NP = (unsigned)pp_tsp_prefixes(n, K, Ls);     // < 2^21 by the callers' limits
-    const int nsuf = n - Ls;         // 0, 1 or 2
+    const int nsuf = n - Ls;         // 0 .. 3
     double best = PP_DBL_MAX;
     for (unsigned pbase = 0; pbase < NP; pbase += 64u) {
         const unsigned pid = pbase + (unsigned)lane;
@@ -967,25 +967,27 @@ __device__ inline double pp_h_tsp_point(const double* T, const double* KM, int n
             const typename PPTsp<MAXN>::Ord srt = sortK ? pp_tsp_sort<MAXN>(KM, a.ord, rem, a.pt) : a.ord;
             a = pp_tsp_child<MAXN>(T, LEN, a, srt, (int)dg, twoW);
         }
+        // the remaining (at most three) levels: wave-uniform loops, every lane below its own prefix node
         double v = PP_DBL_MAX;
         if (nsuf == 0) {
             v = a.sf;
         } else {
-            const int remA = n - Ls;
+            const int remA = nsuf;
             const int bA = 2 * (remA < K ? remA : K);
             const typename PPTsp<MAXN>::Ord srtA = sortK ? pp_tsp_sort<MAXN>(KM, a.ord, remA, a.pt) : a.ord;
             for (int uA = 0; uA < bA; uA++) {
-                const PPTspNode<MAXN> bnode = pp_tsp_child<MAXN>(T, LEN, a, srtA, uA, twoW);
-                if (nsuf == 1) {
-                    v = fmin(v, bnode.sf);
-                } else {
-                    const int remB = remA - 1;
-                    const int bB = 2 * (remB < K ? remB : K);
-                    const typename PPTsp<MAXN>::Ord srtB = sortK ? pp_tsp_sort<MAXN>(KM, bnode.ord, remB, bnode.pt) : bnode.ord;
-                    for (int uB = 0; uB < bB; uB++) {
-                        const PPTspNode<MAXN> leaf = pp_tsp_child<MAXN>(T, LEN, bnode, srtB, uB, twoW);
-                        v = fmin(v, leaf.sf);
-                    }
+                const PPTspNode<MAXN> nb = pp_tsp_child<MAXN>(T, LEN, a, srtA, uA, twoW);
+                if (nsuf == 1) { v = fmin(v, nb.sf); continue; }
+                const int remB = remA - 1;
+                const int bB = 2 * (remB < K ? remB : K);
+                const typename PPTsp<MAXN>::Ord srtB = sortK ? pp_tsp_sort<MAXN>(KM, nb.ord, remB, nb.pt) : nb.ord;
+                for (int uB = 0; uB < bB; uB++) {
+                    const PPTspNode<MAXN> nc = pp_tsp_child<MAXN>(T, LEN, nb, srtB, uB, twoW);
+                    if (nsuf == 2) { v = fmin(v, nc.sf); continue; }
+                    const int remC = remB - 1;
+                    const int bC = 2 * (remC < K ? remC : K);
+                    const typename PPTsp<MAXN>::Ord srtC = sortK ? pp_tsp_sort<MAXN>(KM, nc.ord, remC, nc.pt) : nc.ord;
+                    for (int uC = 0; uC < bC; uC++) v = fmin(v, pp_tsp_child<MAXN>(T, LEN, nc, srtC, uC, twoW).sf);
                 }
             }
         }

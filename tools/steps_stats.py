@@ -15,3 +15,5 @@ print("infeasible", (r['flags']&1).mean(), "nobst", len(w.obst), "cfg", w.cfg)
 for c in range(4):
     print(c, steps[c::4].mean())
 print(np.percentile(steps,[10,25,50,75,90]))
+nr = (r['info'] >> 8) & 255
+print("child ribbon histogram:", np.bincount(nr), " throws:", int(((r['flags'] & 2) != 0).sum()))
