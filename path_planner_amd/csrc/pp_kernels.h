@@ -646,7 +646,9 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
         }
         int nexec = cnt > lastEv + 1 ? cnt : lastEv + 1;
         nexec = nexec < limit ? nexec : limit;
-        if (blockedAtLimit && nexec == limit) {             // reached the blocked step: `break` at :146
+        // the blocked step is reached only if every step before it ran AND its own time still passes `while (t < endTime)`
+        // (endTime may have shrunk at an event before it, Edge.cpp:169)
+        if (blockedAtLimit && nexec == limit && pp_const_f64(tg + limit)[0] < endTime) {   // `break` at :146
             infeasible = true;
             lastIdx = limit;
             coverFinal = cov || (((pp_const_u64(teq + (limit >> 6))[0] >> (limit & 63)) & 1ull) != 0ull);

@@ -439,3 +439,20 @@ def test_more_than_64_obstacles(torch_cuda, model):
     print(model, rep, "edges with a penalty:", int(np.count_nonzero(cpu["collision_penalty"] > 0)))
     assert rep["ok"], rep
     assert np.count_nonzero(cpu["collision_penalty"] > 0) > 50
+
+
+def test_randomized_worlds(torch_cuda):
+    """tools/fuzz_parity.py: 80 random worlds (grid, obstacle model, ribbons, speeds, radii, horizon, increment, heuristic, start
+    time up to Unix-epoch size) x 640 edges each against the oracle.  Seed 3 contains the case that exposed a blocked step being
+    counted although the edge's end time had shrunk onto that very step (ribbons done, endTime = coverageCompletedTime +
+    timeMinimum landing exactly on a step time)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    import oracle as orc
+    rng = np.random.default_rng(3)
+    bad = [r for r in range(80) if not fz.one_round(rng, r)]
+    orc.O.ppo_set_ribbon_width(1.5)
+    assert not bad, bad

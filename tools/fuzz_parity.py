@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""GPU box: randomized differential test of the HIP path against the CPU oracle.  Each round draws a world (grid density and
+resolution, obstacle model and count, ribbon layout and width, speeds, radii, horizon, increment, heuristic) and a few hundred
+edges, and requires identical flags / word / ribbon counts / step counts and costs within 1e-5.
+usage: tools/fuzz_parity.py [rounds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from path_planner_amd import api, workloads
+from path_planner_amd.types import RESULT_DTYPE, edge_pack, make_config, H_MAX_DISTANCE, H_TSP_POINT_ALL, H_TSP_POINT_K, H_TSP_DUBINS_ALL, H_TSP_DUBINS_K
+from path_planner_amd.workloads import root_vertex
+from parity import compare_results
+import oracle as orc
+
+
+def one_round(rng, rid):
+    size = int(rng.choice([128, 256, 400]))
+    res = float(rng.choice([0.25, 0.5, 1.0]))
+    extent = size * res
+    grid = np.zeros((size, size), dtype=np.uint8)
+    for _ in range(int(rng.integers(0, 12))):
+        a, b = rng.integers(0, size - 20, 2)
+        grid[a:a + rng.integers(4, 20), b:b + rng.integers(4, 20)] = 1
+    cx, cy = extent / 2, extent / 2
+    i0, j0 = int(cy / res), int(cx / res)
+    grid[max(0, i0 - 6):i0 + 6, max(0, j0 - 6):j0 + 6] = 0
+    heur = int(rng.choice([H_MAX_DISTANCE, H_TSP_POINT_ALL, H_TSP_POINT_K, H_TSP_POINT_K, H_TSP_DUBINS_ALL, H_TSP_DUBINS_K]))
+    nrib = int(rng.integers(0, 5 if heur in (H_TSP_POINT_ALL, H_TSP_DUBINS_ALL, H_TSP_DUBINS_K) else 7))
+    rib = []
+    for _ in range(nrib):
+        x, y = rng.uniform(0.2 * extent, 0.8 * extent, 2)
+        L, th = rng.uniform(4, 0.3 * extent), rng.uniform(0, 2 * np.pi)
+        rib.append([x, y, min(max(x + L * np.cos(th), 1), extent - 1), min(max(y + L * np.sin(th), 1), extent - 1)])
+    rib = np.asarray(rib, dtype=np.float64).reshape(-1, 4)
+    t0 = float(rng.choice([0.0, 3.0, 1234.5, 1.6e9]))
+    max_speed = float(rng.choice([1.0, 2.5, 4.0]))
+    kw = dict(start_state_time=t0, heuristic=heur, tsp_k=int(rng.integers(1, 4)), max_speed=max_speed,
+              slow_speed=float(rng.choice([-1.0, 0.5, max_speed])), turning_radius=float(rng.choice([4.0, 8.0, 6.5])),
+              coverage_turning_radius=float(rng.choice([8.0, 16.0, 11.0])), time_horizon=float(rng.choice([8.0, 20.0, 30.0])),
+              time_minimum=float(rng.choice([0.0, 2.0, 5.0])), collision_checking_increment=float(rng.choice([0.05, 0.11, 0.25])),
+              ribbon_width=float(rng.choice([1.0, 1.5, 3.0])), heuristic_turning_radius=float(rng.choice([5.0, 8.0])))
+    cfg = make_config(**kw)
+    orc.O.ppo_set_ribbon_width(cfg.ribbon_width)
+    model = rng.choice(["none", "binary", "binary", "gaussian"])
+    nob = int(rng.integers(1, 90))
+    ctx = api.Context(0)
+    ctx.set_config(cfg); ctx.set_grid(grid, res)
+    if model == "binary":
+        ob = workloads.obstacles(nob, int(rng.integers(1, 1 << 30)), extent, time=t0, width=float(rng.uniform(2, 8)), length=float(rng.uniform(4, 20)),
+                                 keep_free=(cx, cy, 8))
+        ctx.set_obstacles(ob); world = orc.World(cfg, grid, res, ob)
+    elif model == "gaussian":
+        ob = np.column_stack([rng.uniform(0, extent, nob), rng.uniform(0, extent, nob), rng.uniform(0, 2 * np.pi, nob), rng.uniform(0, 3, nob),
+                              np.full(nob, t0)])
+        ctx.set_gaussian_obstacles(ob); world = orc.World(cfg, grid, res, gauss=ob)
+    else:
+        ctx.set_obstacles(None); world = orc.World(cfg, grid, res)
+    root = root_vertex(cx, cy, float(rng.uniform(0, 2 * np.pi)), max_speed, t0 + float(rng.choice([0.0, 0.37])), rib,
+                       cct=(t0 if nrib == 0 else -1.0))
+    n = 160
+    sx, sy, sh = rng.uniform(0.05 * extent, 0.95 * extent, n), rng.uniform(0.05 * extent, 0.95 * extent, n), rng.uniform(0, 2 * np.pi, n)
+    if nrib:                                    # some targets on / along ribbons, where coverage happens
+        for i in range(0, min(n, 40)):
+            r = rib[i % nrib]; u = rng.uniform(0, 1)
+            sx[i], sy[i] = r[0] + u * (r[2] - r[0]), r[1] + u * (r[3] - r[1])
+            sh[i] = (np.pi / 2 - np.arctan2(r[3] - r[1], r[2] - r[0])) % (2 * np.pi) if i % 2 == 0 else sh[i]
+    far = np.hypot(sx - cx, sy - cy) > 2 * cfg.collision_checking_increment
+    sx, sy, sh = sx[far], sy[far], sh[far]
+    n = len(sx)
+    ctx.set_vertices(root, rib); ctx.set_samples(sx, sy, sh)
+    ne = 4 * n
+    d_res = torch.zeros(ne * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
+    d_child = torch.zeros(ne * 20 * 4, dtype=torch.float64, device="cuda:0")
+    ctx.cost_edges_dense(0, 1, 0, n, 0xF, d_res.data_ptr(), d_child.data_ptr(), 20); ctx.synchronize()
+    gpu, gchild = d_res.cpu().numpy().view(RESULT_DTYPE), d_child.cpu().numpy().reshape(ne, 20, 4)
+    e = edge_pack(np.zeros(ne, dtype=np.uint64), np.repeat(np.arange(n), 4), np.tile(np.arange(4), n))
+    cpu, cchild = world.cost_edges(root, rib, sx, sy, sh, e, stride=20)
+    rep = compare_results(gpu, cpu, gchild, cchild)
+    tag = f"round {rid}: grid {size}@{res} rib {nrib} w {cfg.ribbon_width} heur {heur} K {cfg.tsp_k} obst {model}/{nob} t0 {t0} inc {cfg.collision_checking_increment}"
+    print(tag, "->", "ok" if rep["ok"] else "MISMATCH", "worst_rel %.2e" % rep["worst_rel"], "feasible", rep["n_feasible"], "of", rep["n"], flush=True)
+    if not rep["ok"]:
+        print(rep, flush=True)
+        bad = np.nonzero((gpu["flags"] != cpu["flags"]) | (gpu["info"] != cpu["info"]))[0]
+        for b in bad[:6]:
+            print("   edge", int(b), "cfg", int(b) % 4, "flags gpu/cpu", hex(int(gpu["flags"][b])), hex(int(cpu["flags"][b])), "info gpu/cpu (type, nrib, steps)",
+                  (int(gpu["info"][b]) & 255, (int(gpu["info"][b]) >> 8) & 255, int(gpu["info"][b]) >> 16),
+                  (int(cpu["info"][b]) & 255, (int(cpu["info"][b]) >> 8) & 255, int(cpu["info"][b]) >> 16),
+                  "end_time", float(gpu["end_time"][b]), float(cpu["end_time"][b]), "target", float(sx[b // 4]), float(sy[b // 4]), float(sh[b // 4]), flush=True)
+    return rep["ok"]
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    bad = 0
+    t = time.time()
+    for r in range(rounds):
+        bad += 0 if one_round(rng, r) else 1
+    orc.O.ppo_set_ribbon_width(1.5)
+    print(f"{rounds} rounds, {bad} with mismatches, {time.time() - t:.0f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
