@@ -263,6 +263,20 @@ int ppgpu_cost_edges_list(ppgpu_ctx* ctx, int64_t n, const uint64_t* d_edges,
                           ppgpu_edge_result* d_results,
                           double* d_child_ribbons, int32_t ribbon_stride);
 
+/* SamplingBasedPlanner::expand (SamplingBasedPlanner.cpp:52-151) for nv open vertices in ONE round trip: upload the
+ * vertices (as ppgpu_set_vertices), find the k samples of smallest Dubins length per vertex and radius (:85-133), build every
+ * vertex's edges in the order expand() pushes them —
+ *     the vertex's nearest-point-to-cover target (h_nearest, 3 doubles {x, y, heading} per vertex, x = NaN: none; :64-81)
+ *       at each speed {max, slow if distinct} and each radius {turning, coverage if distinct},
+ *     then, per radius, its k winners in ascending Dubins length, each at each speed (:134-149)
+ * — cost them (Vertex::connect + Edge::computeTrueCost + computeApproxToGo) and return descriptors, records and child ribbons
+ * compacted vertex by vertex.  Output arrays hold ppgpu_expand_capacity(nv, k) entries; *n_edges receives the count.
+ * Synchronous; replaces the open-vertex array and the explicit targets of the handle. */
+int64_t ppgpu_expand_capacity(int32_t nv, int32_t k);
+int ppgpu_expand_host(ppgpu_ctx* ctx, int32_t nv, const ppgpu_vertex* h_vertices, int32_t n_ribbons, const double* h_ribbons,
+                      const double* h_nearest, int32_t k, int64_t* n_edges, uint64_t* h_edges, ppgpu_edge_result* h_results,
+                      double* h_child_ribbons, int32_t ribbon_stride);
+
 /* Convenience for small batches (the host planner's <= 40 edges per expansion):
  * host descriptors in, host results out, synchronous. */
 int ppgpu_cost_edges_host(ppgpu_ctx* ctx, int64_t n, const uint64_t* h_edges,

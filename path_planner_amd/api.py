@@ -30,6 +30,8 @@ def _load():
         "ppgpu_last_error": (C.c_char_p, []),
         "ppgpu_set_stream": (C.c_int, [vp, vp]),
         "ppgpu_synchronize": (C.c_int, [vp]),
+        "ppgpu_expand_capacity": (C.c_int64, [i32, i32]),
+        "ppgpu_expand_host": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, C.POINTER(C.c_int64), vp, vp, vp, i32]),
         "ppgpu_enable_timing": (C.c_int, [vp, i32]),
         "ppgpu_last_timing": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]),
         "ppgpu_set_config": (C.c_int, [vp, C.POINTER(PpgpuConfig)]),
@@ -183,6 +185,14 @@ class Context:
     def dubins_lengths(self, v0, nv, d_lengths):
         self._ck(LIB.ppgpu_dubins_lengths(self._h, v0, nv, _ptr(d_lengths)), "ppgpu_dubins_lengths")
 
+    def set_extra_targets(self, x, y, heading):
+        """Explicit (non-sample) targets; returns the index of the first one for edge descriptors."""
+        x, y, heading = [np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, heading)]
+        first = C.c_int64(0)
+        self._ck(LIB.ppgpu_set_extra_targets(self._h, x.shape[0], _ptr(x) if x.shape[0] else None, _ptr(y) if x.shape[0] else None,
+                                             _ptr(heading) if x.shape[0] else None, C.byref(first)), "ppgpu_set_extra_targets")
+        return int(first.value)
+
     def select_nearest(self, v0, nv, k):
         idx = np.zeros((nv, 2, k), dtype=np.int32)
         ln = np.zeros((nv, 2, k), dtype=np.float64)
@@ -196,6 +206,21 @@ class Context:
     def cost_edges_list(self, n, d_edges, d_results, d_child=None, stride=0):
         self._ck(LIB.ppgpu_cost_edges_list(self._h, n, _ptr(d_edges), _ptr(d_results), _ptr(d_child), stride),
                  "ppgpu_cost_edges_list")
+
+    def expand_host(self, vertices, ribbons4, nearest3, k, stride=0):
+        """SamplingBasedPlanner::expand for several vertices in one round trip: (descriptors, records, child ribbons)."""
+        v = np.ascontiguousarray(vertices, dtype=VERTEX_DTYPE)
+        r = np.ascontiguousarray(ribbons4, dtype=np.float64).reshape(-1, 4)
+        nz = np.ascontiguousarray(nearest3, dtype=np.float64).reshape(-1, 3)
+        cap = int(LIB.ppgpu_expand_capacity(v.shape[0], k))
+        e = np.zeros(cap, dtype=np.uint64)
+        res = np.zeros(cap, dtype=RESULT_DTYPE)
+        child = np.zeros((cap, stride, 4), dtype=np.float64) if stride > 0 else None
+        n = C.c_int64(0)
+        self._ck(LIB.ppgpu_expand_host(self._h, v.shape[0], _ptr(v), r.shape[0], _ptr(r) if r.shape[0] else None, _ptr(nz), k, C.byref(n),
+                                       _ptr(e), _ptr(res), _ptr(child), stride), "ppgpu_expand_host")
+        m = n.value
+        return e[:m], res[:m], (child[:m] if child is not None else None)
 
     def cost_edges_host(self, edges, stride=0):
         e = np.ascontiguousarray(edges, dtype=np.uint64)

@@ -995,6 +995,42 @@ __global__ __launch_bounds__(256) void pp_k_select_nearest(const double* lengths
 }
 
 // ------------------------------------------------------------------------------------------
+// The edge list of SamplingBasedPlanner::expand for every open vertex, in its push order (see ppgpu_expand_host): E slots
+// per vertex, unused slots hold an all-ones descriptor (vertex index out of range: the costing kernels skip it).
+__global__ __launch_bounds__(64) void pp_k_build_expand_edges(int nverts, int k, const int* nearest_idx /* [nv][2][k] */, const unsigned char* has_extra,
+                                                             long long first_extra, int two_speeds, int two_radii, int E,
+                                                             unsigned long long* edges) {
+    const int v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= nverts) return;
+    unsigned long long* out = edges + (size_t)v * E;
+    int n = 0;
+    const int nsp = two_speeds ? 2 : 1, nrad = two_radii ? 2 : 1;
+    // coverageAllowed = (radius == coverageTurningRadius): with one radius that single radius IS the coverage radius
+    if (has_extra[v]) {
+        for (int si = 0; si < nsp; si++)
+            for (int ri = 0; ri < nrad; ri++) {
+                const unsigned cov = (two_radii ? ri == 1 : 1) ? PPGPU_EDGE_COVERAGE : 0u;
+                out[n++] = ((unsigned long long)(cov | (si == 1 ? PPGPU_EDGE_SLOW : 0u)) << 56) | ((unsigned long long)v << 32) |
+                           (unsigned long long)(unsigned)(first_extra + v);
+            }
+    }
+    if (nearest_idx) {
+        for (int ri = 0; ri < nrad; ri++) {
+            const unsigned cov = (two_radii ? ri == 1 : 1) ? PPGPU_EDGE_COVERAGE : 0u;
+            const int slot = (ri == 1) ? 1 : 0;           // slot 1 of the selection is always the coverage radius
+            for (int j = 0; j < k; j++) {
+                const int s = nearest_idx[((size_t)v * 2 + slot) * k + j];
+                if (s < 0) break;
+                for (int si = 0; si < nsp; si++)
+                    out[n++] = ((unsigned long long)(cov | (si == 1 ? PPGPU_EDGE_SLOW : 0u)) << 56) | ((unsigned long long)v << 32) |
+                               (unsigned long long)(unsigned)s;
+            }
+        }
+    }
+    for (; n < E; n++) out[n] = ~0ull;
+}
+
+// ------------------------------------------------------------------------------------------
 // Incumbent selection: lexicographic min of (bits of f, edge index) over feasible edges — the
 // batch form of `if (!best || v->f() < best->f()) best = v` (AStarPlanner.cpp:109-117).
 // Stage 1: wave shuffle-reduce + LDS across the 4 waves -> one partial per workgroup;

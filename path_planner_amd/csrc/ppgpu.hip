@@ -101,6 +101,8 @@ struct ppgpu_ctx {
     bool ev_valid = false;
     int max_vertex_ribbons = 0;
     DevBuf<int> tmp_idx;
+    void* stage_in = nullptr; size_t stage_in_cap = 0;      // pinned host staging of ppgpu_expand_host
+    void* stage_out = nullptr; size_t stage_out_cap = 0;
     DevBuf<unsigned long long> gather;
 };
 
@@ -148,6 +150,8 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     c->setup.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
     c->track_summary.release(); c->track_pen.release(); c->track_chunk_pen.release();
+    if (c->stage_in) (void)hipHostFree(c->stage_in);
+    if (c->stage_out) (void)hipHostFree(c->stage_out);
     for (int i = 0; i < 5; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -739,6 +743,127 @@ int ppgpu_cost_wrapper_edges_host(ppgpu_ctx* c, int64_t n, const ppgpu_wrapper_e
     if (h_child)
         HIP_TRY(hipMemcpyAsync(h_child, c->tmp_child.p, (size_t)n * stride * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return PPGPU_OK;
+}
+
+// ------------------------------------------------------------------------------ expand
+int64_t ppgpu_expand_capacity(int32_t nv, int32_t k) {
+    if (nv <= 0) return 0;
+    if (k < 0) k = 0;
+    return (int64_t)nv * (4 + 4 * (int64_t)k);
+}
+
+// grow-only pinned staging: one H2D in, one D2H out per call instead of a dozen pageable copies
+static int stage_reserve(void** p, size_t* cap, size_t n) {
+    if (n <= *cap) return PPGPU_OK;
+    size_t ncap = *cap ? *cap : 4096;
+    while (ncap < n) ncap *= 2;
+    if (*p) HIP_TRY(hipHostFree(*p));
+    *p = nullptr; *cap = 0;
+    HIP_TRY(hipHostMalloc(p, ncap, hipHostMallocDefault));
+    *cap = ncap;
+    return PPGPU_OK;
+}
+
+int ppgpu_expand_host(ppgpu_ctx* c, int32_t nv, const ppgpu_vertex* hv, int32_t n_ribbons, const double* hr, const double* h_nearest,
+                      int32_t k, int64_t* n_edges, uint64_t* h_edges, ppgpu_edge_result* h_results, double* h_child, int32_t stride) {
+    int rc = require_cfg(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (nv <= 0 || !hv || n_ribbons < 0 || (n_ribbons > 0 && !hr) || k < 0 || !n_edges || !h_edges || !h_results)
+        return fail(PPGPU_EINVAL, "expand_host: bad arguments");
+    if (h_child && stride <= 0) return fail(PPGPU_EINVAL, "expand_host: ribbon_stride must be positive");
+    if (nv > 65535) return fail(PPGPU_ECAPACITY, "expand_host: at most 65535 vertices per call");
+    int maxr = 0;
+    for (int i = 0; i < nv; i++) {
+        if (hv[i].ribbon_count < 0 || hv[i].ribbon_offset < 0 || hv[i].ribbon_offset + hv[i].ribbon_count > n_ribbons)
+            return fail(PPGPU_EINVAL, "expand_host: ribbon range outside the pool");
+        if (hv[i].ribbon_count > PP_WAVE) return fail(PPGPU_ECAPACITY, "expand_host: more than 64 ribbons on one vertex");
+        if (hv[i].time < c->cfg.start_state_time) return fail(PPGPU_EINVAL, "expand_host: vertex time before start_state_time");
+        if (hv[i].ribbon_count > maxr) maxr = hv[i].ribbon_count;
+    }
+    const long long ns = c->n_samples;
+    const bool select = ns > 0 && k > 0;
+    const int E = 4 + 4 * k;
+    const long long cap = (long long)nv * E;
+    hipStream_t st = c->stream;
+    // ---- stage in: vertices | ribbons | extra x | extra y | extra heading | has_extra
+    const size_t o_v = 0, o_r = o_v + (size_t)nv * sizeof(ppgpu_vertex), o_x = o_r + (size_t)n_ribbons * 4 * sizeof(double),
+                 o_y = o_x + (size_t)nv * sizeof(double), o_h = o_y + (size_t)nv * sizeof(double), o_f = o_h + (size_t)nv * sizeof(double),
+                 in_bytes = o_f + (size_t)nv;
+    if ((rc = stage_reserve(&c->stage_in, &c->stage_in_cap, in_bytes))) return rc;
+    char* sin = (char*)c->stage_in;
+    std::memcpy(sin + o_v, hv, (size_t)nv * sizeof(ppgpu_vertex));
+    if (n_ribbons > 0) std::memcpy(sin + o_r, hr, (size_t)n_ribbons * 4 * sizeof(double));
+    for (int i = 0; i < nv; i++) {
+        const bool has = h_nearest && !std::isnan(h_nearest[3 * i]);
+        ((double*)(sin + o_x))[i] = has ? h_nearest[3 * i] : 0.0;
+        ((double*)(sin + o_y))[i] = has ? h_nearest[3 * i + 1] : 0.0;
+        ((double*)(sin + o_h))[i] = has ? h_nearest[3 * i + 2] : 0.0;
+        ((unsigned char*)(sin + o_f))[i] = has ? 1 : 0;
+    }
+    const size_t need = (size_t)(ns + nv);
+    if ((rc = c->verts.reserve((size_t)nv, false, st)) || (rc = c->ribbons.reserve((size_t)(n_ribbons > 0 ? n_ribbons : 1) * 4, false, st)) ||
+        (rc = c->tgrid.reserve((size_t)nv * c->ng, false, st)) || (rc = c->sx.reserve(need, true, st)) || (rc = c->sy.reserve(need, true, st)) ||
+        (rc = c->sh.reserve(need, true, st)) || (rc = c->s_bytes.reserve((size_t)nv, false, st)) ||
+        (rc = c->tmp_edges.reserve((size_t)cap, false, st)) || (rc = c->tmp_results.reserve((size_t)cap, false, st)) ||
+        (h_child && (rc = c->tmp_child.reserve((size_t)cap * stride * 4, false, st))))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(c->verts.p, sin + o_v, (size_t)nv * sizeof(ppgpu_vertex), hipMemcpyHostToDevice, st));
+    if (n_ribbons > 0) HIP_TRY(hipMemcpyAsync(c->ribbons.p, sin + o_r, (size_t)n_ribbons * 4 * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->sx.p + ns, sin + o_x, (size_t)nv * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->sy.p + ns, sin + o_y, (size_t)nv * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->sh.p + ns, sin + o_h, (size_t)nv * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->s_bytes.p, sin + o_f, (size_t)nv, hipMemcpyHostToDevice, st));
+    c->nverts = nv; c->nribbons = n_ribbons; c->max_vertex_ribbons = maxr; c->n_extra = nv;
+    hipLaunchKernelGGL(pp_k_time_grid, dim3((unsigned)nv), dim3(64), 0, st, c->verts.p, nv, c->cfg.start_state_time,
+                       c->cfg.collision_checking_increment, c->cfg.max_speed, c->ng, c->tgrid.p);
+    // ---- k nearest per (vertex, radius), on the device
+    if (select) {
+        const size_t nout = (size_t)nv * 2 * k;
+        if ((rc = c->tmp_lengths.reserve((size_t)nv * ns * 2, false, st)) || (rc = c->tmp_idx.reserve(nout, false, st)) ||
+            (rc = c->tmp_len_out.reserve(nout, false, st)))
+            return rc;
+        hipLaunchKernelGGL(pp_k_dubins_lengths, dim3((unsigned)((ns + 255) / 256), (unsigned)nv), dim3(256), 0, st, c->verts.p, 0, c->sx.p, c->sy.p,
+                           c->sh.p, ns, c->cfg.turning_radius, c->cfg.coverage_turning_radius, c->cfg.collision_checking_increment, c->tmp_lengths.p);
+        hipLaunchKernelGGL(pp_k_select_nearest, dim3((unsigned)(nv * 2)), dim3(256), 0, st, c->tmp_lengths.p, ns, k, c->tmp_idx.p, c->tmp_len_out.p);
+    }
+    const double slow = c->cfg.slow_speed <= 0 ? c->cfg.max_speed : c->cfg.slow_speed;     // PlannerConfig::slowSpeed()
+    const int two_speeds = (slow != c->cfg.max_speed) ? 1 : 0;                              // SamplingBasedPlanner.cpp:57-59
+    const int two_radii = (c->cfg.coverage_turning_radius != c->cfg.turning_radius) ? 1 : 0;  // :60-63
+    hipLaunchKernelGGL(pp_k_build_expand_edges, dim3((unsigned)((nv + 63) / 64)), dim3(64), 0, st, nv, k, select ? c->tmp_idx.p : nullptr,
+                       c->s_bytes.p, ns, two_speeds, two_radii, E, c->tmp_edges.p);
+    HIP_TRY(hipGetLastError());
+    // ---- cost the whole list
+    if (h_child) HIP_TRY(hipMemsetAsync(c->tmp_child.p, 0, (size_t)cap * stride * 4 * sizeof(double), st));
+    PPParams p;
+    fill_params(c, p);
+    p.edges = c->tmp_edges.p; p.wedges = nullptr;
+    p.v0 = 0; p.nv = 0; p.s0 = 0; p.ns = 1; p.cfg_mask = 0; p.per = 1;
+    p.n_edges = cap;
+    p.out = c->tmp_results.p; p.child = h_child ? c->tmp_child.p : nullptr; p.stride = stride;
+    if ((rc = launch_cost(c, p))) return rc;
+    // ---- stage out: descriptors | records | child ribbons
+    const size_t q_e = 0, q_r = q_e + (size_t)cap * sizeof(uint64_t), q_c = q_r + (size_t)cap * sizeof(ppgpu_edge_result),
+                 out_bytes = q_c + (h_child ? (size_t)cap * stride * 4 * sizeof(double) : 0);
+    if ((rc = stage_reserve(&c->stage_out, &c->stage_out_cap, out_bytes))) return rc;
+    char* sout = (char*)c->stage_out;
+    HIP_TRY(hipMemcpyAsync(sout + q_e, c->tmp_edges.p, (size_t)cap * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(sout + q_r, c->tmp_results.p, (size_t)cap * sizeof(ppgpu_edge_result), hipMemcpyDeviceToHost, st));
+    if (h_child) HIP_TRY(hipMemcpyAsync(sout + q_c, c->tmp_child.p, (size_t)cap * stride * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t* se = (const uint64_t*)(sout + q_e);
+    const ppgpu_edge_result* sr = (const ppgpu_edge_result*)(sout + q_r);
+    const double* sc = (const double*)(sout + q_c);
+    int64_t n = 0;
+    for (long long i = 0; i < cap; i++) {
+        if (se[i] == ~0ull) continue;
+        h_edges[n] = se[i];
+        h_results[n] = sr[i];
+        if (h_child) std::memcpy(h_child + (size_t)n * stride * 4, sc + (size_t)i * stride * 4, (size_t)stride * 4 * sizeof(double));
+        n++;
+    }
+    *n_edges = n;
     return PPGPU_OK;
 }
 

@@ -237,89 +237,54 @@ int GpuAStarPlanner::costStateEdges(int source, const std::vector<State>& target
 void GpuAStarPlanner::expandBatch(const std::vector<int>& sources) {
     ppgpu_ctx* h = m_Ctx->handle();
     const int M = (int)sources.size();
-    const double speeds[2] = {m_Config.maxSpeed(), m_Config.maxSpeed() == m_Config.slowSpeed() ? -1 : m_Config.slowSpeed()};
-    const double radii[2] = {m_Config.turningRadius(),
-                             m_Config.coverageTurningRadius() == m_Config.turningRadius() ? -1 : m_Config.coverageTurningRadius()};
     // these vertices become the device's open-vertex array
-    {
-        std::vector<ppgpu_vertex> verts((size_t)M);
-        std::vector<double> pool, rib;
-        for (int i = 0; i < M; i++) {
-            verts[i] = makeVertex(m_Nodes[sources[i]]);
-            verts[i].ribbon_offset = (int32_t)(pool.size() / 4);
-            ribbonsToArray(m_Nodes[sources[i]].ribbons, rib);
-            pool.insert(pool.end(), rib.begin(), rib.end());
-        }
-        check(ppgpu_set_vertices(h, M, verts.data(), (int32_t)(pool.size() / 4), pool.empty() ? nullptr : pool.data()), "ppgpu_set_vertices");
+    std::vector<ppgpu_vertex> verts((size_t)M);
+    std::vector<double> pool, rib;
+    int maxParent = 0;
+    for (int i = 0; i < M; i++) {
+        verts[i] = makeVertex(m_Nodes[sources[i]]);
+        verts[i].ribbon_offset = (int32_t)(pool.size() / 4);
+        ribbonsToArray(m_Nodes[sources[i]].ribbons, rib);
+        pool.insert(pool.end(), rib.begin(), rib.end());
+        maxParent = std::max(maxParent, (int)verts[i].ribbon_count);
     }
-    // nearest point to cover (:64-81): one explicit target per vertex that has one
-    std::vector<double> ex, ey, eh;
-    std::vector<long> extraOf((size_t)M, -1);
+    // nearest point to cover (:64-81): one explicit target per vertex that has one (computed on the host, as in the reference)
+    std::vector<double> nearest((size_t)M * 3, std::nan(""));
     for (int i = 0; i < M; i++) {
         const Node& n = m_Nodes[sources[i]];
         if (n.ribbons.done()) continue;
         State s = n.ribbons.getNearestEndpointAsState(n.state);
         if (n.state.distanceTo(s) > m_Config.collisionCheckingIncrement()) {
-            extraOf[i] = (long)ex.size();
-            ex.push_back(s.x()); ey.push_back(s.y()); eh.push_back(s.heading());
+            nearest[3 * i] = s.x(); nearest[3 * i + 1] = s.y(); nearest[3 * i + 2] = s.heading();
         }
     }
-    int64_t first = m_NumSamples;
-    check(ppgpu_set_extra_targets(h, (int32_t)ex.size(), ex.data(), ey.data(), eh.data(), &first), "ppgpu_set_extra_targets");
-    // k best samples by Dubins length per (vertex, radius) (:85-133)
+    // everything else of expand() — k nearest samples per radius, edge list in push order, costing — is one device round trip
     const int k = m_Config.branchingFactor();
-    std::vector<int32_t> idx;
-    if (m_NumSamples > 0 && k > 0) {
-        idx.resize((size_t)M * 2 * k);
-        std::vector<double> len((size_t)M * 2 * k);
-        check(ppgpu_select_nearest(h, 0, M, k, idx.data(), len.data()), "ppgpu_select_nearest");
-    }
-    std::vector<uint64_t> edges;
-    std::vector<unsigned> cfg;
-    std::vector<int> owner;
-    for (int i = 0; i < M; i++) {
-        if (extraOf[i] >= 0) {
-            for (int si = 0; si < 2; si++) {
-                if (speeds[si] <= 0) continue;
-                for (int ri = 0; ri < 2; ri++) {
-                    if (radii[ri] <= 0) continue;
-                    const bool coverageAllowed = radii[ri] == m_Config.coverageTurningRadius();
-                    const unsigned c = (coverageAllowed ? PPGPU_EDGE_COVERAGE : 0u) | (si == 1 ? PPGPU_EDGE_SLOW : 0u);
-                    edges.push_back(ppgpu_edge_pack((uint32_t)i, (uint32_t)(first + extraOf[i]), c));
-                    cfg.push_back(c); owner.push_back(i);
-                }
-            }
-        }
-        // every winner at every speed (:134-149)
-        if (!idx.empty()) {
-            for (int ri = 0; ri < 2; ri++) {
-                if (radii[ri] <= 0) continue;
-                const bool coverageAllowed = radii[ri] == m_Config.coverageTurningRadius();
-                // slot 1 of the device result is always the coverage radius; with equal radii slot 0 IS the coverage radius
-                const int slot = (ri == 1) ? 1 : 0;
-                for (int j = 0; j < k; j++) {
-                    const int32_t s = idx[((size_t)i * 2 + slot) * k + j];
-                    if (s < 0) break;
-                    for (int si = 0; si < 2; si++) {
-                        if (speeds[si] <= 0) continue;
-                        const unsigned c = (coverageAllowed ? PPGPU_EDGE_COVERAGE : 0u) | (si == 1 ? PPGPU_EDGE_SLOW : 0u);
-                        edges.push_back(ppgpu_edge_pack((uint32_t)i, (uint32_t)s, c));
-                        cfg.push_back(c); owner.push_back(i);
-                    }
-                }
-            }
-        }
+    const int64_t cap = ppgpu_expand_capacity(M, k);
+    std::vector<uint64_t> edges((size_t)cap);
+    std::vector<ppgpu_edge_result> res((size_t)cap);
+    std::vector<double> child;
+    int64_t n = 0;
+    int stride = std::min(kRibbonStride, maxParent + 6);
+    for (;;) {
+        child.assign((size_t)cap * stride * 4, 0.0);
+        check(ppgpu_expand_host(h, M, verts.data(), (int32_t)(pool.size() / 4), pool.empty() ? nullptr : pool.data(), nearest.data(), k, &n,
+                                edges.data(), res.data(), child.data(), stride),
+              "ppgpu_expand_host");
+        m_Stats.EdgesCosted += (unsigned long)n;
+        bool retry = false;
+        if (stride < kRibbonStride)
+            for (int64_t i = 0; i < n && !retry; i++)
+                retry = (res[i].flags & PPGPU_F_RIBBON_OVF) && (int)((res[i].info >> 8) & 0xff) > stride;
+        if (!retry) break;
+        stride = kRibbonStride;       // some child does not fit: again at the device's full per-vertex capacity
     }
     for (int i = 0; i < M; i++) m_Speculated[sources[i]];   // an entry even when a vertex has no edges at all
-    const size_t n = edges.size();
-    if (n == 0) return;
-    std::vector<ppgpu_edge_result> res;
-    std::vector<double> child;
-    int maxParent = 0;
-    for (int i = 0; i < M; i++) maxParent = std::max(maxParent, (int)m_Nodes[sources[i]].ribbons.get().size());
-    const int stride = costEdgeList(edges, maxParent, res, child);
-    for (size_t e = 0; e < n; e++)
-        m_Speculated[sources[owner[e]]].push_back(makeChild(sources[owner[e]], cfg[e], res[e], child.data() + e * (size_t)stride * 4));
+    for (int64_t e = 0; e < n; e++) {
+        const int owner = (int)((edges[e] >> 32) & 0xffffffu);
+        const unsigned cfg = (unsigned)(edges[e] >> 56);
+        m_Speculated[sources[owner]].push_back(makeChild(sources[owner], cfg, res[e], child.data() + (size_t)e * stride * 4));
+    }
 }
 
 // expand(source) as the search sees it.  The device answers for `source` and, speculatively, for the open vertices the

@@ -456,3 +456,48 @@ def test_randomized_worlds(torch_cuda):
     bad = [r for r in range(80) if not fz.one_round(rng, r)]
     orc.O.ppo_set_ribbon_width(1.5)
     assert not bad, bad
+
+
+def test_expand_host_equals_the_step_by_step_calls(torch_cuda):
+    """ppgpu_expand_host = set_vertices + set_extra_targets + select_nearest + the edge list of SamplingBasedPlanner::expand +
+    cost_edges_host, in one round trip: same descriptors in the same order, bit-identical records and child ribbons."""
+    from path_planner_amd import workloads
+    from path_planner_amd.types import edge_pack, F_INFEASIBLE
+    w = workloads.config2()
+    ctx, world, n, cs = _setup(w, 1500)
+    gpu, gchild = _dense(torch_cuda, ctx, 1, n, 0xF)
+    pick = np.nonzero((gpu["flags"] & 0x0F) == 0)[0][:9:2]            # a few feasible children as open vertices
+    verts, pool = _children_as_vertices(w, gpu, gchild, pick)          # root + children
+    k = 5
+    nearest = np.full((len(verts), 3), np.nan)
+    nearest[1] = [w.ribbons4[0][0], w.ribbons4[0][1], 0.7]           # only some vertices have a nearest-point target
+    nearest[3] = [w.ribbons4[1][2], w.ribbons4[1][3], 2.1]
+    e1, r1, c1 = ctx.expand_host(verts, pool, nearest, k, stride=8)
+    # the same by hand
+    ctx.set_vertices(verts, pool)
+    has = ~np.isnan(nearest[:, 0])
+    first = ctx.set_extra_targets(nearest[has, 0], nearest[has, 1], nearest[has, 2])
+    slot = np.cumsum(has) - 1
+    idx, _ = ctx.select_nearest(0, len(verts), k)
+    want = []
+    for v in range(len(verts)):
+        if has[v]:
+            for si in range(2):
+                for ri in range(2):
+                    want.append(edge_pack(v, first + slot[v], (1 if ri == 1 else 0) | (2 if si == 1 else 0)))
+        for ri in range(2):
+            for j in range(k):
+                s = idx[v, ri, j]
+                if s < 0:
+                    break
+                for si in range(2):
+                    want.append(edge_pack(v, int(s), (1 if ri == 1 else 0) | (2 if si == 1 else 0)))
+    want = np.array(want, dtype=np.uint64)
+    r2, c2 = ctx.cost_edges_host(want, stride=8)
+    assert len(e1) == len(want)
+    # explicit targets sit at different sample-store indices in the two call sequences; everything else must be identical
+    assert np.array_equal(e1 >> np.uint64(32), want >> np.uint64(32))
+    samp = (want & np.uint64(0xffffffff)) < np.uint64(n)
+    assert np.array_equal(e1[samp], want[samp])
+    assert r1.tobytes() == r2.tobytes() and c1.tobytes() == c2.tobytes()
+    assert np.count_nonzero((r1["flags"] & F_INFEASIBLE) == 0) >= 10
