@@ -131,10 +131,18 @@ def main():
         # sweep's summary (16 B) and its per-chunk words (12 B per 64 steps); poses are recomputed, not stored
         workspace_bytes_per_edge = 384 + 16 + 12.0 * (steps_mean / 64.0)
         traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")   # written from a separate rocprofv3 --pmc pass
+        sweep_hbm = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")   # written from separate rocprofv3 --pmc passes (tools/traffic.sh)
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tp))
+                traffic = tj.get("hbm_bytes_per_launch")
+                # "achieved HBM GB/s on the collision sweep against the chip's peak" (BASELINE north_star): counter bytes of the
+                # pose sweep (collision checks) over its live kernel time.  Low is good here: the sweep is ALU-bound.
+                ps = tj["kernels"]["pp_k_pose_sweep"]
+                nbytes = ps.get("fetch_size_bytes", 0.0) + ps.get("write_size_bytes", 0.0)
+                sweep_hbm = {"kernel": "pp_k_pose_sweep", "pmc_bytes_per_launch": nbytes, "GBps": nbytes / (pose_ms * 1e-3) / 1e9,
+                             "frac_of_peak": nbytes / (pose_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             except Exception:
                 traffic = None
         key = d_key2.cpu().numpy().view(np.uint64)
@@ -159,6 +167,7 @@ def main():
                          "kernels_ms": {"pp_k_solve_edges": solve_ms, "pp_k_pose_sweep": pose_ms, "pp_k_cover_sweep": cover_ms,
                                         "pp_k_heuristic": heur_ms},
                          "algorithmic_bytes_per_edge": bytes_per_edge, "workspace_bytes_per_edge": workspace_bytes_per_edge,
+                         "collision_sweep_hbm": sweep_hbm,
                          "note": "all four kernels are fp64-VALU bound, not HBM bound (SURVEY 8d): see valu_fp64"},
             "valu_fp64": {"achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TFLOPS,
                           "algorithmic_flops_per_edge": flops_per_edge},
