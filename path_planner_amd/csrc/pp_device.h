@@ -579,7 +579,7 @@ __device__ inline int pp_ribbons_event(PPRibbon& r, int n, double w, double x, d
             const double qS = (r.sx - x) * (r.sx - x) + (r.sy - y) * (r.sy - y);
             const double qE = (r.ex - x) * (r.ex - x) + (r.ey - y) * (r.ey - y);
             D = fmin(PP_DBL_MAX, sqrt(pp_min_first_n(act ? fmin(qE, qS) : PP_DBL_MAX, n)));
-            adv = -2;
+            adv = -3;                                                   // like -2 (nothing changed), told apart only by the debug counters
             return n;
         }
     }

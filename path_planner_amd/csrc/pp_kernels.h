@@ -472,7 +472,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
     int dbgEvents = 0;
 #endif
 #ifdef PP_DBG_COUNTS
-    int dbgWindows = 0, dbgCorr = 0, dbgQuiet = 0, dbgGeneric = 0, dbgCorrLen = 0, dbgQuietLen = 0;
+    int dbgWindows = 0, dbgCorr = 0, dbgQuiet = 0, dbgGeneric = 0, dbgCorrLen = 0, dbgQuietLen = 0, dbgFar = 0, dbgNoChange = 0, dbgInPlace = 0;
 #define PP_CNT(x) x
 #else
 #define PP_CNT(x)
@@ -552,6 +552,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                 int adv;
                 PP_CNT(dbgGeneric++);
                 nrib = pp_ribbons_event(rib, nrib, w, xj, yj, ((coverMask >> j) & 1ull) != 0ull, lds, D, adv);
+                PP_CNT(if (adv == -3) dbgFar++; else if (adv == -2) dbgNoChange++; else if (adv >= 0) dbgInPlace++);
                 if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
 #ifndef PP_NO_CORRIDOR_RUN
                 if (adv >= 0 && j + 1 < climit && !runFailed) {
@@ -760,12 +761,13 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
             case 9: v = g; break;
             case 10: v = h; break;
             case 11: v = g + h; break;
-            case 12: v = cct; break;
 #ifdef PP_DBG_COUNTS
+            case 12: v = (double)dbgFar * 1e6 + (double)dbgNoChange * 1e3 + (double)dbgInPlace; break;
             case 13: v = (double)dbgWindows * 1e6 + (double)dbgGeneric; break;
             case 14: v = (double)dbgCorr * 1e6 + (double)dbgCorrLen; break;
             default: v = (double)dbgQuiet * 1e6 + (double)dbgQuietLen; break;
 #else
+            case 12: v = cct; break;
             case 13: v = PP_SF64(p0); break;
             case 14: v = PP_SF64(p1); break;
             default: v = PP_SF64(p2); break;
