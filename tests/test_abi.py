@@ -49,3 +49,15 @@ def test_no_gpu_means_loud_failure_not_a_cpu_fallback():
     from path_planner_amd import api
     with pytest.raises(api.PpgpuError):
         api.Context(0)
+
+
+def test_wire_formats_roundtrip():
+    """path_planner_amd/host Messages.h (the five path_planner_common messages without ROS): plan -> Plan message -> ROS 1
+    bytes -> plan, byte layouts, truncated input.  Host-only C++ (no GPU call)."""
+    import subprocess
+    host = os.path.join(ROOT, "path_planner_amd", "host")
+    exe = os.path.join(host, "msg_roundtrip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", host, "msg_roundtrip"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
