@@ -28,7 +28,7 @@ struct PPParams {
     // A launch may be cut into slices of consecutive edges (n_edges = slice size): e_base = first edge of the slice in
     // the caller's list, ws_base = where the slice's workspace starts.
     long long e_base, ws_base;
-    // workspace: one PPEdgeSetup per edge from pp_k_solve_edges, then the pose sweep's track of each edge
+    // workspace: one PPEdgeSetup per edge from pp_k_solve_edges, then what the pose sweep leaves for the cover sweep
     struct PPEdgeSetup* setup;
     unsigned short* track_hits;          // [edge][ngp]  dynamic-obstacle boxes hit at step k
     unsigned long long* track_eq;        // [edge][nch]  bit k & 63 of word k >> 6: heading(k) == heading(k - 1)
@@ -190,10 +190,10 @@ __global__ __launch_bounds__(256) void pp_k_solve_edges(PPParams p) {
 //                                      at its event steps (ribbon per lane); phase C: end state, last cover, cost, g,
 //                                      one 128-byte record per edge
 //
-// The track (x, y of every step, hit counts, heading-unchanged bits) goes through HBM between the two sweeps.  Fused
-// in one kernel the state machine's registers and the pose pipeline's registers are live together and the loop spills;
-// apart, the pose sweep is a spill-free streaming kernel and the state machine reads only the steps it visits
-// (event poses by scalar load, runs of steps by one coalesced load).
+// Fused in one kernel the state machine's registers and the pose pipeline's registers are live together and the loop
+// spills; apart, the pose sweep is a spill-free streaming kernel.  What it leaves for the cover sweep (the "track") is small:
+// per 64-step chunk a word of heading-unchanged bits and a hit count, per edge where the sweep stopped and why.  The poses
+// themselves are not stored: the cover sweep recomputes them (pp_window_pose, the same code) for the few windows it visits.
 #ifndef PP_WPB
 #define PP_WPB 4   // wavefronts (= edges) per workgroup of the per-edge kernels
 #endif
