@@ -36,6 +36,7 @@ struct PPParams {
     double* track_pen;                   // Gaussian model only: [edge][ngp] collisionExists(step k) ...
     double* track_chunk_pen;             // ... and [edge][nch] its sum times the penalty factor over the chunk's executable steps
     struct PPTrackSummary* track_summary;
+    unsigned* need_big;                  // set by the cover sweep when some child has 9..12 ribbons (pp_k_heuristic_big then has work)
     int ngp, nch;                        // steps per edge rounded up to whole 64-step chunks, and that many chunks
 };
 
@@ -777,6 +778,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
         if (lane < 16) reinterpret_cast<double*>(rec)[lane] = v;
     }
     if (!throwsRef) {
+        if (nrib > PP_TSP_MAX && lane == 0) atomicOr(p.need_big, 1u);
         if (nrib > p.stride && lane == 0) rec->flags = flags | PPGPU_F_RIBBON_OVF;   // after the record store above
         if (lane < nrib && lane < p.stride) {
             double* c = p.child + ((size_t)eg * p.stride + lane) * 4;
@@ -926,6 +928,7 @@ __global__ __launch_bounds__(PP_WPB * 64) void pp_k_heuristic_dubins(PPParams p)
 // TspPointRobotNoSplitKRibbons on child lists of 9..12 ribbons (rare: a vertex whose ribbons were split many times)
 __global__ __launch_bounds__(PP_WPB * 64) void pp_k_heuristic_big(PPParams p) {
     __shared__ double lds_all[PP_WPB][PPTsp<PP_TSP_MAX_BIG>::LDS];
+    if (pp_const_i32(p.need_big)[0] == 0) return;            // almost always: no child list beyond 8 ribbons in this launch
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long e = (long long)blockIdx.x * PP_WPB + wave;
     if (e < p.n_edges) pp_heuristic_edge<false, PP_TSP_MAX_BIG>(p, e, lds_all[wave]);

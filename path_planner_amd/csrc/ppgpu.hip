@@ -95,6 +95,7 @@ struct ppgpu_ctx {
     DevBuf<unsigned long long> track_eq;
     DevBuf<unsigned> track_chunk_hits;
     DevBuf<PPTrackSummary> track_summary;
+    DevBuf<unsigned> need_big;
     DevBuf<double> track_pen, track_chunk_pen;   // Gaussian obstacle model only
     // optional per-kernel timing of costing launches (ppgpu_enable_timing)
     bool timing = false;
@@ -150,7 +151,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->tmp_edges.release(); c->tmp_wedges.release(); c->partial.release(); c->tmp_results.release(); c->tmp_child.release();
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     c->setup.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
-    c->track_summary.release(); c->track_pen.release(); c->track_chunk_pen.release();
+    c->track_summary.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release();
     if (c->stage_in) (void)hipHostFree(c->stage_in);
     if (c->stage_out) (void)hipHostFree(c->stage_out);
     for (int i = 0; i < 5; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -626,6 +627,12 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     p.setup = c->setup.p; p.track_hits = c->track_hits.p; p.track_eq = c->track_eq.p;
     p.track_chunk_hits = c->track_chunk_hits.p; p.track_summary = c->track_summary.p;
     p.track_pen = c->track_pen.p; p.track_chunk_pen = c->track_chunk_pen.p;
+    {
+        int rc = c->need_big.reserve(1, false, c->stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(c->need_big.p, 0, sizeof(unsigned), c->stream));
+        p.need_big = c->need_big.p;
+    }
     for (long long e0 = 0; e0 < total; e0 += slice) {
         p.e_base = e0; p.ws_base = 0; p.n_edges = (total - e0 < slice) ? (total - e0) : slice;
         const unsigned blocks = (unsigned)((p.n_edges + PP_WPB - 1) / PP_WPB);
