@@ -501,3 +501,33 @@ def test_expand_host_equals_the_step_by_step_calls(torch_cuda):
     assert np.array_equal(e1[samp], want[samp])
     assert r1.tobytes() == r2.tobytes() and c1.tobytes() == c2.tobytes()
     assert np.count_nonzero((r1["flags"] & F_INFEASIBLE) == 0) >= 10
+
+
+def test_allreduce_best_on_a_one_rank_communicator(torch_cuda):
+    """ppgpu_allreduce_best loads librccl at run time and does ONE collective (all-gather of 16 bytes per rank) followed by
+    the lexicographic min.  A 1-GPU box can only form a 1-rank communicator: that still exercises the dlopen, the NCCL-ABI
+    call and the reduction kernel on hardware (the N > 1 combination rule is covered by the 2-rank gloo test)."""
+    import ctypes as C
+    from path_planner_amd import api
+    try:
+        rccl = C.CDLL("librccl.so", mode=C.RTLD_GLOBAL)
+    except OSError:
+        rccl = C.CDLL("/opt/rocm/lib/librccl.so", mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        ctx = api.Context(0)
+        key = torch_cuda.tensor([0x4059000000000000, 12345], dtype=torch_cuda.int64, device="cuda:0")   # f = 100.0, edge 12345
+        rc = api.LIB.ppgpu_allreduce_best(ctx._h, comm, C.c_void_p(key.data_ptr()))
+        assert rc == 0, api.LIB.ppgpu_last_error()
+        ctx.synchronize()
+        assert key.cpu().tolist() == [0x4059000000000000, 12345]
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
