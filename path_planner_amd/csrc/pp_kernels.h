@@ -665,30 +665,30 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
         }
     }
 
-    if (lastIdx >= 0) {
-        // `intermediate`'s position at that step: the same sample, every lane on the same step
-        const double tl = pp_const_f64(tg + lastIdx)[0];
-        PP_WINDOW_POSE(S, tl, tl, true, ix, iy);
-    }
-
     // ---- phase C
     // end()->state().time() = endTime; wrapper.sample(end state)  (Edge.cpp:177-178)
     if (!throwsRef && !(wStart <= endTime && wEnd >= endTime)) throwsRef = true;  // DubinsWrapper::containsTime
     double endX = 0, endY = 0, endHeading = 0;
     int hitsTotal = 0;
     if (!throwsRef) {
-        const double cvLength = PP_SF64(length), cvRho = PP_SF64(rho), cvRhoInv = PP_SF64(rho_inv);
-        double dist = (endTime - wStart) * speed;
-        if (dist < 0 || dist > cvLength) dist = dist - 1e-5;
-        if (dist < 0 || dist > cvLength) { flags |= PPGPU_F_DUBINS_ERR; dist = fmin(fmax(dist, 0.0), cvLength); }
-        const double tprime = (cvRhoInv != 0.0) ? dist * cvRhoInv : dist / cvRho;
-        const int es = __builtin_amdgcn_readfirstlane(pp_seg_of(tprime, PP_SF64(seg[0].hi), PP_SF64(seg[1].hi)));
-        const PPSeg cs = pp_seg_load_uniform(&S->seg[es]);
-        double ux, uy, uth;
-        pp_curve_seg(cs.type, (tprime - cs.o1) - cs.o2, cs.bx, cs.by, cs.bth, cs.sb, cs.cb, ux, uy, uth);
-        endX = ux * cvRho + PP_SF64(qx);
-        endY = uy * cvRho + PP_SF64(qy);
-        endHeading = pp_heading_from_yaw(pp_mod2pi(uth));
+        // two samples of the curve in one pass: lane 1 takes the end state's time, every other lane the time of the step
+        // `intermediate` stopped on (its position is needed for the last cover below)
+        {
+            const double tl = (lastIdx >= 0) ? pp_const_f64(tg + lastIdx)[0] : endTime;
+            const PPEdgeSetup* S2 = S;
+            asm volatile("" : "+s"(S2));
+            const PPCurveHot hot = pp_curve_hot(S2);
+            int cur = -1;
+            PPSeg cs = PPSeg{0, 0, 0, 0, 0, INFINITY, -INFINITY, 0, 0, 1, 0};
+            double px, py, puth;
+            bool perr = false;
+            pp_window_pose(S2, hot, cur, cs, lane == 1 ? endTime : tl, tl, true, px, py, puth, perr);
+            if (lastIdx >= 0) { ix = pp_readlane(px, 0); iy = pp_readlane(py, 0); }
+            endX = pp_readlane(px, 1);
+            endY = pp_readlane(py, 1);
+            endHeading = pp_heading_from_yaw(pp_mod2pi(pp_readlane(puth, 1)));
+            if ((__ballot(perr) >> 1) & 1ull) flags |= PPGPU_F_DUBINS_ERR;
+        }
         // cover the last little bit (:182-191)
         if (cov || coverFinal) {
             double Dunused;
