@@ -277,6 +277,13 @@ int ppgpu_expand_host(ppgpu_ctx* ctx, int32_t nv, const ppgpu_vertex* h_vertices
                       const double* h_nearest, int32_t k, int64_t* n_edges, uint64_t* h_edges, ppgpu_edge_result* h_results,
                       double* h_child_ribbons, int32_t ribbon_stride);
 
+/* Vertex::computeApproxToGo (Vertex.cpp:49-64) on its own: h of n poses {x, y, heading}, pose i with its own ribbon list
+ * (h_ribbon_counts[i] ribbons, 4 doubles each, concatenated in h_ribbons), with the configured heuristic.  The root of a
+ * search has no parent edge; this gives it the same arithmetic as every other vertex.  h_out[i] = distance / max_speed *
+ * time_penalty_factor; h_flags[i] (may be NULL) receives PPGPU_F_RIBBON_OVF where the list exceeds the heuristic's limit. */
+int ppgpu_heuristic_host(ppgpu_ctx* ctx, int32_t n, const double* h_poses3, const int32_t* h_ribbon_counts, const double* h_ribbons,
+                         double* h_out, uint32_t* h_flags);
+
 /* Convenience for small batches (the host planner's <= 40 edges per expansion):
  * host descriptors in, host results out, synchronous. */
 int ppgpu_cost_edges_host(ppgpu_ctx* ctx, int64_t n, const uint64_t* h_edges,

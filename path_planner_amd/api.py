@@ -30,6 +30,7 @@ def _load():
         "ppgpu_last_error": (C.c_char_p, []),
         "ppgpu_set_stream": (C.c_int, [vp, vp]),
         "ppgpu_synchronize": (C.c_int, [vp]),
+        "ppgpu_heuristic_host": (C.c_int, [vp, i32, vp, vp, vp, vp, vp]),
         "ppgpu_expand_capacity": (C.c_int64, [i32, i32]),
         "ppgpu_expand_host": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, C.POINTER(C.c_int64), vp, vp, vp, i32]),
         "ppgpu_enable_timing": (C.c_int, [vp, i32]),
@@ -206,6 +207,16 @@ class Context:
     def cost_edges_list(self, n, d_edges, d_results, d_child=None, stride=0):
         self._ck(LIB.ppgpu_cost_edges_list(self._h, n, _ptr(d_edges), _ptr(d_results), _ptr(d_child), stride),
                  "ppgpu_cost_edges_list")
+
+    def heuristic_host(self, poses3, ribbon_lists):
+        """h of each pose {x, y, heading} with its own ribbon list (Vertex::computeApproxToGo); returns (h, flags)."""
+        ps = np.ascontiguousarray(poses3, dtype=np.float64).reshape(-1, 3)
+        counts = np.array([len(r) for r in ribbon_lists], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1, 4) for r in ribbon_lists]) if counts.sum() else np.zeros((0, 4)))
+        out = np.zeros(len(ps), dtype=np.float64)
+        fl = np.zeros(len(ps), dtype=np.uint32)
+        self._ck(LIB.ppgpu_heuristic_host(self._h, len(ps), _ptr(ps), _ptr(counts), _ptr(flat) if len(flat) else None, _ptr(out), _ptr(fl)), "ppgpu_heuristic_host")
+        return out, fl
 
     def expand_host(self, vertices, ribbons4, nearest3, k, stride=0):
         """SamplingBasedPlanner::expand for several vertices in one round trip: (descriptors, records, child ribbons)."""

@@ -686,9 +686,17 @@ __device__ __forceinline__ unsigned long long pp_pieces_in_reach(const PPRibbon&
     return __ballot((lane < n) & !(pp_sq_len(mx, my, x0, y0) > reach * reach));
 }
 
+// cover() erases every piece shorter than the strict minimum length wherever the vehicle is (Ribbon::covered, checked for each
+// ribbon by RibbonManager::cover): while such a piece exists, a step at which cover() runs is never "the same thing again".
+__device__ __forceinline__ bool pp_any_erasable_piece(const PPRibbon& r, int n, double w) {
+    const double minLength = 2 * w;
+    return __ballot((pp_lane() < n) & (pp_sq_len(r.sx, r.sy, r.ex, r.ey) < minLength * minLength / (2.0 * 2.0))) != 0ull;
+}
+
 __device__ inline int pp_corridor_run(const PPRibbon& r, int n, double w, int adv, bool moveEnd, double x, double y, bool stepOk,
                                       unsigned long long coverMask, int first, double span, double& newX, double& newY) {
     const int lane = pp_lane();
+    if (pp_any_erasable_piece(r, n, w)) return 0;      // every step of a corridor run calls cover(): it would erase that piece first
     const double Sx = pp_readlane(r.sx, adv), Sy = pp_readlane(r.sy, adv), Ex = pp_readlane(r.ex, adv), Ey = pp_readlane(r.ey, adv);
     const double g = 1e-9;
     const double dxr = Ex - Sx, dyr = Ey - Sy;
@@ -782,7 +790,8 @@ __device__ inline int pp_quiet_run(const PPRibbon& r, int n, double w, double x,
         }
     }
     const bool coverOn = ((coverMask >> lane) & 1ull) != 0ull;
-    const bool ok = cand & inside & !(maySplit & coverOn);
+    const bool erasable = pp_any_erasable_piece(r, n, w);              // a cover() call at such a step would change the list
+    const bool ok = cand & inside & !((maySplit | erasable) & coverOn);
     const unsigned long long bad = (~__ballot(ok)) >> first;
     return first >= 64 ? 0 : (bad ? (__ffsll((long long)bad) - 1) : (64 - first));
 }

@@ -754,6 +754,56 @@ int ppgpu_cost_wrapper_edges_host(ppgpu_ctx* c, int64_t n, const ppgpu_wrapper_e
     return PPGPU_OK;
 }
 
+// ------------------------------------------------------------------------------ heuristic on its own
+int ppgpu_heuristic_host(ppgpu_ctx* c, int32_t n, const double* poses3, const int32_t* counts, const double* ribbons, double* h_out, uint32_t* h_flags) {
+    int rc = require_cfg(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (n <= 0 || !poses3 || !counts || !h_out) return fail(PPGPU_EINVAL, "heuristic_host: bad arguments");
+    int stride = 1;
+    size_t total = 0;
+    for (int i = 0; i < n; i++) {
+        if (counts[i] < 0 || counts[i] > PP_WAVE) return fail(PPGPU_ECAPACITY, "heuristic_host: between 0 and 64 ribbons per pose");
+        if (counts[i] > stride) stride = counts[i];
+        total += (size_t)counts[i];
+    }
+    if (total > 0 && !ribbons) return fail(PPGPU_EINVAL, "heuristic_host: ribbons are null");
+    // records as the cover sweep would leave them: end pose, g = 0, ribbon count; child ribbons at `stride` per record
+    std::vector<ppgpu_edge_result> rec((size_t)n);
+    std::vector<double> child((size_t)n * stride * 4, 0.0);
+    size_t off = 0;
+    for (int i = 0; i < n; i++) {
+        std::memset(&rec[i], 0, sizeof(ppgpu_edge_result));
+        rec[i].info = (uint32_t)counts[i] << 8;
+        rec[i].end_x = poses3[3 * i]; rec[i].end_y = poses3[3 * i + 1]; rec[i].end_heading = poses3[3 * i + 2];
+        if (counts[i] > 0) std::memcpy(child.data() + (size_t)i * stride * 4, ribbons + off * 4, (size_t)counts[i] * 4 * sizeof(double));
+        off += (size_t)counts[i];
+    }
+    if ((rc = c->tmp_results.reserve((size_t)n, false, c->stream)) || (rc = c->tmp_child.reserve(child.size(), false, c->stream)) ||
+        (rc = c->need_big.reserve(1, false, c->stream)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(c->tmp_results.p, rec.data(), rec.size() * sizeof(ppgpu_edge_result), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tmp_child.p, child.data(), child.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const unsigned one = 1u;       // let the 12-ribbon pass look at every record
+    HIP_TRY(hipMemcpyAsync(c->need_big.p, &one, sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    PPParams p;
+    fill_params(c, p);
+    p.edges = nullptr; p.wedges = nullptr; p.n_edges = n; p.total_edges = n; p.e_base = 0; p.ws_base = 0;
+    p.out = c->tmp_results.p; p.child = c->tmp_child.p; p.stride = stride; p.need_big = c->need_big.p;
+    const dim3 grid((unsigned)((n + PP_WPB - 1) / PP_WPB)), block(PP_WPB * 64);
+    if (p.heuristic == PPGPU_H_TSP_DUBINS_ALL || p.heuristic == PPGPU_H_TSP_DUBINS_K) hipLaunchKernelGGL(pp_k_heuristic_dubins, grid, block, 0, c->stream, p);
+    else hipLaunchKernelGGL(pp_k_heuristic, grid, block, 0, c->stream, p);
+    if (p.heuristic == PPGPU_H_TSP_POINT_K) hipLaunchKernelGGL(pp_k_heuristic_big, grid, block, 0, c->stream, p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rec.data(), c->tmp_results.p, rec.size() * sizeof(ppgpu_edge_result), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++) {
+        h_out[i] = rec[i].h;
+        if (h_flags) h_flags[i] = rec[i].flags;
+    }
+    return PPGPU_OK;
+}
+
 // ------------------------------------------------------------------------------ expand
 int64_t ppgpu_expand_capacity(int32_t nv, int32_t k) {
     if (nv <= 0) return 0;

@@ -531,3 +531,35 @@ def test_allreduce_best_on_a_one_rank_communicator(torch_cuda):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_heuristic_host_matches_oracle(torch_cuda):
+    """ppgpu_heuristic_host = Vertex::computeApproxToGo for a pose and its ribbons, all five heuristics, against
+    RibbonManager::approximateDistanceUntilDone as restated in the oracle (bit-identical for the point-robot heuristics: the
+    arithmetic is sqrt, +, -, fmin, fmax only)."""
+    import oracle as orc
+    from path_planner_amd import api
+    from path_planner_amd.types import make_config, H_MAX_DISTANCE, H_TSP_POINT_ALL, H_TSP_POINT_K, H_TSP_DUBINS_ALL, H_TSP_DUBINS_K, F_RIBBON_OVF
+    rng = np.random.default_rng(8)
+    orc.O.ppo_set_ribbon_width(2.0)
+    try:
+        for heur, K, nmax in ((H_MAX_DISTANCE, 2, 40), (H_TSP_POINT_ALL, 2, 6), (H_TSP_POINT_K, 1, 9), (H_TSP_POINT_K, 2, 9), (H_TSP_POINT_K, 3, 8),
+                              (H_TSP_DUBINS_ALL, 2, 4), (H_TSP_DUBINS_K, 2, 4)):
+            cfg = make_config(heuristic=heur, tsp_k=K, ribbon_width=2.0, max_speed=2.0, heuristic_turning_radius=6.0)
+            ctx = api.Context(0)
+            ctx.set_config(cfg)
+            poses, lists = [], []
+            for _ in range(24):
+                n = int(rng.integers(0, nmax + 1))
+                lists.append(rng.uniform(0, 120, (n, 4)))
+                poses.append([rng.uniform(0, 120), rng.uniform(0, 120), rng.uniform(0, 2 * np.pi)])
+            g, fl = ctx.heuristic_host(poses, lists)
+            for i in range(len(poses)):
+                want = orc.ribbons_heuristic(lists[i], heur, K, poses[i][0], poses[i][1], poses[i][2], 6.0) / 2.0
+                assert (fl[i] & F_RIBBON_OVF) == 0
+                if heur in (H_TSP_DUBINS_ALL, H_TSP_DUBINS_K):
+                    assert abs(g[i] - want) <= 1e-9 * max(1.0, want), (heur, K, i, g[i], want)
+                else:
+                    assert g[i] == want, (heur, K, i, g[i], want)
+    finally:
+        orc.O.ppo_set_ribbon_width(1.5)

@@ -26,11 +26,23 @@ def one_round(rng, rid):
     i0, j0 = int(cy / res), int(cx / res)
     grid[max(0, i0 - 6):i0 + 6, max(0, j0 - 6):j0 + 6] = 0
     heur = int(rng.choice([H_MAX_DISTANCE, H_TSP_POINT_ALL, H_TSP_POINT_K, H_TSP_POINT_K, H_TSP_DUBINS_ALL, H_TSP_DUBINS_K]))
-    nrib = int(rng.integers(0, 5 if heur in (H_TSP_POINT_ALL, H_TSP_DUBINS_ALL, H_TSP_DUBINS_K) else 7))
+    many = heur == H_MAX_DISTANCE and rng.random() < 0.3
+    nrib = int(rng.integers(8, 25)) if many else int(rng.integers(0, 5 if heur in (H_TSP_POINT_ALL, H_TSP_DUBINS_ALL, H_TSP_DUBINS_K) else 7))
     rib = []
-    for _ in range(nrib):
+    for i in range(nrib):
         x, y = rng.uniform(0.2 * extent, 0.8 * extent, 2)
         L, th = rng.uniform(4, 0.3 * extent), rng.uniform(0, 2 * np.pi)
+        kind = rng.random()
+        if kind < 0.12:
+            L = rng.uniform(0.05, 2.5)            # short pieces, some below Ribbon::minLength: erased by the first cover()
+        elif kind < 0.24 and rib:
+            x, y = rib[-1][2], rib[-1][3]         # chained to the previous ribbon's end (shared endpoint)
+        elif kind < 0.32 and rib:
+            px, py, qx, qy = rib[-1]              # parallel to the previous one, closer than a ribbon width
+            nrm = np.hypot(qx - px, qy - py) + 1e-9
+            off = rng.uniform(0.2, 1.0)
+            x, y = px - off * (qy - py) / nrm, py + off * (qx - px) / nrm
+            L, th = nrm, np.arctan2(qy - py, qx - px)
         rib.append([x, y, min(max(x + L * np.cos(th), 1), extent - 1), min(max(y + L * np.sin(th), 1), extent - 1)])
     rib = np.asarray(rib, dtype=np.float64).reshape(-1, 4)
     t0 = float(rng.choice([0.0, 3.0, 1234.5, 1.6e9]))
@@ -38,8 +50,8 @@ def one_round(rng, rid):
     kw = dict(start_state_time=t0, heuristic=heur, tsp_k=int(rng.integers(1, 4)), max_speed=max_speed,
               slow_speed=float(rng.choice([-1.0, 0.5, max_speed])), turning_radius=float(rng.choice([4.0, 8.0, 6.5])),
               coverage_turning_radius=float(rng.choice([8.0, 16.0, 11.0])), time_horizon=float(rng.choice([8.0, 20.0, 30.0])),
-              time_minimum=float(rng.choice([0.0, 2.0, 5.0])), collision_checking_increment=float(rng.choice([0.05, 0.11, 0.25])),
-              ribbon_width=float(rng.choice([1.0, 1.5, 3.0])), heuristic_turning_radius=float(rng.choice([5.0, 8.0])))
+              time_minimum=float(rng.choice([0.0, 2.0, 5.0])), collision_checking_increment=float(rng.choice([0.05, 0.11, 0.25, 0.8])),
+              ribbon_width=float(rng.choice([0.4, 1.0, 1.5, 3.0, 6.0])), heuristic_turning_radius=float(rng.choice([5.0, 8.0])))
     cfg = make_config(**kw)
     orc.O.ppo_set_ribbon_width(cfg.ribbon_width)
     model = rng.choice(["none", "binary", "binary", "gaussian"])
@@ -78,6 +90,10 @@ def one_round(rng, rid):
     cpu, cchild = world.cost_edges(root, rib, sx, sy, sh, e, stride=20)
     dub_h = heur in (H_TSP_DUBINS_ALL, H_TSP_DUBINS_K)     # see DESIGN.md "Numerics": compared by the dedicated tests, not here
     rep = compare_results(gpu, cpu, gchild, cchild, allow_word_ties=True, skip_heuristic=dub_h)
+    if os.environ.get("FUZZ_DUMP") == str(rid):
+        import pickle
+        pickle.dump({"cfg_kw": kw, "grid": grid, "res": res, "model": str(model), "ob": (ob if model != "none" else None), "root": root, "rib": rib,
+                     "sx": sx, "sy": sy, "sh": sh}, open(os.path.join(ROOT, "gpurun_out", "fuzz_case.pkl"), "wb"))
     tag = f"round {rid}: grid {size}@{res} rib {nrib} w {cfg.ribbon_width} heur {heur} K {cfg.tsp_k} obst {model}/{nob} t0 {t0} inc {cfg.collision_checking_increment}"
     print(tag, "->", "ok" if rep["ok"] else "MISMATCH", "worst_rel %.2e" % rep["worst_rel"], "feasible", rep["n_feasible"], "of", rep["n"], flush=True)
     ok2 = True
@@ -130,6 +146,11 @@ def one_round(rng, rid):
     if not rep["ok"]:
         print(rep, flush=True)
         bad = np.nonzero((gpu["flags"] != cpu["flags"]) | (gpu["info"] != cpu["info"]))[0]
+        if len(bad):
+            b = int(bad[0])
+            print("   root", [float(root[k][0]) for k in ("x", "y", "heading", "time")], "ribbons", rib.tolist(), "w", cfg.ribbon_width, flush=True)
+            print("   gpu child", gchild[b, :int((gpu["info"][b] >> 8) & 255)].tolist(), flush=True)
+            print("   cpu child", cchild[b, :int((cpu["info"][b] >> 8) & 255)].tolist(), flush=True)
         for b in bad[:6]:
             print("   edge", int(b), "cfg", int(b) % 4, "flags gpu/cpu", hex(int(gpu["flags"][b])), hex(int(cpu["flags"][b])), "info gpu/cpu (type, nrib, steps)",
                   (int(gpu["info"][b]) & 255, (int(gpu["info"][b]) >> 8) & 255, int(gpu["info"][b]) >> 16),
