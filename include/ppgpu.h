@@ -147,7 +147,9 @@ typedef struct ppgpu_wrapper_edge {
     int32_t type;              /* DubinsPathType                                          */
     int32_t reserved;
     double speed;              /* DubinsWrapper::getSpeed()                               */
-    double start_time;         /* start time of the curve (m_StartTime)                   */
+    double start_time;         /* start time of the curve (m_StartTime); later than the
+                                * vertex's first step: that sample throws, the edge is
+                                * infeasible with 0 steps (Edge.cpp:126-133)             */
     double end_time;           /* getEndTime(), possibly truncated by updateEndTime()     */
 } ppgpu_wrapper_edge;
 

@@ -92,6 +92,13 @@ int ppo_dubins_extract_subpath(const double* path8, double t, double* out8) {
     return e;
 }
 
+// DubinsWrapper::fill(path, speed, startTime) then getEndTime() (DubinsWrapper.cpp:85-94)
+double ppo_wrapper_fill_end_time(const double* path8, double speed, double start_time) {
+    DubinsWrapper w;
+    w.fill(path_from8(path8), speed, start_time);
+    return w.endTime;
+}
+
 // DubinsWrapper(s1, s2, rho) then sample(time): returns 0 ok, 1 = would throw.  out5 = sampled State.
 int ppo_wrapper_sample(const double* s1_5, const double* s2_5, double rho, double new_speed, double time, double* out5,
                        double* end_time) {
@@ -307,22 +314,8 @@ long ppo_add_samples(void* w, const double* b6, uint64_t seed, int n_ribbons, co
 
 // ------------------------------------------------------------------ edges
 static thread_local int g_last_events = 0, g_last_mutations = 0, g_last_kinds[4] = {0, 0, 0, 0};
-static void cost_one(const World& W, const Config& cfg, const ppgpu_vertex* verts, const double* pool,
-                     const double* sx, const double* sy, const double* sh, uint64_t desc, ppgpu_edge_result* out,
-                     double* child, int stride) {
-    uint32_t target = (uint32_t)(desc & 0xffffffffu);
-    uint32_t vi = (uint32_t)((desc >> 32) & 0xffffffu);
-    uint32_t c = (uint32_t)(desc >> 56);
-    const ppgpu_vertex& pv = verts[vi];
-    Vertex src;
-    src.state = State(pv.x, pv.y, pv.heading, pv.speed, pv.time);
-    src.currentCost = pv.g;
-    src.ribbons = make_rm(W, pool + 4 * (size_t)pv.ribbon_offset, pv.ribbon_count, pv.coverage_completed_time);
-    bool cov = (c & PPGPU_EDGE_COVERAGE) != 0;
-    double rho = cov ? cfg.coverageTurningRadius : cfg.turningRadius;
-    double speed = (c & PPGPU_EDGE_SLOW) ? cfg.slowSpeed() : cfg.maxSpeed;
-    State tgt(sx[target], sy[target], sh[target], speed, 0);
-    Vertex end = connectState(src, 0, tgt, rho, cov);
+// computeTrueCost + the record, for an edge whose child vertex has been connected (state edge or wrapper edge)
+static void finish_edge(const World& W, const Config& cfg, Vertex& src, Vertex& end, ppgpu_edge_result* out, double* child, int stride) {
     memset(out, 0, sizeof(*out));
     bool threw = false;
     try {
@@ -367,6 +360,26 @@ static void cost_one(const World& W, const Config& cfg, const ppgpu_vertex* vert
 
 // Vertex::connect(state) + Edge::computeTrueCost for a list of packed edge descriptors.
 // n_threads > 1: static chunking over std::thread (edges are independent).
+
+static void cost_one(const World& W, const Config& cfg, const ppgpu_vertex* verts, const double* pool,
+                     const double* sx, const double* sy, const double* sh, uint64_t desc, ppgpu_edge_result* out,
+                     double* child, int stride) {
+    uint32_t target = (uint32_t)(desc & 0xffffffffu);
+    uint32_t vi = (uint32_t)((desc >> 32) & 0xffffffu);
+    uint32_t c = (uint32_t)(desc >> 56);
+    const ppgpu_vertex& pv = verts[vi];
+    Vertex src;
+    src.state = State(pv.x, pv.y, pv.heading, pv.speed, pv.time);
+    src.currentCost = pv.g;
+    src.ribbons = make_rm(W, pool + 4 * (size_t)pv.ribbon_offset, pv.ribbon_count, pv.coverage_completed_time);
+    bool cov = (c & PPGPU_EDGE_COVERAGE) != 0;
+    double rho = cov ? cfg.coverageTurningRadius : cfg.turningRadius;
+    double speed = (c & PPGPU_EDGE_SLOW) ? cfg.slowSpeed() : cfg.maxSpeed;
+    State tgt(sx[target], sy[target], sh[target], speed, 0);
+    Vertex end = connectState(src, 0, tgt, rho, cov);
+    finish_edge(W, cfg, src, end, out, child, stride);
+}
+
 int ppo_cost_edges(void* w, const ppgpu_vertex* verts, const double* pool, const double* sx, const double* sy,
                    const double* sh, long n, const uint64_t* edges, ppgpu_edge_result* out, double* child_ribbons,
                    int stride, int n_threads) {
@@ -383,6 +396,37 @@ int ppo_cost_edges(void* w, const ppgpu_vertex* verts, const double* pool, const
         std::vector<std::thread> th;
         for (int t = 0; t < n_threads; t++) th.emplace_back(work, n * t / n_threads, n * (t + 1) / n_threads);
         for (auto& t : th) t.join();
+    }
+    return 0;
+}
+
+// Vertex::connect(start, DubinsWrapper, coverageAllowed) + computeTrueCost (Vertex.cpp:28-36, Edge.cpp:208-216): what
+// AStarPlanner::plan does with each segment of the previous plan (AStarPlanner.cpp:46-59).  Same records as ppo_cost_edges.
+int ppo_cost_wrapper_edges(void* w, const ppgpu_vertex* verts, const double* pool, long n, const ppgpu_wrapper_edge* edges,
+                           ppgpu_edge_result* out, double* child_ribbons, int stride) {
+    World* W = (World*)w;
+    if (!W->have_cfg) return -1;
+    Config cfg = make_config(*W);
+    for (long e = 0; e < n; e++) {
+        const ppgpu_wrapper_edge& we = edges[e];
+        const ppgpu_vertex& pv = verts[we.vertex];
+        Vertex src;
+        src.state = State(pv.x, pv.y, pv.heading, pv.speed, pv.time);
+        src.currentCost = pv.g;
+        src.ribbons = make_rm(*W, pool + 4 * (size_t)pv.ribbon_offset, pv.ribbon_count, pv.coverage_completed_time);
+        DubinsPath dp;
+        for (int i = 0; i < 3; i++) { dp.qi[i] = we.qi[i]; dp.param[i] = we.param[i]; }
+        dp.rho = we.rho; dp.type = we.type;
+        memset(out + e, 0, sizeof(*out));
+        try {
+            DubinsWrapper wr;
+            wr.fill(dp, we.speed, we.start_time);   // a negative start time reads as "unset" and throws (DubinsWrapper.cpp:19-22)
+            if (we.end_time < wr.endTime) wr.updateEndTime(we.end_time);
+            Vertex end = connectWrapper(src, 0, wr, we.coverage_allowed != 0);
+            finish_edge(*W, cfg, src, end, out + e, child_ribbons ? child_ribbons + (size_t)e * stride * 4 : nullptr, stride);
+        } catch (SampleError&) {     // sampling the wrapper's end state threw while connecting
+            out[e].flags = PPGPU_F_THROWS | PPGPU_F_INFEASIBLE;
+        }
     }
     return 0;
 }

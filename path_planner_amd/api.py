@@ -240,6 +240,14 @@ class Context:
         self._ck(LIB.ppgpu_cost_edges_host(self._h, e.shape[0], _ptr(e), _ptr(res), _ptr(child), stride), "ppgpu_cost_edges_host")
         return (res, child) if stride > 0 else res
 
+    def cost_wrapper_edges_host(self, wedges, stride=0):
+        from .types import WRAPPER_EDGE_DTYPE
+        e = np.ascontiguousarray(wedges, dtype=WRAPPER_EDGE_DTYPE)
+        res = np.zeros(e.shape[0], dtype=RESULT_DTYPE)
+        child = np.zeros((e.shape[0], stride, 4), dtype=np.float64) if stride > 0 else None
+        self._ck(LIB.ppgpu_cost_wrapper_edges_host(self._h, e.shape[0], _ptr(e), _ptr(res), _ptr(child), stride), "ppgpu_cost_wrapper_edges_host")
+        return (res, child) if stride > 0 else res
+
     @staticmethod
     def dense_edge_count(nv, ns, cfg_mask):
         return LIB.ppgpu_dense_edge_count(nv, ns, cfg_mask)

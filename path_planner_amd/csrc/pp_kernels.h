@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void pp_k_solve_edges(PPParams p) {
 // per-edge result of the pose sweep
 struct PPTrackSummary {
     int limit;      // steps [0, limit) can execute: the first blocked step, or the first step at/after the edge's end time
-    int blocked;    // 1: step `limit` exists and is blocked (Edge.cpp:144-147)
+    int blocked;    // 1: step `limit` exists and is blocked (Edge.cpp:144-147); 2: sampling step 0 threw (limit = 0, :126-133)
     int dub_err;    // some sampled arc length fell outside the curve even after the reference's 1e-5 retry
     int pad;
 };
@@ -289,11 +289,20 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
     const PPCurveHot hot = pp_curve_hot(S);
     const double wEnd = PP_SF64(wEnd), wStart = hot.wStart, speed = hot.speed, cvLength = hot.length, cvQx = hot.qx, cvQy = hot.qy;
     const double endTime = fmin(p.horizon + 1e-12 + p.sst, wEnd);    // Edge.cpp:90 (the cover sweep may end the edge earlier)
+    const double* tg = p.tgrid + (size_t)vi * p.ng;
+    if (p.wedges && p.ng > 0) {
+        // a given curve that starts after the vertex's first step: DubinsWrapper::sample throws at that step, the loop
+        // catches it, marks the edge infeasible and stops without counting the step (Edge.cpp:126-133)
+        const double t0 = pp_const_f64(tg)[0];
+        if (t0 < endTime && t0 < wStart) {
+            if (lane == 0) { sum->limit = 0; sum->blocked = 2; sum->dub_err = 0; sum->pad = 0; }
+            return;
+        }
+    }
     // the segment of the curve the sweep is on: its constants live in scalar registers, the other two stay in memory
     int cur = 0;
     PPSeg cs = pp_seg_load_uniform(&S->seg[0]);
 
-    const double* tg = p.tgrid + (size_t)vi * p.ng;
     unsigned short* thits = p.track_hits + (size_t)e * p.ngp;
     unsigned long long* teq = p.track_eq + (size_t)e * p.nch;
     unsigned* tch = p.track_chunk_hits + (size_t)e * p.nch;
@@ -464,7 +473,8 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
     // ---- the pose sweep's track of this edge
     const PPTrackSummary* sum = p.track_summary + e;
     const int limit = pp_const_i32(&sum->limit)[0];
-    const bool blockedAtLimit = pp_const_i32(&sum->blocked)[0] != 0;
+    const int stopKind = pp_const_i32(&sum->blocked)[0];
+    const bool blockedAtLimit = stopKind == 1;
     if (pp_const_i32(&sum->dub_err)[0]) flags |= PPGPU_F_DUBINS_ERR;
     const unsigned long long* teq = p.track_eq + (size_t)e * p.nch;
     const double* tg = p.tgrid + (size_t)vi * p.ng;
@@ -657,7 +667,8 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
             tfinal = pp_const_f64(tg + limit)[0];
             steps = limit + 1;
             hexec = limit;
-        } else {                                            // loop condition failed
+        } else {                                            // loop condition failed, or the first sample threw
+            if (stopKind == 2 && pp_const_f64(tg)[0] < endTime) infeasible = true;   // `intermediate` still holds the source pose
             lastIdx = nexec - 1;
             tfinal = (nexec < p.ng) ? pp_const_f64(tg + nexec)[0] : INFINITY;
             steps = nexec;

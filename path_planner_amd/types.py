@@ -54,6 +54,13 @@ RESULT_DTYPE = np.dtype([
 ])
 assert RESULT_DTYPE.itemsize == 128
 
+# struct ppgpu_wrapper_edge, 96 bytes
+WRAPPER_EDGE_DTYPE = np.dtype([
+    ("vertex", "<i4"), ("coverage_allowed", "<i4"), ("qi", "<f8", (3,)), ("param", "<f8", (3,)), ("rho", "<f8"),
+    ("type", "<i4"), ("reserved", "<i4"), ("speed", "<f8"), ("start_time", "<f8"), ("end_time", "<f8"),
+])
+assert WRAPPER_EDGE_DTYPE.itemsize == 96
+
 
 def edge_pack(vertex, target, cfg):
     """ppgpu_edge_pack()."""

@@ -49,6 +49,8 @@ for _n, _r, _a in [
     ("ppo_dubins_path_sample", i32, [vp, dbl, vp]),
     ("ppo_dubins_extract_subpath", i32, [vp, dbl, vp]),
     ("ppo_wrapper_sample", i32, [vp, vp, dbl, dbl, dbl, vp, vp]),
+    ("ppo_wrapper_fill_end_time", dbl, [vp, dbl, dbl]),
+    ("ppo_cost_wrapper_edges", i32, [vp, vp, vp, C.c_long, vp, vp, vp, i32]),
     ("ppo_state_yaw", dbl, [dbl]),
     ("ppo_state_heading_to", dbl, [dbl, dbl, dbl, dbl]),
     ("ppo_state_move", None, [vp, dbl]),
@@ -162,6 +164,21 @@ class World:
         out = np.zeros(e.shape[0], dtype=RESULT_DTYPE)
         child = np.zeros((e.shape[0], stride, 4), dtype=np.float64) if stride > 0 else None
         rc = O.ppo_cost_edges(self.h, _p(v), _p(r), _p(sx), _p(sy), _p(sh), e.shape[0], _p(e), _p(out), _p(child), stride, threads)
+        assert rc == 0
+        return (out, child) if stride > 0 else out
+
+    def cost_wrapper_edges(self, vertices, ribbons4, wedges, stride=0):
+        """Vertex::connect(start, DubinsWrapper, coverageAllowed) + computeTrueCost per ppgpu_wrapper_edge."""
+        from path_planner_amd.types import WRAPPER_EDGE_DTYPE
+        O.ppo_world_set_config(self.h, C.byref(self.cfg))
+        v = np.ascontiguousarray(vertices, dtype=VERTEX_DTYPE)
+        r = f64(ribbons4).reshape(-1, 4)
+        if r.shape[0] == 0:
+            r = np.zeros((1, 4))
+        e = np.ascontiguousarray(wedges, dtype=WRAPPER_EDGE_DTYPE)
+        out = np.zeros(e.shape[0], dtype=RESULT_DTYPE)
+        child = np.zeros((e.shape[0], stride, 4), dtype=np.float64) if stride > 0 else None
+        rc = O.ppo_cost_wrapper_edges(self.h, _p(v), _p(r), e.shape[0], _p(e), _p(out), _p(child), stride)
         assert rc == 0
         return (out, child) if stride > 0 else out
 

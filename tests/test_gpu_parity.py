@@ -563,3 +563,23 @@ def test_heuristic_host_matches_oracle(torch_cuda):
                     assert g[i] == want, (heur, K, i, g[i], want)
     finally:
         orc.O.ppo_set_ribbon_width(1.5)
+
+
+def test_wrapper_edges_match_oracle(torch_cuda):
+    """ppgpu_cost_wrapper_edges_host (AStarPlanner.cpp:46-59: the previous plan's segments re-costed): curves handed over as
+    DubinsWrapper fields, from the root and from children, entered part-way along, cut short by updateEndTime, at a foreign
+    speed, and starting late (first sample throws -> infeasible, Edge.cpp:126-133); world of config 3 with grid and obstacles."""
+    import importlib.util
+    import os
+    from path_planner_amd import workloads
+    from path_planner_amd.types import F_INFEASIBLE, F_GOAL
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    w = workloads.config3(n_samples=512)
+    ctx, world, n, cs = _setup(w, 512)
+    gpu, gchild = _dense(torch_cuda, ctx, 1, n, 0xF)
+    feas = np.nonzero(((gpu["flags"] & F_INFEASIBLE) == 0) & ((gpu["flags"] & F_GOAL) == 0))[0]
+    verts, pool = _children_as_vertices(w, gpu, gchild, feas[:: max(1, len(feas) // 30)][:30])
+    rng = np.random.default_rng(17)
+    assert fz.wrapper_leg(rng, ctx, world, w.cfg, verts, pool, cs[:, 0], cs[:, 1], cs[:, 2], False, per_vertex=40)

@@ -272,3 +272,35 @@ def test_heuristic_consistency_along_ribbon():
             checked += 1
             t += 1
         assert checked >= 25
+
+
+# ------------------------------------------------------------------ edges whose curve is given
+def test_wrapper_edge_equals_state_edge_and_truncates():
+    """Vertex::connect(start, DubinsWrapper, coverageAllowed) (Vertex.cpp:28-36, Edge.cpp:208-216) with the shortest path to a
+    state is the same edge as connect(start, state); with updateEndTime (DubinsWrapper.cpp:100-104) it stops early; a curve that
+    starts after the vertex's first step is infeasible with no step counted (the sample throws inside Edge.cpp:126-133)."""
+    from path_planner_amd.types import WRAPPER_EDGE_DTYPE
+    cfg = make_config(start_state_time=1.0)
+    rib = orc.ribbons_add([], 0, 10, 0, 40)
+    root5 = [0, 0, 0, 2.5, 1]
+    tgt = [3.0, 30.0, 0.4]
+    ref, refchild = cost_edge(cfg, root5, rib, tgt)
+    world = orc.World(cfg)
+    v = root_vertex(*root5, np.asarray(rib).reshape(-1, 4))
+    q0 = [0.0, 0.0, orc.O.ppo_state_yaw(0.0)]
+    q1 = [tgt[0], tgt[1], orc.O.ppo_state_yaw(tgt[2])]
+    err, p8 = orc.dubins_shortest_path(q0, q1, cfg.turning_radius)
+    assert err == 0
+    end = orc.O.ppo_wrapper_fill_end_time(p8.ctypes.data, 2.5, 1.0)
+
+    def wedge(start, stop):
+        return np.array([(0, 0, p8[0:3], p8[3:6], p8[6], int(p8[7]), 0, 2.5, start, stop)], dtype=WRAPPER_EDGE_DTYPE)
+
+    r, child = world.cost_wrapper_edges(v, rib, wedge(1.0, end), stride=8)
+    assert r[0].tobytes() == ref.tobytes() and child[0].tobytes() == refchild.tobytes()
+    cut = 1.0 + 0.5 * (end - 1.0)
+    r, _ = world.cost_wrapper_edges(v, rib, wedge(1.0, cut), stride=8)
+    assert r["end_time"][0] == cut and not (r["flags"][0] & F_INFEASIBLE)
+    assert double_eq(r["approx_cost"][0], cut - 1.0) and (r["info"][0] >> 16) < (ref["info"] >> 16)
+    r, _ = world.cost_wrapper_edges(v, rib, wedge(1.5, orc.O.ppo_wrapper_fill_end_time(p8.ctypes.data, 2.5, 1.5)), stride=8)
+    assert (r["flags"][0] & F_INFEASIBLE) and (r["info"][0] >> 16) == 0
