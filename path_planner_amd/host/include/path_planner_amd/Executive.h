@@ -42,7 +42,10 @@ public:
     void startPlanner();
     void cancelPlanner();
     void terminate();
-    void setPlannerVisualization(bool, const std::string&) {}   // no visualisation stream on the device path
+    void setPlannerVisualization(bool visualize, const std::string& visualizationFilePath) {   // executive.cpp:443-449
+        m_PlannerConfig.setVisualizations(visualize);
+        if (visualize) m_PlannerConfig.setVisualizer(std::make_shared<Visualizer>(visualizationFilePath));
+    }
     // this build's knobs
     void setPlanningTimeSeconds(double s) { m_PlanningTimeSeconds = s; }   // reference: c_PlanningTimeSeconds = 0.85 (executive.h:183)
     void setSpeculation(int n) { m_PlannerConfig.setSpeculation(n); }

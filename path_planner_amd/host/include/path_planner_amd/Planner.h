@@ -79,6 +79,7 @@ public:
         bool coverageAllowed = false;
         bool infeasible = false;
         double collisionPenalty = 0;
+        int steps = 0;             // collision-check steps the edge's sweep executed (visualisation only)
         DubinsWrapper wrapper;     // parent edge's curve
         double f() const { return g + h; }
     };
@@ -104,8 +105,13 @@ private:
     int aStar(double endTime);
     void addSamples(long n);
     int depth(int v) const;
-    DubinsPlan tracePlan(int v);
+    DubinsPlan tracePlan(int v, bool addToStats = true);
     void check(int rc, const char* what) const;
+    // the reference's search dump (SamplingBasedPlanner.cpp:210-238, Edge.cpp:122-143); no-ops unless the config enables it
+    void visualizeVertex(int v, const char* tag, bool expanded);
+    void visualizeTrajectory(const Node& child);
+    void visualizePlan(const DubinsPlan& plan);
+    void visualizeSamples();
     int costStateEdges(int source, const std::vector<State>& targets, const std::vector<unsigned>& cfgBits,
                        const std::vector<long>& sampleIndex);
 };

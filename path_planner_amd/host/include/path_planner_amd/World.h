@@ -7,6 +7,7 @@
 #pragma once
 #include <cfloat>
 #include <cstdint>
+#include <fstream>
 #include <functional>
 #include <iostream>
 #include <memory>
@@ -126,6 +127,17 @@ private:
     std::unordered_set<uint32_t> m_Ignored;
 };
 
+// Visualizer.h: owns the file the search is dumped to (the text format visualizer.py:485-547 reads)
+class Visualizer {
+public:
+    typedef std::shared_ptr<Visualizer> SharedPtr;
+    explicit Visualizer(const std::string& path) { m_File.open(path, std::ios::trunc | std::ios::out); }
+    std::ostream& stream() { return m_File; }
+
+private:
+    std::ofstream m_File;
+};
+
 class PlannerConfig {
 public:
     explicit PlannerConfig(std::ostream* output) : m_Output(output) {}
@@ -162,8 +174,13 @@ public:
     // reference's call pattern).  Results do not depend on it, only when the arithmetic happens.
     int speculation() const { return m_Speculation; }
     void setSpeculation(int n) { m_Speculation = n < 1 ? 1 : n; }
-    // the reference's visualisation stream is not available on the device path
-    bool visualizations() const { return false; }
+    // PlannerConfig.h:60-80,116-118: the search dump.  The device keeps no per-step poses, so the planner rebuilds the
+    // "Trajectory:" samples of an edge on the host from the child's curve when (and only when) this is on.
+    bool visualizations() const { return m_Visualizations && (m_Visualizer || m_VisualizationStream); }
+    void setVisualizations(bool v) { m_Visualizations = v; }
+    void setVisualizer(Visualizer::SharedPtr v) { m_Visualizer = std::move(v); }
+    void setVisualizationStream(std::ostream* s) { m_VisualizationStream = s; }   // any stream instead of a file
+    std::ostream& visualizationStream() const { return m_Visualizer ? m_Visualizer->stream() : *m_VisualizationStream; }
 
 private:
     int m_BranchingFactor = 9;
@@ -173,6 +190,9 @@ private:
     double m_CollisionCheckingIncrement = 0.05;
     int m_InitialSamples = 100;
     bool m_UseBrownPaths = false;
+    bool m_Visualizations = false;
+    Visualizer::SharedPtr m_Visualizer;
+    std::ostream* m_VisualizationStream = nullptr;
     Map::SharedPtr m_Map;
     DynamicObstaclesManager::SharedPtr m_ObstaclesManager = std::make_shared<DynamicObstaclesManager>();
     std::ostream* m_Output;

@@ -118,7 +118,75 @@ void GpuAStarPlanner::pushVertexQueue(int vi) {   // SamplingBasedPlanner.cpp:7-
     if (m_Best >= 0 && m_Nodes[m_Best].f() == v.f() && goalCondition(v)) return;
     m_Queue.push_back(vi);
     std::push_heap(m_Queue.begin(), m_Queue.end(), [&](int a, int b) { return m_Nodes[a].f() > m_Nodes[b].f(); });
+    visualizeVertex(vi, "vertex", false);
     m_Stats.Generated++;
+}
+
+// ------------------------------------------------------------------------------------------------ search dump
+// "Generated|Expanded State: (x y heading speed time), f: F, g: G, h: H tag id id ... " — Vertex::toString (Vertex.cpp:114-119)
+// plus the chain of vertex identities from the root (the reference prints object addresses, Vertex.cpp:140-143; here the
+// identity is the node's index + 1: visualizer.py only needs a distinct integer per vertex).
+void GpuAStarPlanner::visualizeVertex(int vi, const char* tag, bool expanded) {
+    if (!m_Config.visualizations()) return;
+    const Node& v = m_Nodes[vi];
+    std::vector<int> chain;
+    for (int cur = vi; cur >= 0; cur = m_Nodes[cur].parent) chain.push_back(cur);
+    std::ostream& o = m_Config.visualizationStream();
+    o << (expanded ? "Expanded " : "Generated ") << "State: (" << v.state.toStringRad() << "), f: " << v.g + v.h << ", g: " << v.g
+      << ", h: " << v.h << " " << tag << " ";
+    for (auto it = chain.rbegin(); it != chain.rend(); ++it) o << (*it + 1) << " ";
+    o << std::endl;
+}
+
+// What Edge::computeTrueCost streams while it sweeps (Edge.cpp:122-143): "Trajectory:" and every int(1/increment)+1-th sampled
+// state with the cost accrued so far (start g + time so far + collision penalty of the steps before it) and the START vertex's
+// h.  Rebuilt here from the child's curve, the same time grid (:114-120) and the host obstacle manager.
+void GpuAStarPlanner::visualizeTrajectory(const Node& child) {
+    if (!m_Config.visualizations() || child.parent < 0) return;
+    const Node& src = m_Nodes[child.parent];
+    std::ostream& o = m_Config.visualizationStream();
+    o << "Trajectory:" << std::endl;
+    const double timeIncrement = m_Config.collisionCheckingIncrement() / m_Config.maxSpeed();
+    State intermediate(src.state);
+    intermediate.time() += std::fmod(intermediate.time() - m_StartStateTime, timeIncrement);
+    int visCount = int(1.0 / m_Config.collisionCheckingIncrement());
+    double collisionPenalty = 0;
+    for (int k = 0; k < child.steps; k++) {
+        try {
+            child.wrapper.sample(intermediate);
+        } catch (std::runtime_error&) {
+            break;
+        }
+        if (visCount-- <= 0) {
+            visCount = int(1.0 / m_Config.collisionCheckingIncrement());
+            const double gSoFar = src.g + (intermediate.time() - src.state.time()) + collisionPenalty;
+            o << "State: (" << intermediate.toStringRad() << "), f: " << gSoFar + src.h << ", g: " << gSoFar << ", h: " << src.h
+              << " trajectory" << std::endl;
+        }
+        collisionPenalty += m_Config.obstaclesManager().collisionExists(intermediate, true) * kCollisionPenaltyFactor;
+        intermediate.time() += timeIncrement;
+    }
+}
+
+void GpuAStarPlanner::visualizePlan(const DubinsPlan& plan) {   // SamplingBasedPlanner.cpp:227-238: one state per second
+    if (!m_Config.visualizations() || plan.empty()) return;
+    State s;
+    s.time() = plan.getStartTime();
+    while (s.time() < plan.getEndTime()) {
+        plan.sample(s);
+        m_Config.visualizationStream() << "State: (" << s.toStringRad() << "), f: " << 0 << ", g: " << 0 << ", h: " << 0 << " plan" << std::endl;
+        s.time() += 1;
+    }
+}
+
+void GpuAStarPlanner::visualizeSamples() {   // AStarPlanner.cpp:103-108: every sample, every iteration (read back from the device)
+    if (!m_Config.visualizations() || m_NumSamples <= 0) return;
+    std::vector<double> s5((size_t)m_NumSamples * 5);
+    check(ppgpu_get_samples(m_Ctx->handle(), 0, m_NumSamples, s5.data()), "ppgpu_get_samples");
+    for (long i = 0; i < m_NumSamples; i++) {
+        State s(s5[5 * i], s5[5 * i + 1], s5[5 * i + 2], s5[5 * i + 3], s5[5 * i + 4]);
+        m_Config.visualizationStream() << "State: (" << s.toStringRad() << "), f: " << 0 << ", g: " << 0 << ", h: " << 0 << " sample" << std::endl;
+    }
 }
 
 int GpuAStarPlanner::popVertexQueue() {   // :21-27
@@ -164,6 +232,7 @@ GpuAStarPlanner::Node GpuAStarPlanner::makeChild(int source, unsigned cfgBits, c
     c.coverageAllowed = (cfgBits & PPGPU_EDGE_COVERAGE) != 0;
     c.infeasible = (r.flags & PPGPU_F_INFEASIBLE) != 0;
     c.collisionPenalty = r.collision_penalty;
+    c.steps = (int)(r.info >> 16);
     c.g = r.g;
     c.h = r.h;
     c.ribbons = src.ribbons;   // keeps heuristic, K, turning radius
@@ -226,6 +295,7 @@ int GpuAStarPlanner::costStateEdges(int source, const std::vector<State>& target
     const int stride = costEdgeList(edges, (int)m_Nodes[source].ribbons.get().size(), res, child);
     for (size_t i = 0; i < n; i++) {
         m_Nodes.push_back(makeChild(source, cfgBits[i], res[i], child.data() + i * (size_t)stride * 4));
+        visualizeTrajectory(m_Nodes.back());
         pushVertexQueue((int)m_Nodes.size() - 1);
     }
     return (int)n;
@@ -292,6 +362,7 @@ void GpuAStarPlanner::expandBatch(const std::vector<int>& sources) {
 // is pushed, and in which order, is exactly what expanding one vertex at a time would push: speculation only changes when
 // the arithmetic happens.  Nothing survives a change of the sample set (m_Speculated is cleared by addSamples).
 void GpuAStarPlanner::expand(int source) {
+    visualizeVertex(source, "vertex", true);
     auto it = m_Speculated.find(source);
     if (it == m_Speculated.end()) {
         std::vector<int> batch{source};
@@ -314,6 +385,7 @@ void GpuAStarPlanner::expand(int source) {
     m_Speculated.erase(it);
     for (Node& c : children) {
         m_Nodes.push_back(std::move(c));
+        visualizeTrajectory(m_Nodes.back());   // in the reference each edge streams its sweep, then its vertex is pushed
         pushVertexQueue((int)m_Nodes.size() - 1);
     }
     m_Stats.Expanded++;
@@ -322,7 +394,10 @@ void GpuAStarPlanner::expand(int source) {
 int GpuAStarPlanner::aStar(double endTime) {   // AStarPlanner.cpp:134-148
     int vertex = popVertexQueue();
     while (now() < endTime) {
-        if (goalCondition(m_Nodes[vertex])) return vertex;
+        if (goalCondition(m_Nodes[vertex])) {
+            visualizeVertex(vertex, "vertex", false);
+            return vertex;
+        }
         expand(vertex);
         if (m_Queue.empty()) return -1;
         vertex = popVertexQueue();
@@ -330,7 +405,7 @@ int GpuAStarPlanner::aStar(double endTime) {   // AStarPlanner.cpp:134-148
     return -1;
 }
 
-DubinsPlan GpuAStarPlanner::tracePlan(int v) {   // Planner.cpp:12-32
+DubinsPlan GpuAStarPlanner::tracePlan(int v, bool addToStats) {   // Planner.cpp:12-32
     DubinsPlan plan;
     if (v < 0) return plan;
     std::vector<int> branch;
@@ -339,7 +414,7 @@ DubinsPlan GpuAStarPlanner::tracePlan(int v) {   // Planner.cpp:12-32
         branch.push_back(cur);
         if (m_Nodes[cur].collisionPenalty > 0) {
             dangerous = true;
-            m_Stats.PlanCollisionPenalty += m_Nodes[cur].collisionPenalty;
+            if (addToStats) m_Stats.PlanCollisionPenalty += m_Nodes[cur].collisionPenalty;
         }
     }
     plan.setDangerous(dangerous);
@@ -396,6 +471,7 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
 
     // collision check old plan (:46-59)
     int lastPlanEnd = startV;
+    std::vector<int> previousPlanNodes;   // the vertices made from it, for the search dump
     if (!previousPlan.empty()) {
         for (const auto& p : previousPlan.get()) {
             if (p.getEndTime() <= start.time()) continue;
@@ -441,6 +517,7 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
                 c.coverageAllowed = cov;
                 c.infeasible = (r.flags & PPGPU_F_INFEASIBLE) != 0;
                 c.collisionPenalty = r.collision_penalty;
+                c.steps = (int)(r.info >> 16);
                 c.g = r.g; c.h = r.h;
                 c.ribbons = m_Nodes[lastPlanEnd].ribbons;
                 c.ribbons.assign(child.data(), (int)((r.info >> 8) & 0xff), r.coverage_completed_time);
@@ -450,6 +527,7 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
             }
             if (m_Nodes.size() == before) break;
             lastPlanEnd = (int)m_Nodes.size() - 1;
+            previousPlanNodes.push_back(lastPlanEnd);
             if (m_Nodes[lastPlanEnd].infeasible) {
                 lastPlanEnd = startV;
                 break;
@@ -464,6 +542,17 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
         if (m_Best >= 0 && m_Nodes[m_Best].f() <= m_Nodes[startV].f()) {
             *m_Config.output() << "Found best possible plan, assuming heuristic admissibility" << std::endl;
             break;
+        }
+        if (m_Config.visualizations()) {
+            // :67-92.  The reference re-costs the previous plan here when it visualises (same arithmetic, fresh vertices); the
+            // vertices costed above are shown instead.
+            visualizeVertex(startV, "start", false);
+            for (int v : previousPlanNodes) {
+                visualizeTrajectory(m_Nodes[v]);
+                visualizeVertex(v, "lastPlanEnd", false);
+            }
+            m_Config.visualizationStream() << "Incumbent f-value: " << (m_Best >= 0 ? m_Nodes[m_Best].f() : 0) << std::endl;
+            m_Config.visualizationStream() << m_RibbonManager.dumpRibbons() << "End Ribbons" << std::endl;
         }
         pushVertexQueue(startV);
         if (lastPlanEnd != startV) pushVertexQueue(lastPlanEnd);
@@ -485,8 +574,15 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
         // first iteration: initialSamples; afterwards double them (:101-102)
         if (m_NumSamples < m_Config.initialSamples()) addSamples(m_Config.initialSamples());
         else addSamples(m_NumSamples);
+        visualizeSamples();
         int v = aStar(endTime);
-        if (m_Best < 0 || (v >= 0 && m_Nodes[v].f() + 0.0 < m_Nodes[m_Best].f())) m_Best = v;
+        if (m_Best < 0 || (v >= 0 && m_Nodes[v].f() + 0.0 < m_Nodes[m_Best].f())) {
+            m_Best = v;
+            if (v >= 0 && m_Config.visualizations()) {   // :113-116
+                visualizePlan(tracePlan(v, false));
+                visualizeVertex(v, "goal", false);
+            }
+        }
         if (v >= 0 && m_Stats.FirstGoalIteration < 0) m_Stats.FirstGoalIteration = (long)m_Stats.Iterations;
         m_Stats.Iterations++;
     }

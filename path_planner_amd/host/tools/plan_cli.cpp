@@ -69,6 +69,10 @@ int main(int argc, char** argv) {
             if (s >> c[0] >> c[1] >> c[2] >> c[3]) gauss->update(mmsi++, x, y, h, v, t, c); else gauss->update(mmsi++, x, y, h, v, t);
             haveGauss = true;
         } else if (k == "map_file") { std::string p; s >> p; map = std::make_shared<GridWorldMap>(p);
+        } else if (k == "visualization_file") {   // the search dump visualizer.py reads (executive.cpp:443-449)
+            std::string p; s >> p;
+            config.setVisualizations(true);
+            config.setVisualizer(std::make_shared<Visualizer>(p));
         } else if (k == "clock") { s >> t0 >> dt;
         } else if (k == "time_remaining") { s >> timeRemaining;
         } else if (k == "repeat") { s >> repeat;

@@ -188,3 +188,100 @@ def test_speculative_expansion_changes_nothing_but_the_round_trips():
             assert o[k] == base[k], (k, o[k], base[k])
         assert o["edges_costed"] >= base["edges_costed"]
     assert base["expanded"] >= 10
+
+
+def _read_search_dump(path):
+    """The text format of the reference's search dump, tokenised the way its viewer does (visualizer.py:485-547): drop
+    "():," and split on blanks; "Generated"/"Expanded" prefix; ribbon block between "Ribbons" and "End Ribbons"; otherwise
+    State x y heading speed time f F g G h H tag [ids...]."""
+    items, ribbons, in_ribbons = [], [], False
+    for raw in open(path):
+        line = raw
+        for ch in "():,\n":
+            line = line.replace(ch, "")
+        tok = [t for t in line.split(" ")]
+        while tok and tok[-1] == "":
+            tok.pop()
+        if not tok:
+            continue
+        kind = None
+        if tok[0] in ("Expanded", "Generated"):
+            kind, tok = tok[0], tok[1:]
+        if tok[0] == "End" and tok[1] == "Ribbons":
+            in_ribbons = False
+        elif tok[0] == "Ribbons":
+            in_ribbons = True
+        elif in_ribbons:
+            if tok[0] != "None":
+                ribbons.append([float(tok[0]), float(tok[1]), float(tok[3]), float(tok[4])])
+        elif tok[0] == "Trajectory":
+            items.append({"tag": "trajectory-start"})
+        elif tok[0] == "Incumbent":
+            items.append({"tag": "incumbent", "f": float(tok[2])})
+        else:
+            assert tok[0] == "State", raw
+            items.append({"kind": kind, "x": float(tok[1]), "y": float(tok[2]), "heading": float(tok[3]), "speed": float(tok[4]),
+                          "time": float(tok[5]), "f": float(tok[7]), "g": float(tok[9]), "h": float(tok[11]), "tag": tok[12].lower(),
+                          "ids": [int(t) for t in tok[13:]]})
+    return items, ribbons
+
+
+def test_search_dump_is_what_the_visualizer_reads():
+    """PlannerConfig::setVisualizations + Visualizer (PlannerConfig.h:60-80, Visualizer.h): the dump of the search — start,
+    incumbent, ribbons, samples, per-edge trajectories, generated / expanded vertices with their ancestry, goal plans — in the
+    reference's text format, and a search that is not changed by being watched."""
+    from path_planner_amd import workloads
+    w = workloads.by_name("cfg3")
+    t0, dt, calls, init = 1000.0, 1e-3, 24, 256
+    with tempfile.TemporaryDirectory() as d:
+        mp = os.path.join(d, "grid.map")
+        _write_map(w.grid, w.res, mp)
+        sc = os.path.join(d, "s.txt")
+        _scenario(w, sc, mp, t0, dt, calls, init)
+        plain = _run_cli(sc)
+        dump = os.path.join(d, "search.txt")
+        with open(sc, "a") as f:
+            f.write(f"visualization_file {dump}\n")
+        seen = _run_cli(sc)
+        same = lambda r: {k: v for k, v in r.items() if not k.startswith("wall_ms")}
+        assert same(plain) == same(seen)
+        items, ribbons = _read_search_dump(dump)
+    tags = [i["tag"] for i in items]
+    assert tags.count("start") == seen["iterations"] and tags.count("incumbent") == seen["iterations"]
+    assert len(ribbons) == len(w.ribbons4) * seen["iterations"]
+    assert np.allclose(np.array(ribbons[:len(w.ribbons4)]), w.ribbons4, atol=1e-4)
+    expanded = [i for i in items if i.get("kind") == "Expanded"]
+    generated = [i for i in items if i.get("kind") == "Generated" and i["tag"] == "vertex"]
+    assert len(expanded) == seen["expanded"]
+    assert seen["generated"] <= len(generated) <= seen["generated"] + seen["iterations"]     # + the goal each aStar() returned
+    # samples are listed every iteration; the last listing is the final sample set
+    last_start = len(tags) - 1 - tags[::-1].index("start")
+    assert tags[last_start:].count("sample") == seen["samples"]
+    # ancestry: the last id is the vertex's own, the chain is as long as the vertex is deep, children of the root start with 1
+    own = {}
+    for g in generated:
+        assert g["ids"][0] == 1 and abs(g["f"] - (g["g"] + g["h"])) <= 1e-3 * max(1.0, g["f"])
+        own.setdefault(g["ids"][-1], g)
+    assert len(own) >= seen["generated"] - seen["iterations"]
+    deep = max(generated, key=lambda g: len(g["ids"]))
+    assert len(deep["ids"]) >= 3 and all(i in own or i == 1 for i in deep["ids"])
+    # trajectories: every edge streams one; its samples advance in time by a whole number of collision-check steps, cost
+    # so far = start g + elapsed time + penalties, h = the START vertex's h
+    inc_t = w.cfg.collision_checking_increment / w.cfg.max_speed
+    per = int(1.0 / w.cfg.collision_checking_increment) + 1
+    n_traj = tags.count("trajectory-start")
+    assert n_traj >= seen["generated"] - 2 * seen["iterations"]
+    checked = 0
+    for a in range(len(items) - 2):
+        if items[a]["tag"] == "trajectory" and items[a + 1]["tag"] == "trajectory":
+            p, q = items[a], items[a + 1]
+            assert abs((q["time"] - p["time"]) - per * inc_t) < 1e-5 and p["h"] == q["h"]
+            dg = q["g"] - p["g"]
+            pen = round((dg - per * inc_t) / 600.0)
+            tol = 2e-5 * max(abs(p["g"]), abs(q["g"])) + 1e-4          # operator<< prints six significant digits
+            assert pen >= 0 and abs(dg - per * inc_t - 600.0 * pen) < tol
+            assert np.hypot(q["x"] - p["x"], q["y"] - p["y"]) <= per * inc_t * w.cfg.max_speed + 1e-4
+            checked += 1
+    assert checked > 100
+    # a goal was found: its plan sampled once per second and the goal vertex itself
+    assert seen["first_goal_iteration"] >= 0 and "goal" in tags and "plan" in tags
