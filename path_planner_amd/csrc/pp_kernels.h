@@ -36,6 +36,7 @@ struct PPParams {
     double* track_pen;                   // Gaussian model only: [edge][ngp] collisionExists(step k) ...
     double* track_chunk_pen;             // ... and [edge][nch] its sum times the penalty factor over the chunk's executable steps
     struct PPTrackSummary* track_summary;
+    unsigned long long* work;            // work-queue heads of the per-edge kernels (PP_Q_*), zeroed by pp_k_solve_edges
     unsigned* need_big;                  // set by the cover sweep when some child has 9..12 ribbons (pp_k_heuristic_big then has work)
     int ngp, nch;                        // steps per edge rounded up to whole 64-step chunks, and that many chunks
 };
@@ -126,8 +127,59 @@ __device__ __forceinline__ void pp_edge_decode(const PPParams& p, long long e, u
 
 // Phase 0 for every edge of a launch, one lane per edge (Vertex::connect -> Edge::computeApproxCost ->
 // DubinsWrapper::set, Edge.cpp:14-18,73-76; Edge::setEnd(wrapper), Edge.cpp:208-216 for wrapper edges).
+// A per-edge kernel can be launched as a resident grid whose waves pull edges from queues, in launch order, instead of one
+// workgroup per PP_WPB edges.  Edges differ in length by two orders of magnitude (blocked at the first step ... the full
+// horizon); the cover sweep runs 4 waves per SIMD (128 VGPRs) and with dispatcher-placed workgroups the counters show 3.15 of
+// those 4 slots occupied on average - a wave that takes its next edge itself leaves none empty (cover sweep: -9 %).  The pose
+// sweep (6 waves per SIMD, VALU 97 % busy either way) and the heuristic (3 us of work per edge, about the latency of the
+// atomic) measure 4 % and 8 % SLOWER that way and keep the plain launch (tools/ablate.py q0 / q2 / q7).
+// One queue head would serialise: a device-scope atomic on one address completes every ~12.5 ns on this part (measured: 236 140
+// of them stretch any kernel to 3 ms), so the edges are dealt round-robin onto PP_NQ queues whose heads sit in different memory
+// channels; a workgroup works on queue (blockIdx mod PP_NQ) and, when that is empty, on the next ones (a plain look first: an
+// exhausted queue stays exhausted).
+#define PP_Q_POSE 0
+#define PP_Q_COVER 1
+#define PP_Q_HEUR 2
+#define PP_Q_BIG 3
+#define PP_NQ 32
+#define PP_QSTRIDE 544               // unsigned long longs between queue heads: 4 KiB + 256 B
+#define PP_WORK_WORDS (4 * PP_NQ * PP_QSTRIDE)
+#ifndef PP_QUEUE_MASK
+#define PP_QUEUE_MASK 2              // which kernels pull from queues: 1 pose sweep, 2 cover sweep, 4 heuristics (others: one workgroup per PP_WPB edges)
+#endif
+struct PPQueue { int q, dry; };      // the queue this wave draws from, how many queues in a row it has found empty
+__device__ __forceinline__ PPQueue pp_queue_init() {
+    PPQueue s; s.q = (int)(blockIdx.x % PP_NQ); s.dry = 0; return s;
+}
+// for (PP_EACH_EDGE(idx, kernel bit, queue, n)) body;  -- either this wave's one edge, or edges from the queues until they are dry
+#define PP_EACH_EDGE(idx, bit, kern, n)                                                                                     \
+    long long idx = ((PP_QUEUE_MASK) & (bit)) ? pp_next_edge(p, kern, qs, n)                                                \
+                                              : (long long)blockIdx.x * PP_WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); \
+    idx < (n);                                                                                                              \
+    idx = ((PP_QUEUE_MASK) & (bit)) ? pp_next_edge(p, kern, qs, n) : (n)
+// next edge of kernel `kern` for this wave, or n when every queue is empty (every wave gets there: the grid always drains)
+__device__ __forceinline__ long long pp_next_edge(const PPParams& p, int kern, PPQueue& s, long long n) {
+    while (s.dry < PP_NQ) {
+        unsigned long long* head = p.work + (size_t)(kern * PP_NQ + s.q) * PP_QSTRIDE;
+        unsigned long long k = 0;
+        if (pp_lane() == 0) {
+            k = (s.dry > 0) ? __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;   // someone else's queue: look first
+            if ((long long)(k * PP_NQ) + s.q < n) k = atomicAdd(head, 1ull);
+        }
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)k);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(k >> 32));
+        const int q = __builtin_amdgcn_readfirstlane(s.q);
+        const long long idx = (long long)((((unsigned long long)hi << 32) | lo) * PP_NQ) + q;
+        if (idx < n) { s.dry = 0; return idx; }
+        s.q = (s.q + 1 == PP_NQ) ? 0 : s.q + 1;
+        s.dry++;
+    }
+    return n;
+}
 __global__ __launch_bounds__(256) void pp_k_solve_edges(PPParams p) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    // the queue heads of the kernels that follow (all of them start after this kernel has ended, in stream order)
+    if (e < 4 * PP_NQ) p.work[(size_t)e * PP_QSTRIDE] = 0ull;
     if (e >= p.n_edges) return;
     unsigned vi, target, cbits;
     const long long eg = pp_edge_position(p, p.e_base + e);   // position in the caller's edge list; e = position in this slice
@@ -803,26 +855,28 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
 #endif
 // n_edges = slice size (ppgpu.hip: launch_cost)
 __global__ __launch_bounds__(PP_WPB * 64, PP_POSE_MIN_WAVES) void pp_k_pose_sweep(PPParams p) {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long idx = (long long)blockIdx.x * PP_WPB + wave;
-    if (idx < p.n_edges) pp_pose_sweep_edge<false>(p, p.ws_base + idx);
+    PPQueue qs = pp_queue_init();
+    for (PP_EACH_EDGE(idx, 1, PP_Q_POSE, p.n_edges))
+        pp_pose_sweep_edge<false>(p, p.ws_base + idx);
 }
 __global__ __launch_bounds__(PP_WPB * 64, 4) void pp_k_pose_sweep_gaussian(PPParams p) {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long idx = (long long)blockIdx.x * PP_WPB + wave;
-    if (idx < p.n_edges) pp_pose_sweep_edge<true>(p, p.ws_base + idx);
+    PPQueue qs = pp_queue_init();
+    for (PP_EACH_EDGE(idx, 1, PP_Q_POSE, p.n_edges))
+        pp_pose_sweep_edge<true>(p, p.ws_base + idx);
 }
 __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep(PPParams p) {
     __shared__ double lds_all[PP_WPB][PP_WAVE * 4];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long idx = (long long)blockIdx.x * PP_WPB + wave;
-    if (idx < p.n_edges) pp_cover_sweep_edge<false>(p, p.ws_base + idx, pp_edge_position(p, p.e_base + idx), lds_all[wave]);
+    PPQueue qs = pp_queue_init();
+    for (PP_EACH_EDGE(idx, 2, PP_Q_COVER, p.n_edges))
+        pp_cover_sweep_edge<false>(p, p.ws_base + idx, pp_edge_position(p, p.e_base + idx), lds_all[wave]);
 }
 __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep_gaussian(PPParams p) {
     __shared__ double lds_all[PP_WPB][PP_WAVE * 4];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long idx = (long long)blockIdx.x * PP_WPB + wave;
-    if (idx < p.n_edges) pp_cover_sweep_edge<true>(p, p.ws_base + idx, pp_edge_position(p, p.e_base + idx), lds_all[wave]);
+    PPQueue qs = pp_queue_init();
+    for (PP_EACH_EDGE(idx, 2, PP_Q_COVER, p.n_edges))
+        pp_cover_sweep_edge<true>(p, p.ws_base + idx, pp_edge_position(p, p.e_base + idx), lds_all[wave]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -927,22 +981,25 @@ __device__ __forceinline__ void pp_heuristic_edge(const PPParams& p, const long 
 __global__ __launch_bounds__(PP_WPB * 64, PP_H_MIN_WAVES) void pp_k_heuristic(PPParams p) {
     __shared__ double lds_all[PP_WPB][PPTsp<PP_TSP_MAX>::LDS];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long e = (long long)blockIdx.x * PP_WPB + wave;
-    if (e < p.n_edges) pp_heuristic_edge<false, PP_TSP_MAX>(p, e, lds_all[wave]);
+    PPQueue qs = pp_queue_init();
+    for (PP_EACH_EDGE(e, 4, PP_Q_HEUR, p.n_edges))
+        pp_heuristic_edge<false, PP_TSP_MAX>(p, e, lds_all[wave]);
 }
 __global__ __launch_bounds__(PP_WPB * 64) void pp_k_heuristic_dubins(PPParams p) {
     __shared__ double lds_all[PP_WPB][PPTsp<PP_TSP_MAX>::LDS];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long e = (long long)blockIdx.x * PP_WPB + wave;
-    if (e < p.n_edges) pp_heuristic_edge<true, PP_TSP_MAX>(p, e, lds_all[wave]);
+    PPQueue qs = pp_queue_init();
+    for (PP_EACH_EDGE(e, 4, PP_Q_HEUR, p.n_edges))
+        pp_heuristic_edge<true, PP_TSP_MAX>(p, e, lds_all[wave]);
 }
 // TspPointRobotNoSplitKRibbons on child lists of 9..12 ribbons (rare: a vertex whose ribbons were split many times)
 __global__ __launch_bounds__(PP_WPB * 64) void pp_k_heuristic_big(PPParams p) {
     __shared__ double lds_all[PP_WPB][PPTsp<PP_TSP_MAX_BIG>::LDS];
     if (pp_const_i32(p.need_big)[0] == 0) return;            // almost always: no child list beyond 8 ribbons in this launch
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long e = (long long)blockIdx.x * PP_WPB + wave;
-    if (e < p.n_edges) pp_heuristic_edge<false, PP_TSP_MAX_BIG>(p, e, lds_all[wave]);
+    PPQueue qs = pp_queue_init();
+    for (PP_EACH_EDGE(e, 4, PP_Q_BIG, p.n_edges))
+        pp_heuristic_edge<false, PP_TSP_MAX_BIG>(p, e, lds_all[wave]);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -96,6 +96,9 @@ struct ppgpu_ctx {
     DevBuf<unsigned> track_chunk_hits;
     DevBuf<PPTrackSummary> track_summary;
     DevBuf<unsigned> need_big;
+    DevBuf<unsigned long long> work;    // queue heads of the resident per-edge grids (PP_Q_*)
+    int n_cu = 0;
+    int resident[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // workgroups of each per-edge kernel the device holds at once (0 = not asked yet)
     DevBuf<double> track_pen, track_chunk_pen;   // Gaussian obstacle model only
     // optional per-kernel timing of costing launches (ppgpu_enable_timing)
     bool timing = false;
@@ -131,6 +134,7 @@ int ppgpu_create(int device, ppgpu_ctx** out) {
         return fail(PPGPU_ENODEV, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
     ppgpu_ctx* c = new ppgpu_ctx();
     c->device = device;
+    c->n_cu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     if (const char* sb = std::getenv("PPGPU_SLICE_BYTES")) {
@@ -151,7 +155,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->tmp_edges.release(); c->tmp_wedges.release(); c->partial.release(); c->tmp_results.release(); c->tmp_child.release();
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     c->setup.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
-    c->track_summary.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release();
+    c->track_summary.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->work.release();
     if (c->stage_in) (void)hipHostFree(c->stage_in);
     if (c->stage_out) (void)hipHostFree(c->stage_out);
     for (int i = 0; i < 5; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -588,6 +592,20 @@ int64_t ppgpu_dense_edge_count(int32_t nv, int64_t ns, uint32_t cfg_mask) {
     return (int64_t)nv * ns * (int64_t)__builtin_popcount(cfg_mask & 0xFu);
 }
 
+// Grid of a per-edge kernel: as many workgroups as the device keeps resident (its waves pull edges from the queue), or fewer
+// when the launch has fewer edges than that.
+static unsigned resident_grid(ppgpu_ctx* c, int slot, void (*kernel)(PPParams), long long n_edges) {
+    const int bit = slot < 2 ? 1 : (slot < 4 ? 2 : 4);
+    if (!((PP_QUEUE_MASK) & bit)) return (unsigned)((n_edges + PP_WPB - 1) / PP_WPB);   // this kernel takes one edge per wave
+    if (c->resident[slot] == 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, PP_WPB * 64, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
+        c->resident[slot] = per_cu * (c->n_cu > 0 ? c->n_cu : 256);
+    }
+    const long long need = (n_edges + PP_WPB - 1) / PP_WPB;
+    return (unsigned)(need < c->resident[slot] ? need : c->resident[slot]);
+}
+
 static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     if (p.n_edges <= 0) return PPGPU_OK;
     const long long total = p.n_edges;
@@ -632,34 +650,35 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(c->need_big.p, 0, sizeof(unsigned), c->stream));
         p.need_big = c->need_big.p;
+        if ((rc = c->work.reserve(PP_WORK_WORDS, false, c->stream))) return rc;
+        p.work = c->work.p;
     }
     for (long long e0 = 0; e0 < total; e0 += slice) {
         p.e_base = e0; p.ws_base = 0; p.n_edges = (total - e0 < slice) ? (total - e0) : slice;
-        const unsigned blocks = (unsigned)((p.n_edges + PP_WPB - 1) / PP_WPB);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(pp_k_solve_edges, dim3((unsigned)((p.n_edges + 255) / 256)), dim3(256), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN)
-            hipLaunchKernelGGL(pp_k_pose_sweep_gaussian, dim3(blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+            hipLaunchKernelGGL(pp_k_pose_sweep_gaussian, dim3(resident_grid(c, 0, pp_k_pose_sweep_gaussian, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
         else
-            hipLaunchKernelGGL(pp_k_pose_sweep, dim3(blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+            hipLaunchKernelGGL(pp_k_pose_sweep, dim3(resident_grid(c, 1, pp_k_pose_sweep, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
         if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN)
-            hipLaunchKernelGGL(pp_k_cover_sweep_gaussian, dim3(blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+            hipLaunchKernelGGL(pp_k_cover_sweep_gaussian, dim3(resident_grid(c, 2, pp_k_cover_sweep_gaussian, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
         else
-            hipLaunchKernelGGL(pp_k_cover_sweep, dim3(blocks), dim3(PP_WPB * 64), 0, c->stream, p);
+            hipLaunchKernelGGL(pp_k_cover_sweep, dim3(resident_grid(c, 3, pp_k_cover_sweep, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     }
     p.e_base = 0;
     p.n_edges = total;
     if (p.heuristic == PPGPU_H_TSP_DUBINS_ALL || p.heuristic == PPGPU_H_TSP_DUBINS_K)
-        hipLaunchKernelGGL(pp_k_heuristic_dubins, dim3((unsigned)((total + PP_WPB - 1) / PP_WPB)), dim3(PP_WPB * 64), 0, c->stream, p);
+        hipLaunchKernelGGL(pp_k_heuristic_dubins, dim3(resident_grid(c, 4, pp_k_heuristic_dubins, total)), dim3(PP_WPB * 64), 0, c->stream, p);
     else
-        hipLaunchKernelGGL(pp_k_heuristic, dim3((unsigned)((total + PP_WPB - 1) / PP_WPB)), dim3(PP_WPB * 64), 0, c->stream, p);
+        hipLaunchKernelGGL(pp_k_heuristic, dim3(resident_grid(c, 5, pp_k_heuristic, total)), dim3(PP_WPB * 64), 0, c->stream, p);
     // child lists of 9..12 ribbons under the K variant: a second pass that touches only those edges (the others cost it one
     // 8-byte read each)
     if (p.heuristic == PPGPU_H_TSP_POINT_K)
-        hipLaunchKernelGGL(pp_k_heuristic_big, dim3((unsigned)((total + PP_WPB - 1) / PP_WPB)), dim3(PP_WPB * 64), 0, c->stream, p);
+        hipLaunchKernelGGL(pp_k_heuristic_big, dim3(resident_grid(c, 6, pp_k_heuristic_big, total)), dim3(PP_WPB * 64), 0, c->stream, p);
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], c->stream)); c->ev_valid = true; }
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;
@@ -780,8 +799,9 @@ int ppgpu_heuristic_host(ppgpu_ctx* c, int32_t n, const double* poses3, const in
         off += (size_t)counts[i];
     }
     if ((rc = c->tmp_results.reserve((size_t)n, false, c->stream)) || (rc = c->tmp_child.reserve(child.size(), false, c->stream)) ||
-        (rc = c->need_big.reserve(1, false, c->stream)))
+        (rc = c->need_big.reserve(1, false, c->stream)) || (rc = c->work.reserve(PP_WORK_WORDS, false, c->stream)))
         return rc;
+    HIP_TRY(hipMemsetAsync(c->work.p, 0, (size_t)PP_WORK_WORDS * sizeof(unsigned long long), c->stream));   // queue heads (no solve kernel runs here)
     HIP_TRY(hipMemcpyAsync(c->tmp_results.p, rec.data(), rec.size() * sizeof(ppgpu_edge_result), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->tmp_child.p, child.data(), child.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     const unsigned one = 1u;       // let the 12-ribbon pass look at every record
@@ -789,8 +809,8 @@ int ppgpu_heuristic_host(ppgpu_ctx* c, int32_t n, const double* poses3, const in
     PPParams p;
     fill_params(c, p);
     p.edges = nullptr; p.wedges = nullptr; p.n_edges = n; p.total_edges = n; p.e_base = 0; p.ws_base = 0;
-    p.out = c->tmp_results.p; p.child = c->tmp_child.p; p.stride = stride; p.need_big = c->need_big.p;
-    const dim3 grid((unsigned)((n + PP_WPB - 1) / PP_WPB)), block(PP_WPB * 64);
+    p.out = c->tmp_results.p; p.child = c->tmp_child.p; p.stride = stride; p.need_big = c->need_big.p; p.work = c->work.p;
+    const dim3 grid((unsigned)((n + PP_WPB - 1) / PP_WPB)), block(PP_WPB * 64);   // n is small: never more than fits
     if (p.heuristic == PPGPU_H_TSP_DUBINS_ALL || p.heuristic == PPGPU_H_TSP_DUBINS_K) hipLaunchKernelGGL(pp_k_heuristic_dubins, grid, block, 0, c->stream, p);
     else hipLaunchKernelGGL(pp_k_heuristic, grid, block, 0, c->stream, p);
     if (p.heuristic == PPGPU_H_TSP_POINT_K) hipLaunchKernelGGL(pp_k_heuristic_big, grid, block, 0, c->stream, p);

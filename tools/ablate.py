@@ -54,11 +54,13 @@ ctx.set_config(w.cfg); ctx.set_grid(w.grid, w.res); ctx.set_obstacles(w.obst); c
 ctx.sampler_init(w.bounds6, w.seed, w.ribbons4); n = ctx.sampler_add(w.n_samples)
 d = torch.zeros(4*n*128, dtype=torch.uint8, device="cuda")
 ts = []
-for i in range(4):
+ks = []
+ctx.enable_timing(True)
+for i in range(8):
     a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
     a.record(st); ctx.cost_edges_dense(0,1,0,n,0xF,d.data_ptr()); b.record(st); torch.cuda.synchronize()
-    ts.append(a.elapsed_time(b))
-print(json.dumps({"ms": min(ts[1:]), "edges": 4*n}))
+    ts.append(a.elapsed_time(b)); ks.append(ctx.last_timing())
+print(json.dumps({"ms": min(ts[1:]), "edges": 4*n, "kernels": [float(x) for x in np.median(np.array(ks[1:]), axis=0)]}))
 '''
 
 
@@ -75,7 +77,8 @@ def main():
         env = dict(os.environ, PPGPU_LIB_OVERRIDE=lib)
         out = subprocess.check_output([sys.executable, "-c", CHILD % {"root": ROOT, "n": n}], env=env).decode().strip().splitlines()[-1]
         r = json.loads(out)
-        print(f"{name:28s} {r['ms']:9.3f} ms   {r['edges'] / r['ms'] / 1e3:8.2f} Medges/s", flush=True)
+        print(f"{name:28s} {r['ms']:9.3f} ms   {r['edges'] / r['ms'] / 1e3:8.2f} Medges/s   solve/pose/cover/heuristic " +
+              " ".join(f"{x:6.3f}" for x in r["kernels"]), flush=True)
 
 
 if __name__ == "__main__":
