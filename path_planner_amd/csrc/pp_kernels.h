@@ -147,30 +147,44 @@ __device__ __forceinline__ void pp_edge_decode(const PPParams& p, long long e, u
 #ifndef PP_QUEUE_MASK
 #define PP_QUEUE_MASK 2              // which kernels pull from queues: 1 pose sweep, 2 cover sweep, 4 heuristics (others: one workgroup per PP_WPB edges)
 #endif
-struct PPQueue { int q, dry; };      // the queue this wave draws from, how many queues in a row it has found empty
+#ifndef PP_Q_CHUNK_COVER
+#define PP_Q_CHUNK_COVER 1           // edges a cover-sweep wave takes per atomic
+#endif
+#ifndef PP_Q_CHUNK_HEUR
+#define PP_Q_CHUNK_HEUR 4            // edges a heuristic wave takes per atomic (its edges are short: see pp_next_edge)
+#endif
+struct PPQueue { int q, dry, left; unsigned long long k; };   // queue drawn from, empty queues seen in a row, rest of the chunk in hand
 __device__ __forceinline__ PPQueue pp_queue_init() {
-    PPQueue s; s.q = (int)(blockIdx.x % PP_NQ); s.dry = 0; return s;
+    PPQueue s; s.q = (int)(blockIdx.x % PP_NQ); s.dry = 0; s.left = 0; s.k = 0; return s;
 }
-// for (PP_EACH_EDGE(idx, kernel bit, queue, n)) body;  -- either this wave's one edge, or edges from the queues until they are dry
-#define PP_EACH_EDGE(idx, bit, kern, n)                                                                                     \
-    long long idx = ((PP_QUEUE_MASK) & (bit)) ? pp_next_edge(p, kern, qs, n)                                                \
-                                              : (long long)blockIdx.x * PP_WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); \
+// for (PP_EACH_EDGE(idx, kernel bit, queue, n, chunk)) body;  -- either this wave's one edge, or edges from the queues until they are dry
+#define PP_EACH_EDGE(idx, bit, kern, n, chunk)                                                                              \
+    long long idx = ((PP_QUEUE_MASK) & (bit)) ? pp_next_edge<chunk>(p, kern, qs, n)                                         \
+                                              : (long long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); \
     idx < (n);                                                                                                              \
-    idx = ((PP_QUEUE_MASK) & (bit)) ? pp_next_edge(p, kern, qs, n) : (n)
-// next edge of kernel `kern` for this wave, or n when every queue is empty (every wave gets there: the grid always drains)
+    idx = ((PP_QUEUE_MASK) & (bit)) ? pp_next_edge<chunk>(p, kern, qs, n) : (n)
+// next edge of kernel `kern` for this wave, or n when every queue is empty (every wave gets there: the grid always drains).
+// Queue q holds the edges q, q + NQ, q + 2 NQ, ...; one atomic takes CHUNK consecutive ones of them.
+template <int CHUNK>
 __device__ __forceinline__ long long pp_next_edge(const PPParams& p, int kern, PPQueue& s, long long n) {
+    if (CHUNK > 1 && s.left > 0) {
+        const long long idx = (long long)(s.k * PP_NQ) + __builtin_amdgcn_readfirstlane(s.q);
+        if (idx < n) { s.left--; s.k++; return idx; }
+        s.left = 0;
+    }
     while (s.dry < PP_NQ) {
         unsigned long long* head = p.work + (size_t)(kern * PP_NQ + s.q) * PP_QSTRIDE;
         unsigned long long k = 0;
         if (pp_lane() == 0) {
             k = (s.dry > 0) ? __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;   // someone else's queue: look first
-            if ((long long)(k * PP_NQ) + s.q < n) k = atomicAdd(head, 1ull);
+            if ((long long)(k * PP_NQ) + s.q < n) k = atomicAdd(head, (unsigned long long)CHUNK);
         }
         const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)k);
         const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(k >> 32));
         const int q = __builtin_amdgcn_readfirstlane(s.q);
-        const long long idx = (long long)((((unsigned long long)hi << 32) | lo) * PP_NQ) + q;
-        if (idx < n) { s.dry = 0; return idx; }
+        const unsigned long long kk = ((unsigned long long)hi << 32) | lo;
+        const long long idx = (long long)(kk * PP_NQ) + q;
+        if (idx < n) { s.dry = 0; s.left = CHUNK - 1; s.k = kk + 1; return idx; }
         s.q = (s.q + 1 == PP_NQ) ? 0 : s.q + 1;
         s.dry++;
     }
@@ -856,26 +870,26 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
 // n_edges = slice size (ppgpu.hip: launch_cost)
 __global__ __launch_bounds__(PP_WPB * 64, PP_POSE_MIN_WAVES) void pp_k_pose_sweep(PPParams p) {
     PPQueue qs = pp_queue_init();
-    for (PP_EACH_EDGE(idx, 1, PP_Q_POSE, p.n_edges))
+    for (PP_EACH_EDGE(idx, 1, PP_Q_POSE, p.n_edges, 1))
         pp_pose_sweep_edge<false>(p, p.ws_base + idx);
 }
 __global__ __launch_bounds__(PP_WPB * 64, 4) void pp_k_pose_sweep_gaussian(PPParams p) {
     PPQueue qs = pp_queue_init();
-    for (PP_EACH_EDGE(idx, 1, PP_Q_POSE, p.n_edges))
+    for (PP_EACH_EDGE(idx, 1, PP_Q_POSE, p.n_edges, 1))
         pp_pose_sweep_edge<true>(p, p.ws_base + idx);
 }
 __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep(PPParams p) {
     __shared__ double lds_all[PP_WPB][PP_WAVE * 4];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     PPQueue qs = pp_queue_init();
-    for (PP_EACH_EDGE(idx, 2, PP_Q_COVER, p.n_edges))
+    for (PP_EACH_EDGE(idx, 2, PP_Q_COVER, p.n_edges, PP_Q_CHUNK_COVER))
         pp_cover_sweep_edge<false>(p, p.ws_base + idx, pp_edge_position(p, p.e_base + idx), lds_all[wave]);
 }
 __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep_gaussian(PPParams p) {
     __shared__ double lds_all[PP_WPB][PP_WAVE * 4];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     PPQueue qs = pp_queue_init();
-    for (PP_EACH_EDGE(idx, 2, PP_Q_COVER, p.n_edges))
+    for (PP_EACH_EDGE(idx, 2, PP_Q_COVER, p.n_edges, PP_Q_CHUNK_COVER))
         pp_cover_sweep_edge<true>(p, p.ws_base + idx, pp_edge_position(p, p.e_base + idx), lds_all[wave]);
 }
 
@@ -978,27 +992,30 @@ __device__ __forceinline__ void pp_heuristic_edge(const PPParams& p, const long 
     const double h = hdist / p.max_speed * p.tpf;
     if (lane == 0) { rec->h = h; rec->f = g + h; rec->flags = flags; }
 }
-__global__ __launch_bounds__(PP_WPB * 64, PP_H_MIN_WAVES) void pp_k_heuristic(PPParams p) {
-    __shared__ double lds_all[PP_WPB][PPTsp<PP_TSP_MAX>::LDS];
+#ifndef PP_H_WPB
+#define PP_H_WPB PP_WPB   // wavefronts per workgroup of the heuristic kernels
+#endif
+__global__ __launch_bounds__(PP_H_WPB * 64, PP_H_MIN_WAVES) void pp_k_heuristic(PPParams p) {
+    __shared__ double lds_all[PP_H_WPB][PPTsp<PP_TSP_MAX>::LDS];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     PPQueue qs = pp_queue_init();
-    for (PP_EACH_EDGE(e, 4, PP_Q_HEUR, p.n_edges))
+    for (PP_EACH_EDGE(e, 4, PP_Q_HEUR, p.n_edges, PP_Q_CHUNK_HEUR))
         pp_heuristic_edge<false, PP_TSP_MAX>(p, e, lds_all[wave]);
 }
-__global__ __launch_bounds__(PP_WPB * 64) void pp_k_heuristic_dubins(PPParams p) {
-    __shared__ double lds_all[PP_WPB][PPTsp<PP_TSP_MAX>::LDS];
+__global__ __launch_bounds__(PP_H_WPB * 64) void pp_k_heuristic_dubins(PPParams p) {
+    __shared__ double lds_all[PP_H_WPB][PPTsp<PP_TSP_MAX>::LDS];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     PPQueue qs = pp_queue_init();
-    for (PP_EACH_EDGE(e, 4, PP_Q_HEUR, p.n_edges))
+    for (PP_EACH_EDGE(e, 4, PP_Q_HEUR, p.n_edges, PP_Q_CHUNK_HEUR))
         pp_heuristic_edge<true, PP_TSP_MAX>(p, e, lds_all[wave]);
 }
 // TspPointRobotNoSplitKRibbons on child lists of 9..12 ribbons (rare: a vertex whose ribbons were split many times)
-__global__ __launch_bounds__(PP_WPB * 64) void pp_k_heuristic_big(PPParams p) {
-    __shared__ double lds_all[PP_WPB][PPTsp<PP_TSP_MAX_BIG>::LDS];
+__global__ __launch_bounds__(PP_H_WPB * 64) void pp_k_heuristic_big(PPParams p) {
+    __shared__ double lds_all[PP_H_WPB][PPTsp<PP_TSP_MAX_BIG>::LDS];
     if (pp_const_i32(p.need_big)[0] == 0) return;            // almost always: no child list beyond 8 ribbons in this launch
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     PPQueue qs = pp_queue_init();
-    for (PP_EACH_EDGE(e, 4, PP_Q_BIG, p.n_edges))
+    for (PP_EACH_EDGE(e, 4, PP_Q_BIG, p.n_edges, PP_Q_CHUNK_HEUR))
         pp_heuristic_edge<false, PP_TSP_MAX_BIG>(p, e, lds_all[wave]);
 }
 

@@ -596,13 +596,14 @@ int64_t ppgpu_dense_edge_count(int32_t nv, int64_t ns, uint32_t cfg_mask) {
 // when the launch has fewer edges than that.
 static unsigned resident_grid(ppgpu_ctx* c, int slot, void (*kernel)(PPParams), long long n_edges) {
     const int bit = slot < 2 ? 1 : (slot < 4 ? 2 : 4);
-    if (!((PP_QUEUE_MASK) & bit)) return (unsigned)((n_edges + PP_WPB - 1) / PP_WPB);   // this kernel takes one edge per wave
+    const int wpb = slot < 4 ? PP_WPB : PP_H_WPB;
+    if (!((PP_QUEUE_MASK) & bit)) return (unsigned)((n_edges + wpb - 1) / wpb);   // this kernel takes one edge per wave
     if (c->resident[slot] == 0) {
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, PP_WPB * 64, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, wpb * 64, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
         c->resident[slot] = per_cu * (c->n_cu > 0 ? c->n_cu : 256);
     }
-    const long long need = (n_edges + PP_WPB - 1) / PP_WPB;
+    const long long need = (n_edges + wpb - 1) / wpb;
     return (unsigned)(need < c->resident[slot] ? need : c->resident[slot]);
 }
 
@@ -672,13 +673,13 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     p.e_base = 0;
     p.n_edges = total;
     if (p.heuristic == PPGPU_H_TSP_DUBINS_ALL || p.heuristic == PPGPU_H_TSP_DUBINS_K)
-        hipLaunchKernelGGL(pp_k_heuristic_dubins, dim3(resident_grid(c, 4, pp_k_heuristic_dubins, total)), dim3(PP_WPB * 64), 0, c->stream, p);
+        hipLaunchKernelGGL(pp_k_heuristic_dubins, dim3(resident_grid(c, 4, pp_k_heuristic_dubins, total)), dim3(PP_H_WPB * 64), 0, c->stream, p);
     else
-        hipLaunchKernelGGL(pp_k_heuristic, dim3(resident_grid(c, 5, pp_k_heuristic, total)), dim3(PP_WPB * 64), 0, c->stream, p);
+        hipLaunchKernelGGL(pp_k_heuristic, dim3(resident_grid(c, 5, pp_k_heuristic, total)), dim3(PP_H_WPB * 64), 0, c->stream, p);
     // child lists of 9..12 ribbons under the K variant: a second pass that touches only those edges (the others cost it one
     // 8-byte read each)
     if (p.heuristic == PPGPU_H_TSP_POINT_K)
-        hipLaunchKernelGGL(pp_k_heuristic_big, dim3(resident_grid(c, 6, pp_k_heuristic_big, total)), dim3(PP_WPB * 64), 0, c->stream, p);
+        hipLaunchKernelGGL(pp_k_heuristic_big, dim3(resident_grid(c, 6, pp_k_heuristic_big, total)), dim3(PP_H_WPB * 64), 0, c->stream, p);
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], c->stream)); c->ev_valid = true; }
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;
@@ -810,7 +811,7 @@ int ppgpu_heuristic_host(ppgpu_ctx* c, int32_t n, const double* poses3, const in
     fill_params(c, p);
     p.edges = nullptr; p.wedges = nullptr; p.n_edges = n; p.total_edges = n; p.e_base = 0; p.ws_base = 0;
     p.out = c->tmp_results.p; p.child = c->tmp_child.p; p.stride = stride; p.need_big = c->need_big.p; p.work = c->work.p;
-    const dim3 grid((unsigned)((n + PP_WPB - 1) / PP_WPB)), block(PP_WPB * 64);   // n is small: never more than fits
+    const dim3 grid((unsigned)((n + PP_H_WPB - 1) / PP_H_WPB)), block(PP_H_WPB * 64);   // n is small: never more than fits
     if (p.heuristic == PPGPU_H_TSP_DUBINS_ALL || p.heuristic == PPGPU_H_TSP_DUBINS_K) hipLaunchKernelGGL(pp_k_heuristic_dubins, grid, block, 0, c->stream, p);
     else hipLaunchKernelGGL(pp_k_heuristic, grid, block, 0, c->stream, p);
     if (p.heuristic == PPGPU_H_TSP_POINT_K) hipLaunchKernelGGL(pp_k_heuristic_big, grid, block, 0, c->stream, p);
