@@ -1044,15 +1044,18 @@ __global__ __launch_bounds__(256) void pp_k_dubins_lengths(const ppgpu_vertex* v
     reinterpret_cast<double2*>(out)[(size_t)v * ns + s] = o;
 }
 
-// k smallest (length, index) per (vertex, radius); one 256-thread workgroup each.  Round j finds
-// the lexicographic successor of round j-1's winner, so no exclusion list is needed.
-__global__ __launch_bounds__(256) void pp_k_select_nearest(const double* lengths, long long ns, int k, int* out_idx,
-                                                           double* out_len) {
-    __shared__ double sl[256];
-    __shared__ long long si[256];
-    const int vr = blockIdx.x;               // vertex * 2 + radius
-    const int v = vr >> 1, r = vr & 1;
-    const double* L = lengths + ((size_t)v * ns) * 2 + r;
+// k smallest (length, index) per (vertex, radius), in ascending (length, index) order; one 256-thread workgroup each.
+// Two passes over the lengths instead of k: the k-th smallest of the 256 per-thread minima bounds the k-th smallest overall,
+// so the second pass keeps the few entries not above that bound and ranks them.  (Fewer than k threads with an entry, or more
+// survivors than the list holds - many equal lengths - fall back to k successive minimum scans.)
+#define PP_SEL_CAP 1024
+__device__ __forceinline__ bool pp_sel_less(double l1, long long i1, double l2, long long i2) {   // (l1, i1) < (l2, i2); i < 0 = none, after everything
+    if (i1 < 0) return false;
+    if (i2 < 0) return true;
+    return l1 < l2 || (l1 == l2 && i1 < i2);
+}
+// Round j finds the lexicographic successor of round j-1's winner, so no exclusion list is needed.
+__device__ __noinline__ void pp_select_rounds(const double* L, long long ns, int k, int* oi, double* ol, double* sl, long long* si) {
     double prevL = -INFINITY;
     long long prevI = -1;
     for (int j = 0; j < k; j++) {
@@ -1075,12 +1078,73 @@ __global__ __launch_bounds__(256) void pp_k_select_nearest(const double* lengths
             __syncthreads();
         }
         prevL = sl[0]; prevI = si[0];
-        if (threadIdx.x == 0) { out_idx[(size_t)vr * k + j] = (int)prevI; out_len[(size_t)vr * k + j] = prevI >= 0 ? prevL : -1.0; }
+        if (threadIdx.x == 0) { oi[j] = (int)prevI; ol[j] = prevI >= 0 ? prevL : -1.0; }
         __syncthreads();
         if (prevI < 0) {                                                    // fewer than k candidates
-            for (int jj = j + 1; jj < k; jj++) if (threadIdx.x == 0) { out_idx[(size_t)vr * k + jj] = -1; out_len[(size_t)vr * k + jj] = -1.0; }
+            for (int jj = j + 1; jj < k; jj++) if (threadIdx.x == 0) { oi[jj] = -1; ol[jj] = -1.0; }
             break;
         }
+    }
+}
+__global__ __launch_bounds__(256) void pp_k_select_nearest(const double* lengths, long long ns, int k, int* out_idx,
+                                                           double* out_len) {
+    __shared__ double sl[PP_SEL_CAP];
+    __shared__ long long si[PP_SEL_CAP];
+    __shared__ double boundL;
+    __shared__ long long boundI;
+    __shared__ int count;
+    const int vr = blockIdx.x;               // vertex * 2 + radius
+    const int v = vr >> 1, r = vr & 1;
+    const double* L = lengths + ((size_t)v * ns) * 2 + r;
+    int* oi = out_idx + (size_t)vr * k;
+    double* ol = out_len + (size_t)vr * k;
+    const int tid = (int)threadIdx.x;
+    // pass 1: this thread's smallest entry
+    double bl = INFINITY;
+    long long bi = -1;
+    for (long long s = tid; s < ns; s += 256) {
+        const double l = L[s * 2];
+        if (l >= 0 && (bi < 0 || l < bl)) { bl = l; bi = s; }   // ascending s: the first of equal lengths stays
+    }
+    sl[tid] = bl; si[tid] = bi;
+    if (tid == 0) { boundI = -1; boundL = 0; count = 0; }
+    __syncthreads();
+    // the k-th smallest of the 256 minima (rank by counting; every thread reads the same LDS word at a time)
+    if (k <= 256) {
+        int rank = 0;
+        for (int j = 0; j < 256; j++) rank += pp_sel_less(sl[j], si[j], bl, bi) ? 1 : 0;
+        if (bi >= 0 && rank == k - 1) { boundL = bl; boundI = bi; }
+    }
+    __syncthreads();
+    const double bL = boundL;
+    const long long bI = boundI;
+    __syncthreads();
+    if (bI < 0) {                            // fewer than k threads hold an entry (a short sample list)
+        pp_select_rounds(L, ns, k, oi, ol, sl, si);
+        return;
+    }
+    // pass 2: the entries not above the bound
+    for (long long s = tid; s < ns; s += 256) {
+        const double l = L[s * 2];
+        if (l >= 0 && !pp_sel_less(bL, bI, l, s)) {
+            const int slot = atomicAdd(&count, 1);
+            if (slot < PP_SEL_CAP) { sl[slot] = l; si[slot] = s; }
+        }
+    }
+    __syncthreads();
+    const int m = count;
+    if (m > PP_SEL_CAP) {                    // uniform: the list overflowed
+        __syncthreads();
+        pp_select_rounds(L, ns, k, oi, ol, sl, si);
+        return;
+    }
+    // rank the survivors (at least k of them: the k minima themselves)
+    for (int c = tid; c < m; c += 256) {
+        const double l = sl[c];
+        const long long i = si[c];
+        int rank = 0;
+        for (int j = 0; j < m; j++) rank += pp_sel_less(sl[j], si[j], l, i) ? 1 : 0;
+        if (rank < k) { oi[rank] = (int)i; ol[rank] = l; }
     }
 }
 

@@ -92,7 +92,15 @@ private:
     double m_StartStateTime = 0;
     RibbonManager m_RibbonManager;
     long m_NumSamples = 0;
-    std::unordered_map<int, std::vector<Node>> m_Speculated;   // children of open vertices costed ahead of their expansion
+    // Edges of open vertices costed ahead of their expansion, as the device returned them: a child Node is built only when the
+    // search expands the parent, and only for edges it would push (an infeasible edge never becomes a vertex).
+    struct Costed {
+        std::vector<unsigned> cfgBits;
+        std::vector<unsigned char> records;   // ppgpu_edge_result each
+        std::vector<double> childRibbons;     // `stride` x 4 doubles per edge
+        int stride = 0;
+    };
+    std::unordered_map<int, Costed> m_Speculated;
 
     void uploadWorld(const State& start);
     void pushVertexQueue(int v);

@@ -8,7 +8,12 @@
 #include "path_planner_amd/Planner.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -17,6 +22,29 @@
 #include "../../../include/ppgpu.h"
 
 namespace ppamd {
+
+// PPAMD_PROFILE=1: where a plan() call's wall time goes on the host side, to stderr (developer aid)
+namespace {
+struct HostProfile {
+    bool on = std::getenv("PPAMD_PROFILE") != nullptr;
+    double t[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long trips = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void report(const char* what) {
+        if (!on) return;
+        std::fprintf(stderr, "[profile] %s: round trips %lu | pick %.1f ms | pack %.1f ms | device %.1f ms | children %.1f ms | push %.1f ms | samples %.1f ms\n",
+                     what, trips, t[0] * 1e3, t[1] * 1e3, t[2] * 1e3, t[3] * 1e3, t[4] * 1e3, t[5] * 1e3);
+        for (double& x : t) x = 0;
+        trips = 0;
+    }
+};
+HostProfile g_prof;
+struct Lap {
+    int slot; double t0;
+    explicit Lap(int s) : slot(s), t0(g_prof.on ? HostProfile::now() : 0) {}
+    ~Lap() { if (g_prof.on) g_prof.t[slot] += HostProfile::now() - t0; }
+};
+}
 
 static const double kTimePenaltyFactor = 1;       // Edge::timePenaltyFactor() (Edge.h:152)
 static const double kCollisionPenaltyFactor = 600;  // Edge::collisionPenaltyFactor() (Edge.h:151)
@@ -207,6 +235,7 @@ bool GpuAStarPlanner::goalCondition(const Node& v) const {   // :42-50
 
 // ------------------------------------------------------------------------------------------------ sampling
 void GpuAStarPlanner::addSamples(long n) {   // SamplingBasedPlanner::addSamples (:157-168)
+    Lap lap(5);
     int64_t total = 0;
     long left = n;
     while (left > 0) {   // the device sampler takes at most 524288 attempts per call
@@ -307,6 +336,8 @@ int GpuAStarPlanner::costStateEdges(int source, const std::vector<State>& target
 void GpuAStarPlanner::expandBatch(const std::vector<int>& sources) {
     ppgpu_ctx* h = m_Ctx->handle();
     const int M = (int)sources.size();
+    g_prof.trips++;
+    std::unique_ptr<Lap> lap(new Lap(1));
     // these vertices become the device's open-vertex array
     std::vector<ppgpu_vertex> verts((size_t)M);
     std::vector<double> pool, rib;
@@ -336,6 +367,7 @@ void GpuAStarPlanner::expandBatch(const std::vector<int>& sources) {
     std::vector<double> child;
     int64_t n = 0;
     int stride = std::min(kRibbonStride, maxParent + 6);
+    lap.reset(new Lap(2));
     for (;;) {
         child.assign((size_t)cap * stride * 4, 0.0);
         check(ppgpu_expand_host(h, M, verts.data(), (int32_t)(pool.size() / 4), pool.empty() ? nullptr : pool.data(), nearest.data(), k, &n,
@@ -349,11 +381,16 @@ void GpuAStarPlanner::expandBatch(const std::vector<int>& sources) {
         if (!retry) break;
         stride = kRibbonStride;       // some child does not fit: again at the device's full per-vertex capacity
     }
-    for (int i = 0; i < M; i++) m_Speculated[sources[i]];   // an entry even when a vertex has no edges at all
+    lap.reset(new Lap(3));
+    for (int i = 0; i < M; i++) m_Speculated[sources[i]].stride = stride;   // an entry even when a vertex has no edges at all
     for (int64_t e = 0; e < n; e++) {
         const int owner = (int)((edges[e] >> 32) & 0xffffffu);
-        const unsigned cfg = (unsigned)(edges[e] >> 56);
-        m_Speculated[sources[owner]].push_back(makeChild(sources[owner], cfg, res[e], child.data() + (size_t)e * stride * 4));
+        Costed& c = m_Speculated[sources[owner]];
+        c.cfgBits.push_back((unsigned)(edges[e] >> 56));
+        const unsigned char* r = reinterpret_cast<const unsigned char*>(&res[e]);
+        c.records.insert(c.records.end(), r, r + sizeof(ppgpu_edge_result));
+        const double* cr = child.data() + (size_t)e * stride * 4;
+        c.childRibbons.insert(c.childRibbons.end(), cr, cr + (size_t)stride * 4);
     }
 }
 
@@ -367,6 +404,7 @@ void GpuAStarPlanner::expand(int source) {
     if (it == m_Speculated.end()) {
         std::vector<int> batch{source};
         const int want = m_Config.speculation();
+        std::unique_ptr<Lap> lap(new Lap(0));
         if (want > 1 && !m_Queue.empty()) {
             std::vector<int> cand;
             for (int v : m_Queue)
@@ -378,13 +416,22 @@ void GpuAStarPlanner::expand(int source) {
             });
             batch.insert(batch.end(), cand.begin(), cand.begin() + take);
         }
+        lap.reset();
         expandBatch(batch);
         it = m_Speculated.find(source);
     }
-    std::vector<Node> children = std::move(it->second);
+    Costed costed = std::move(it->second);
     m_Speculated.erase(it);
-    for (Node& c : children) {
-        m_Nodes.push_back(std::move(c));
+    Lap lapPush(4);
+    const bool watch = m_Config.visualizations();
+    for (size_t e = 0; e < costed.cfgBits.size(); e++) {
+        ppgpu_edge_result r;
+        std::memcpy(&r, costed.records.data() + e * sizeof(ppgpu_edge_result), sizeof(r));
+        // an infeasible edge is never pushed (SamplingBasedPlanner.cpp:8): no vertex is made for it, unless the search is being
+        // watched (its sweep is streamed all the same) or the record carries an error (makeChild throws what the reference throws)
+        const bool plainInfeasible = (r.flags & PPGPU_F_INFEASIBLE) && !(r.flags & (PPGPU_F_THROWS | PPGPU_F_RIBBON_OVF | PPGPU_F_DUBINS_ERR));
+        if (plainInfeasible && !watch) continue;
+        m_Nodes.push_back(makeChild(source, costed.cfgBits[e], r, costed.childRibbons.data() + e * (size_t)costed.stride * 4));
         visualizeTrajectory(m_Nodes.back());   // in the reference each edge streams its sweep, then its vertex is pushed
         pushVertexQueue((int)m_Nodes.size() - 1);
     }
@@ -596,6 +643,7 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
         m_Stats.PlanHValue = m_Nodes[m_Best].h;
         m_Stats.Plan = tracePlan(m_Best);
     }
+    g_prof.report("plan()");
     return m_Stats;
 }
 

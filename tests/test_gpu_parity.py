@@ -583,3 +583,45 @@ def test_wrapper_edges_match_oracle(torch_cuda):
     verts, pool = _children_as_vertices(w, gpu, gchild, feas[:: max(1, len(feas) // 30)][:30])
     rng = np.random.default_rng(17)
     assert fz.wrapper_leg(rng, ctx, world, w.cfg, verts, pool, cs[:, 0], cs[:, 1], cs[:, 2], False, per_vertex=40)
+
+
+@pytest.mark.parametrize("case", ["short_list", "many_equal", "some_equal", "k_larger_than_list"])
+def test_nearest_selection_corner_cases(torch_cuda, case):
+    """ppgpu_select_nearest keeps 'k smallest (length, sample index)' when the two-pass scheme cannot be used as is: fewer
+    entries than k threads hold one, thousands of identical samples (more survivors below the bound than its list holds), a
+    few identical samples among many, and k larger than the whole list (unused slots report -1)."""
+    from path_planner_amd import api, workloads
+    w = workloads.config1()
+    ctx = api.Context(0)
+    ctx.set_config(w.cfg); ctx.set_grid(w.grid, w.res); ctx.set_obstacles(None)
+    ctx.set_vertices(w.root(), w.ribbons4)
+    rng = np.random.default_rng(4)
+    x0, y0 = float(w.start5[0]), float(w.start5[1])
+    k = 9
+    if case == "short_list":
+        n = 6
+        sx, sy, sh = x0 + rng.uniform(-60, 60, n), y0 + rng.uniform(-60, 60, n), rng.uniform(0, 6.28, n)
+    elif case == "k_larger_than_list":
+        n, k = 300, 40
+        sx, sy, sh = x0 + rng.uniform(-60, 60, n), y0 + rng.uniform(-60, 60, n), rng.uniform(0, 6.28, n)
+        sx[:280], sy[:280] = x0, y0          # closer than the increment: not candidates
+    elif case == "many_equal":
+        n = 5000
+        sx, sy, sh = np.full(n, x0 + 12.0), np.full(n, y0 + 7.0), np.full(n, 1.0)
+        sx[4000:] += rng.uniform(1, 40, 1000)
+    else:
+        n = 4000
+        sx, sy, sh = x0 + rng.uniform(-60, 60, n), y0 + rng.uniform(-60, 60, n), rng.uniform(0, 6.28, n)
+        sx[100:130], sy[100:130], sh[100:130] = x0 + 3.0, y0 + 2.0, 0.5      # 30 identical near ones
+    ctx.set_samples(sx, sy, sh)
+    d_len = torch_cuda.zeros(n * 2, dtype=torch_cuda.float64, device="cuda:0")
+    ctx.dubins_lengths(0, 1, d_len.data_ptr()); ctx.synchronize()
+    L = d_len.cpu().numpy().reshape(n, 2)
+    idx, ln = ctx.select_nearest(0, 1, k)
+    for r in range(2):
+        col = L[:, r]
+        cand = np.nonzero(col >= 0)[0]
+        order = cand[np.lexsort((cand, col[cand]))][:k]
+        want = np.full(k, -1); want[:len(order)] = order
+        assert idx[0, r].tolist() == want.tolist(), (case, r)
+        assert np.array_equal(ln[0, r][:len(order)], col[order]) and np.all(ln[0, r][len(order):] == -1.0)
