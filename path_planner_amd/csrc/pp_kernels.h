@@ -60,9 +60,14 @@ struct __attribute__((aligned(128))) PPEdgeSetup {
 // advances `intermediate.time() += timeIncrement` once per step, so step times are a running
 // sum, not t0 + k*inc; they depend only on the source vertex's time, hence one table per vertex
 // (ng entries), built sequentially by one lane per vertex.
-// One wavefront per vertex: lane 0 runs the dependent chain of additions (that is the reference's arithmetic: it cannot be
-// reassociated) into LDS, 2 048 steps at a time, and the 64 lanes then copy the segment out coalesced.  (One thread per
-// vertex storing every step straight to global memory took 29 us for a 1 500-step row; this takes a fraction of that.)
+// One wavefront per vertex.  The running sum cannot be reassociated, but it can be GUESSED and CHECKED in parallel: while the
+// times stay in one binade, adding the increment to a representable time moves it by the same whole number of ulps every
+// step, so from an exact anchor t_s the row is t_s + (k - s) * c with c = fl(t_s + inc) - t_s.  Every lane then verifies the
+// reference's own recurrence on its entries, fl(t_k + inc) == t_(k+1): the anchor is exact, so by induction everything before
+// the first failing k is the sequential result bit for bit.  At a failure (a binade boundary: the ulp doubles) the next time is
+// computed the reference's way and becomes the new anchor.  An increment that falls exactly between two ulps (ties to even
+// alternate) would fail every other step: after a few restarts the rest of the row is done by the sequential chain (lane 0 into
+// LDS, 2 048 steps at a time, copied out coalesced).  19 us -> 2 us for a 1 500-step row on the planner's 16-vertex round trips.
 #define PP_TG_SEG 2048
 __global__ __launch_bounds__(64) void pp_k_time_grid(const ppgpu_vertex* verts, int nverts, double sst, double inc_d, double max_speed,
                                                     int ng, double* tgrid) {
@@ -76,7 +81,25 @@ __global__ __launch_bounds__(64) void pp_k_time_grid(const ppgpu_vertex* verts, 
     double timeNudge = fmod(timeSinceStart, timeIncrement);   // :118
     t += timeNudge;                                           // :119
     double* row = tgrid + (size_t)v * ng;
-    for (int k0 = 0; k0 < ng; k0 += PP_TG_SEG) {
+    int s = 0;                                                // row[s] = t is exact
+    for (int tries = 0; s < ng && tries < 8; tries++) {
+        const double c = (t + timeIncrement) - t;             // what one step adds on this ulp grid
+        int firstBad = ng;
+        for (int k0 = s; k0 < ng; k0 += 64) {
+            const int k = k0 + lane;
+            const double val = t + (double)(k - s) * c;
+            const double nxt = t + (double)(k + 1 - s) * c;
+            if (k < ng) row[k] = val;
+            const bool bad = (k < ng - 1) && !(val + timeIncrement == nxt);      // :173, checked
+            const unsigned long long m = __ballot(bad);
+            if (m != 0ull) { firstBad = k0 + (int)__builtin_ctzll(m); break; }
+        }
+        if (firstBad == ng) { s = ng; break; }
+        const double tf = t + (double)(firstBad - s) * c;     // verified entry
+        t = tf + timeIncrement;                               // the reference's own step across the boundary
+        s = firstBad + 1;
+    }
+    for (int k0 = s; k0 < ng; k0 += PP_TG_SEG) {              // only after repeated failures: the dependent chain
         const int m = (ng - k0) < PP_TG_SEG ? (ng - k0) : PP_TG_SEG;
         if (lane == 0) {
             for (int k = 0; k < m; k++) {
@@ -87,6 +110,7 @@ __global__ __launch_bounds__(64) void pp_k_time_grid(const ppgpu_vertex* verts, 
         __syncthreads();
         for (int k = lane; k < m; k += 64) row[k0 + k] = seg[k];
         __syncthreads();
+        t = __shfl(t, 0, 64);
     }
 }
 
@@ -194,6 +218,7 @@ __global__ __launch_bounds__(256) void pp_k_solve_edges(PPParams p) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     // the queue heads of the kernels that follow (all of them start after this kernel has ended, in stream order)
     if (e < 4 * PP_NQ) p.work[(size_t)e * PP_QSTRIDE] = 0ull;
+    if (e == 0 && p.e_base == 0) *p.need_big = 0u;            // raised by the cover sweeps of this launch, read by pp_k_heuristic_big
     if (e >= p.n_edges) return;
     unsigned vi, target, cbits;
     const long long eg = pp_edge_position(p, p.e_base + e);   // position in the caller's edge list; e = position in this slice
@@ -1145,6 +1170,25 @@ __global__ __launch_bounds__(256) void pp_k_select_nearest(const double* lengths
         int rank = 0;
         for (int j = 0; j < m; j++) rank += pp_sel_less(sl[j], si[j], l, i) ? 1 : 0;
         if (rank < k) { oi[rank] = (int)i; ol[rank] = l; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// ppgpu_expand_host uploads one block {vertices | ribbons | explicit target x, y, heading per vertex | has-target flags} in one
+// copy; this puts its parts where the other kernels expect them (vertex array, ribbon pool, the slots behind the stored
+// samples, flags).  Everything is 8-byte words except the flags.
+__global__ __launch_bounds__(256) void pp_k_expand_unpack(const unsigned char* blk, int nv, int n_ribbons, ppgpu_vertex* verts, double* ribbons,
+                                                        double* ex, double* ey, double* eh, unsigned char* flags) {
+    const size_t wv = (size_t)nv * (sizeof(ppgpu_vertex) / 8), wr = (size_t)n_ribbons * 4;
+    const unsigned long long* src = (const unsigned long long*)blk;
+    const size_t total = wv + wr + 3 * (size_t)nv;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total + (size_t)nv; i += (size_t)gridDim.x * 256) {
+        if (i < wv) ((unsigned long long*)verts)[i] = src[i];
+        else if (i < wv + wr) ((unsigned long long*)ribbons)[i - wv] = src[i];
+        else if (i < wv + wr + nv) ((unsigned long long*)ex)[i - wv - wr] = src[i];
+        else if (i < wv + wr + 2 * (size_t)nv) ((unsigned long long*)ey)[i - wv - wr - nv] = src[i];
+        else if (i < total) ((unsigned long long*)eh)[i - wv - wr - 2 * (size_t)nv] = src[i];
+        else flags[i - total] = blk[total * 8 + (i - total)];
     }
 }
 

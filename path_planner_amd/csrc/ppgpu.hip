@@ -106,6 +106,7 @@ struct ppgpu_ctx {
     bool ev_valid = false;
     int max_vertex_ribbons = 0;
     DevBuf<int> tmp_idx;
+    DevBuf<unsigned char> dstage_in, dstage_out;            // device ends of ppgpu_expand_host's single upload / download
     void* stage_in = nullptr; size_t stage_in_cap = 0;      // pinned host staging of ppgpu_expand_host
     void* stage_out = nullptr; size_t stage_out_cap = 0;
     DevBuf<unsigned long long> gather;
@@ -155,7 +156,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->tmp_edges.release(); c->tmp_wedges.release(); c->partial.release(); c->tmp_results.release(); c->tmp_child.release();
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     c->setup.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
-    c->track_summary.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->work.release();
+    c->track_summary.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->work.release(); c->dstage_in.release(); c->dstage_out.release();
     if (c->stage_in) (void)hipHostFree(c->stage_in);
     if (c->stage_out) (void)hipHostFree(c->stage_out);
     for (int i = 0; i < 5; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -649,8 +650,7 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     {
         int rc = c->need_big.reserve(1, false, c->stream);
         if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(c->need_big.p, 0, sizeof(unsigned), c->stream));
-        p.need_big = c->need_big.p;
+        p.need_big = c->need_big.p;   // cleared by the first slice's pp_k_solve_edges
         if ((rc = c->work.reserve(PP_WORK_WORDS, false, c->stream))) return rc;
         p.work = c->work.p;
     }
@@ -884,16 +884,19 @@ int ppgpu_expand_host(ppgpu_ctx* c, int32_t nv, const ppgpu_vertex* hv, int32_t 
     const size_t need = (size_t)(ns + nv);
     if ((rc = c->verts.reserve((size_t)nv, false, st)) || (rc = c->ribbons.reserve((size_t)(n_ribbons > 0 ? n_ribbons : 1) * 4, false, st)) ||
         (rc = c->tgrid.reserve((size_t)nv * c->ng, false, st)) || (rc = c->sx.reserve(need, true, st)) || (rc = c->sy.reserve(need, true, st)) ||
-        (rc = c->sh.reserve(need, true, st)) || (rc = c->s_bytes.reserve((size_t)nv, false, st)) ||
-        (rc = c->tmp_edges.reserve((size_t)cap, false, st)) || (rc = c->tmp_results.reserve((size_t)cap, false, st)) ||
-        (h_child && (rc = c->tmp_child.reserve((size_t)cap * stride * 4, false, st))))
+        (rc = c->sh.reserve(need, true, st)) || (rc = c->s_bytes.reserve((size_t)nv, false, st)))
         return rc;
-    HIP_TRY(hipMemcpyAsync(c->verts.p, sin + o_v, (size_t)nv * sizeof(ppgpu_vertex), hipMemcpyHostToDevice, st));
-    if (n_ribbons > 0) HIP_TRY(hipMemcpyAsync(c->ribbons.p, sin + o_r, (size_t)n_ribbons * 4 * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(c->sx.p + ns, sin + o_x, (size_t)nv * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(c->sy.p + ns, sin + o_y, (size_t)nv * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(c->sh.p + ns, sin + o_h, (size_t)nv * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(c->s_bytes.p, sin + o_f, (size_t)nv, hipMemcpyHostToDevice, st));
+    // ---- stage out (device end): descriptors | records | child ribbons, one block, one download
+    const size_t q_e = 0, q_r = q_e + (size_t)cap * sizeof(uint64_t), q_c = q_r + (size_t)cap * sizeof(ppgpu_edge_result),
+                 out_bytes = q_c + (h_child ? (size_t)cap * stride * 4 * sizeof(double) : 0);
+    if ((rc = c->dstage_out.reserve(out_bytes, false, st))) return rc;
+    unsigned long long* d_edges = (unsigned long long*)(c->dstage_out.p + q_e);
+    ppgpu_edge_result* d_results = (ppgpu_edge_result*)(c->dstage_out.p + q_r);
+    double* d_child = h_child ? (double*)(c->dstage_out.p + q_c) : nullptr;
+    if ((rc = c->dstage_in.reserve(in_bytes, false, st))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->dstage_in.p, sin, in_bytes, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(pp_k_expand_unpack, dim3((unsigned)((in_bytes / 8 + nv + 255) / 256)), dim3(256), 0, st, c->dstage_in.p, nv, n_ribbons,
+                       c->verts.p, c->ribbons.p, c->sx.p + ns, c->sy.p + ns, c->sh.p + ns, c->s_bytes.p);
     c->nverts = nv; c->nribbons = n_ribbons; c->max_vertex_ribbons = maxr; c->n_extra = nv;
     hipLaunchKernelGGL(pp_k_time_grid, dim3((unsigned)nv), dim3(64), 0, st, c->verts.p, nv, c->cfg.start_state_time,
                        c->cfg.collision_checking_increment, c->cfg.max_speed, c->ng, c->tgrid.p);
@@ -911,25 +914,20 @@ int ppgpu_expand_host(ppgpu_ctx* c, int32_t nv, const ppgpu_vertex* hv, int32_t 
     const int two_speeds = (slow != c->cfg.max_speed) ? 1 : 0;                              // SamplingBasedPlanner.cpp:57-59
     const int two_radii = (c->cfg.coverage_turning_radius != c->cfg.turning_radius) ? 1 : 0;  // :60-63
     hipLaunchKernelGGL(pp_k_build_expand_edges, dim3((unsigned)((nv + 63) / 64)), dim3(64), 0, st, nv, k, select ? c->tmp_idx.p : nullptr,
-                       c->s_bytes.p, ns, two_speeds, two_radii, E, c->tmp_edges.p);
+                       c->s_bytes.p, ns, two_speeds, two_radii, E, d_edges);
     HIP_TRY(hipGetLastError());
     // ---- cost the whole list
-    if (h_child) HIP_TRY(hipMemsetAsync(c->tmp_child.p, 0, (size_t)cap * stride * 4 * sizeof(double), st));
+    if (h_child) HIP_TRY(hipMemsetAsync(d_child, 0, (size_t)cap * stride * 4 * sizeof(double), st));
     PPParams p;
     fill_params(c, p);
-    p.edges = c->tmp_edges.p; p.wedges = nullptr;
+    p.edges = d_edges; p.wedges = nullptr;
     p.v0 = 0; p.nv = 0; p.s0 = 0; p.ns = 1; p.cfg_mask = 0; p.per = 1;
     p.n_edges = cap;
-    p.out = c->tmp_results.p; p.child = h_child ? c->tmp_child.p : nullptr; p.stride = stride;
+    p.out = d_results; p.child = d_child; p.stride = stride;
     if ((rc = launch_cost(c, p))) return rc;
-    // ---- stage out: descriptors | records | child ribbons
-    const size_t q_e = 0, q_r = q_e + (size_t)cap * sizeof(uint64_t), q_c = q_r + (size_t)cap * sizeof(ppgpu_edge_result),
-                 out_bytes = q_c + (h_child ? (size_t)cap * stride * 4 * sizeof(double) : 0);
     if ((rc = stage_reserve(&c->stage_out, &c->stage_out_cap, out_bytes))) return rc;
     char* sout = (char*)c->stage_out;
-    HIP_TRY(hipMemcpyAsync(sout + q_e, c->tmp_edges.p, (size_t)cap * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(sout + q_r, c->tmp_results.p, (size_t)cap * sizeof(ppgpu_edge_result), hipMemcpyDeviceToHost, st));
-    if (h_child) HIP_TRY(hipMemcpyAsync(sout + q_c, c->tmp_child.p, (size_t)cap * stride * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(sout, c->dstage_out.p, out_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const uint64_t* se = (const uint64_t*)(sout + q_e);
     const ppgpu_edge_result* sr = (const ppgpu_edge_result*)(sout + q_r);

@@ -18,6 +18,7 @@ def _dense(torch, ctx, nv, n, mask, stride=8):
     ne = api.Context.dense_edge_count(nv, n, mask)
     d_res = torch.zeros(ne * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
     d_child = torch.zeros(ne * stride * 4, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()      # the fill ran on torch's stream, the library works on its own
     ctx.cost_edges_dense(0, nv, 0, n, mask, d_res.data_ptr(), d_child.data_ptr(), stride)
     ctx.synchronize()
     return d_res.cpu().numpy().view(RESULT_DTYPE), d_child.cpu().numpy().reshape(ne, stride, 4)
@@ -105,10 +106,13 @@ def test_children_as_sources_list_mode_and_best_edge(torch_cuda):
     d_e = torch.from_numpy(edges.view(np.int64)).to("cuda:0")
     d_res = torch.zeros(ne * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
     d_child = torch.zeros(ne * 10 * 4, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()      # the fill ran on torch's stream, the library works on its own
     ctx.cost_edges_list(ne, d_e.data_ptr(), d_res.data_ptr(), d_child.data_ptr(), 10)
     d_key = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()      # the fill ran on torch's stream, the library works on its own
     ctx.best_edge(ne, d_res.data_ptr(), d_key.data_ptr(), goal_only=False, base=7000)
     d_keyg = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()      # the fill ran on torch's stream, the library works on its own
     ctx.best_edge(ne, d_res.data_ptr(), d_keyg.data_ptr(), goal_only=True, base=0)
     ctx.synchronize()
     g2 = d_res.cpu().numpy().view(RESULT_DTYPE)
@@ -146,6 +150,7 @@ def test_dubins_lengths_and_nearest_selection(torch_cuda):
     ctx.set_vertices(verts, pool)
     nv = len(verts)
     d_len = torch.zeros(nv * n * 2, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()      # the fill ran on torch's stream, the library works on its own
     ctx.dubins_lengths(0, nv, d_len.data_ptr())
     ctx.synchronize()
     L = d_len.cpu().numpy().reshape(nv, n, 2)
@@ -615,6 +620,7 @@ def test_nearest_selection_corner_cases(torch_cuda, case):
         sx[100:130], sy[100:130], sh[100:130] = x0 + 3.0, y0 + 2.0, 0.5      # 30 identical near ones
     ctx.set_samples(sx, sy, sh)
     d_len = torch_cuda.zeros(n * 2, dtype=torch_cuda.float64, device="cuda:0")
+    torch_cuda.cuda.synchronize()      # the fill ran on torch's stream, the library works on its own
     ctx.dubins_lengths(0, 1, d_len.data_ptr()); ctx.synchronize()
     L = d_len.cpu().numpy().reshape(n, 2)
     idx, ln = ctx.select_nearest(0, 1, k)
