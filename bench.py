@@ -178,10 +178,46 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline_and_parity(ctx, w, res))
             out.update(first_goal_check())
+        if world == 1:
+            out.update(open_vertex_run(ctx, w, torch, dev))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def open_vertex_run(ctx, w, torch, dev):
+    """SURVEY 8(d) config 3, second half: 64 open vertices (the root and 63 of its first-generation children, each with its own
+    time grid, ribbon list and coverage state) x 4 096 samples x 4 configurations in one launch.  Reported beside the headline
+    figure, never part of it."""
+    import numpy as np
+    from path_planner_amd.types import RESULT_DTYPE, VERTEX_DTYPE, F_INFEASIBLE, F_GOAL, edge_pack
+    ns, stride = 4096, 12
+    res, child = ctx.cost_edges_host(edge_pack(np.zeros(4096, dtype=np.uint64), np.arange(4096) // 4, np.arange(4096) % 4), stride=stride)
+    ok = np.nonzero(((res["flags"] & (F_INFEASIBLE | F_GOAL)) == 0) & (((res["info"] >> 8) & 0xFF) <= stride))[0][:63]
+    v = np.zeros(len(ok) + 1, dtype=VERTEX_DTYPE)
+    pool = [np.asarray(w.ribbons4, dtype=np.float64).reshape(-1, 4)]
+    v[0] = w.root()[0]
+    off = len(pool[0])
+    for k, e in enumerate(ok):
+        r, nr = res[e], int((res[e]["info"] >> 8) & 0xFF)
+        v[k + 1] = (r["end_x"], r["end_y"], r["end_heading"], r["end_speed"], r["end_time"], r["g"], r["coverage_completed_time"], off, nr)
+        pool.append(child[e, :nr]); off += nr
+    ctx.set_vertices(v, np.concatenate(pool))
+    ne = len(v) * ns * 4
+    d = torch.zeros(ne * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    ts = []
+    for _ in range(4):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); ctx.cost_edges_dense(0, len(v), 0, ns, 0xF, d.data_ptr()); b.record()
+        torch.cuda.synchronize(dev)
+        ts.append(a.elapsed_time(b))
+    ms = float(np.median(ts[1:]))
+    r = d.cpu().numpy().view(RESULT_DTYPE)
+    ctx.set_vertices(w.root(), w.ribbons4)
+    return {"open_vertex_run": {"open_vertices": int(len(v)), "samples": ns, "edges": int(ne), "ms": ms, "edges_per_s": ne / (ms * 1e-3),
+                                "mean_sweep_steps_per_edge": float((r["info"] >> 16).mean()),
+                                "feasible_fraction": float(((r["flags"] & F_INFEASIBLE) == 0).mean())}}
 
 
 def cpu_baseline_and_parity(ctx, w, gpu_res):
