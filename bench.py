@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=65536, help="sample attempts per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--open-vertex-run", action="store_true",
+                    help="also time the 64-open-vertex x 4096-sample launch of SURVEY config 3 (extra launches: not in profiled runs)")
     args = ap.parse_args()
 
     import numpy as np
@@ -178,7 +180,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline_and_parity(ctx, w, res))
             out.update(first_goal_check())
-        if world == 1:
+        if world == 1 and args.open_vertex_run:
             out.update(open_vertex_run(ctx, w, torch, dev))
         print(json.dumps(out), flush=True)
     if world > 1:
