@@ -51,9 +51,12 @@ struct __attribute__((aligned(128))) PPEdgeSetup {
     double qx, qy, rho, rho_inv, length;   // DubinsPath::qi (position), rho, path length
     double wStart, wEnd, speed;            // DubinsWrapper start / end time and speed
     double approx, p0, p1, p2;             // Edge::approxCost, DubinsPath::param (only read when the record is written)
+    double tfar;                           // curve parameter (arc length / rho) beyond which the curve stays clear of every ribbon of
+                                           // the source vertex (pp_curve_clear_after); +inf: unknown
     int type;                              // DubinsPathType, -1 = no path
     unsigned vi, cbits, sflags;
 };
+static_assert(sizeof(PPEdgeSetup) == 384, "PPEdgeSetup is sized for three 128-byte lines");
 
 // ------------------------------------------------------------------------------------------
 // Collision-check time grid, one row per open vertex (Edge.cpp:114-120,173): the reference
@@ -151,6 +154,67 @@ __device__ __forceinline__ void pp_edge_decode(const PPParams& p, long long e, u
 
 // Phase 0 for every edge of a launch, one lane per edge (Vertex::connect -> Edge::computeApproxCost ->
 // DubinsWrapper::set, Edge.cpp:14-18,73-76; Edge::setEnd(wrapper), Edge.cpp:208-216 for wrapper edges).
+// From which curve parameter on does a solved curve stay clear of every ribbon of its source vertex?  "Clear" is what
+// pp_ribbons_event's bounding-box path needs: outside each ribbon's bounding box grown by the ribbon width (and 2 mm).  cover()
+// only ever shortens or splits ribbons, so the pieces an edge is left with lie inside the boxes of the ribbons it started
+// with; past that parameter every coverage event finds nothing to contain the vehicle and changes nothing, whatever happened
+// before, and the cover sweep stops visiting them (it checks for itself that no piece is short enough to be erased).
+// Conservative geometry, one lane per edge: an arc is taken whole - it counts as touching a box when both the bounding square
+// of its circle and (for sweeps up to half a turn) the box of its chord grown by the sagitta overlap it; the straight piece is
+// clipped against the box (slab test) and counts up to where it leaves it.
+__device__ inline double pp_curve_clear_after(const PPCurve& c, const double* ribbons4, int n, double w) {
+    if (n <= 0) return INFINITY;                         // a finished vertex: its events do other things (Edge.cpp:162-170)
+    const double rho = c.rho, g = w + 2e-3;
+    const double lo[3] = {0.0, c.p0, c.p0 + c.p1}, len[3] = {c.p0, c.p1, c.p2};
+    const int typ[3] = {c.t0, c.t1, c.t2};
+    // segment end points in world coordinates: start, after segment 0, after segment 1, end of the curve
+    double ex2, ey2, eth2;
+    pp_curve_seg(c.t2, c.p2, c.b2x, c.b2y, c.b2th, c.s2, c.c2, ex2, ey2, eth2);
+    const double px[4] = {c.qx, c.b1x * rho + c.qx, c.b2x * rho + c.qx, ex2 * rho + c.qx};
+    const double py[4] = {c.qy, c.b1y * rho + c.qy, c.b2y * rho + c.qy, ey2 * rho + c.qy};
+    const double sb[3] = {c.s0, c.s1, c.s2}, cb[3] = {c.c0, c.c1, c.c2};
+    double ccx[3], ccy[3], sag[3];
+    const double ubx[3] = {0.0, c.b1x, c.b2x}, uby[3] = {0.0, c.b1y, c.b2y};          // segment bases, unit radius, origin at qi
+    for (int s = 0; s < 3; s++) {
+        ccx[s] = ((typ[s] == 0) ? (ubx[s] - sb[s]) : (ubx[s] + sb[s])) * rho + c.qx;   // centre of the segment's circle (pp_curve_seg)
+        ccy[s] = ((typ[s] == 0) ? (uby[s] + cb[s]) : (uby[s] - cb[s])) * rho + c.qy;
+        sag[s] = (len[s] <= 3.14159) ? rho * (1.0 - cos(0.5 * len[s])) * (1.0 + 1e-9) + 1e-6 : INFINITY;
+    }
+    const double rr = rho * (1.0 + 1e-9) + 1e-6;
+    double tfar = 0.0;
+    for (int i = 0; i < n; i++) {
+        const double sx = ribbons4[4 * i], sy = ribbons4[4 * i + 1], ex = ribbons4[4 * i + 2], ey = ribbons4[4 * i + 3];
+        const double bx0 = fmin(sx, ex) - g, bx1 = fmax(sx, ex) + g, by0 = fmin(sy, ey) - g, by1 = fmax(sy, ey) + g;
+        for (int s = 0; s < 3; s++) {
+            if (!(len[s] > 0.0)) continue;
+            if (typ[s] != 1) {
+                bool touch = (ccx[s] + rr >= bx0) & (ccx[s] - rr <= bx1) & (ccy[s] + rr >= by0) & (ccy[s] - rr <= by1);
+                if (touch && sag[s] < INFINITY) {
+                    const double x0 = fmin(px[s], px[s + 1]) - sag[s], x1 = fmax(px[s], px[s + 1]) + sag[s];
+                    const double y0 = fmin(py[s], py[s + 1]) - sag[s], y1 = fmax(py[s], py[s + 1]) + sag[s];
+                    touch = (x1 >= bx0) & (x0 <= bx1) & (y1 >= by0) & (y0 <= by1);
+                }
+                if (touch) tfar = fmax(tfar, lo[s] + len[s]);
+            } else {
+                // clip P(u) = P0 + u * d, u in [0, L], against the box (slabs); d = (cos, sin) of the base heading
+                const double L = len[s] * rho, dx = cb[s], dy = sb[s];
+                double u0 = -1e-6, u1 = L + 1e-6;
+                bool miss = false;
+                if (fabs(dx) > 1e-12) {
+                    const double a = (bx0 - px[s]) / dx, b = (bx1 - px[s]) / dx;
+                    u0 = fmax(u0, fmin(a, b) - 1e-6); u1 = fmin(u1, fmax(a, b) + 1e-6);
+                } else miss |= (px[s] < bx0 - 1e-6) | (px[s] > bx1 + 1e-6);
+                if (fabs(dy) > 1e-12) {
+                    const double a = (by0 - py[s]) / dy, b = (by1 - py[s]) / dy;
+                    u0 = fmax(u0, fmin(a, b) - 1e-6); u1 = fmin(u1, fmax(a, b) + 1e-6);
+                } else miss |= (py[s] < by0 - 1e-6) | (py[s] > by1 + 1e-6);
+                if (!miss && u0 <= u1) tfar = fmax(tfar, lo[s] + fmin(u1, L) / rho);
+            }
+        }
+    }
+    return tfar + 1e-9;
+}
+
 // A per-edge kernel can be launched as a resident grid whose waves pull edges from queues, in launch order, instead of one
 // workgroup per PP_WPB edges.  Edges differ in length by two orders of magnitude (blocked at the first step ... the full
 // horizon); the cover sweep runs 4 waves per SIMD (128 VGPRs) and with dispatcher-placed workgroups the counters show 3.15 of
@@ -270,6 +334,14 @@ __global__ __launch_bounds__(256) void pp_k_solve_edges(PPParams p) {
     O->p0 = cv.p0; O->p1 = cv.p1; O->p2 = cv.p2;
     O->approx = S.approx; O->wStart = S.wStart; O->wEnd = S.wEnd; O->speed = S.speed;
     O->type = S.type; O->vi = S.vi; O->cbits = S.cbits; O->sflags = S.sflags;
+    double tfar = INFINITY;
+#ifndef PP_NO_TFAR
+    if (S.type >= 0 && !(S.sflags & PP_SETUP_MALFORMED)) {
+        const ppgpu_vertex* V = p.verts + vi;
+        tfar = pp_curve_clear_after(cv, p.ribbons + 4 * (size_t)V->ribbon_offset, V->ribbon_count, p.ribw);
+    }
+#endif
+    O->tfar = tfar;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -574,7 +646,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
     int dbgEvents = 0;
 #endif
 #ifdef PP_DBG_COUNTS
-    int dbgWindows = 0, dbgCorr = 0, dbgQuiet = 0, dbgGeneric = 0, dbgCorrLen = 0, dbgQuietLen = 0, dbgFar = 0, dbgNoChange = 0, dbgInPlace = 0;
+    int dbgWindows = 0, dbgCorr = 0, dbgQuiet = 0, dbgGeneric = 0, dbgCorrLen = 0, dbgQuietLen = 0, dbgFar = 0, dbgNoChange = 0, dbgInPlace = 0, dbgRestFar = 0;
 #define PP_CNT(x) x
 #else
 #define PP_CNT(x)
@@ -596,6 +668,18 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
         bool contMoveEnd = false;
         while (!ended) {
             if (nextEvent >= limit) break;
+#ifndef PP_NO_TFAR
+            if (nrib > 0) {
+                // past the point from which the curve stays clear of every ribbon this vertex had (PPEdgeSetup::tfar), every
+                // further event only measures a distance: none of them is visited, provided no piece is waiting to be erased
+                const double tpn = (pp_const_f64(tg + nextEvent)[0] - wStart) * speed / pp_const_f64(&S->rho)[0];
+                if (tpn > pp_const_f64(&S->tfar)[0]) {
+                    const double minLength0 = 2 * w;
+                    const bool tiny = (lane < nrib) & (pp_sq_len(rib.sx, rib.sy, rib.ex, rib.ey) < minLength0 * minLength0 / (2.0 * 2.0));
+                    if (__ballot(tiny) == 0ull) { PP_CNT(dbgRestFar++); break; }
+                }
+            }
+#endif
             // a window of 64 steps of the track starting AT the next event, one step per lane (stretches without events are
             // never loaded)
             const int base = nextEvent;
@@ -656,6 +740,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                 nrib = pp_ribbons_event(rib, nrib, w, xj, yj, ((coverMask >> j) & 1ull) != 0ull, lds, D, adv);
                 PP_CNT(if (adv == -3) dbgFar++; else if (adv == -2) dbgNoChange++; else if (adv >= 0) dbgInPlace++);
                 if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
+
 #ifndef PP_NO_CORRIDOR_RUN
                 if (adv >= 0 && j + 1 < climit && !runFailed) {
                     // this event only moved one piece's endpoint: the following steps very likely do the same
@@ -865,7 +950,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
             case 10: v = h; break;
             case 11: v = g + h; break;
 #ifdef PP_DBG_COUNTS
-            case 12: v = (double)dbgFar * 1e6 + (double)dbgNoChange * 1e3 + (double)dbgInPlace; break;
+            case 12: v = (double)dbgRestFar * 1e9 + (double)dbgFar * 1e6 + (double)dbgNoChange * 1e3 + (double)dbgInPlace; break;
             case 13: v = (double)dbgWindows * 1e6 + (double)dbgGeneric; break;
             case 14: v = (double)dbgCorr * 1e6 + (double)dbgCorrLen; break;
             default: v = (double)dbgQuiet * 1e6 + (double)dbgQuietLen; break;

@@ -23,12 +23,13 @@ win, gen = p[:, 0] // 1e6, p[:, 0] % 1e6
 cor, corl = p[:, 1] // 1e6, p[:, 1] % 1e6
 qui, quil = p[:, 2] // 1e6, p[:, 2] % 1e6
 cc = r["coverage_completed_time"]
-far, noch, inpl = cc // 1e6, (cc % 1e6) // 1e3, cc % 1e3
+restfar, far, noch, inpl = cc // 1e9, (cc % 1e9) // 1e6, (cc % 1e6) // 1e3, cc % 1e3
 for c in range(4):
     m = slice(c, None, 4)
     print(f"cfg {c}: windows {win[m].mean():6.2f}  generic events {gen[m].mean():6.2f}  corridor runs {cor[m].mean():6.2f} (steps {corl[m].mean():7.1f})"
           f"  quiet runs {qui[m].mean():6.2f} (steps {quil[m].mean():7.1f})")
 print(f"generic events by kind: far fast path {far.mean():.2f}, near but nothing changed {noch.mean():.2f}, in-place endpoint move {inpl.mean():.2f}, "
       f"other (split / erase / compaction) {(gen - far - noch - inpl).mean():.2f}")
+print(f"edges whose event loop ended on 'the rest of the curve is far': {restfar.mean():.3f}; far events of the others: {far[restfar == 0].mean():.2f}")
 print(f"all  : windows {win.mean():6.2f}  generic events {gen.mean():6.2f}  corridor runs {cor.mean():6.2f} (steps {corl.mean():7.1f})"
       f"  quiet runs {qui.mean():6.2f} (steps {quil.mean():7.1f})")
