@@ -159,9 +159,13 @@ __device__ __forceinline__ void pp_edge_decode(const PPParams& p, long long e, u
 // only ever shortens or splits ribbons, so the pieces an edge is left with lie inside the boxes of the ribbons it started
 // with; past that parameter every coverage event finds nothing to contain the vehicle and changes nothing, whatever happened
 // before, and the cover sweep stops visiting them (it checks for itself that no piece is short enough to be erased).
-// Conservative geometry, one lane per edge: an arc is taken whole - it counts as touching a box when both the bounding square
-// of its circle and (for sweeps up to half a turn) the box of its chord grown by the sagitta overlap it; the straight piece is
-// clipped against the box (slab test) and counts up to where it leaves it.
+// Conservative geometry, one lane per edge: an arc can touch a box only if the bounding square of its circle and (for sweeps up
+// to half a turn) the box of its chord grown by the sagitta overlap it; such an arc is cut into eight pieces, each inside its
+// own chord-plus-sagitta box, and counts up to the end of the last piece that touches; the straight piece is clipped against
+// the box (slab test) and counts up to where it leaves it.
+#ifndef PP_CLEAR_SUB
+#define PP_CLEAR_SUB 8
+#endif
 __device__ inline double pp_curve_clear_after(const PPCurve& c, const double* ribbons4, int n, double w) {
     if (n <= 0) return INFINITY;                         // a finished vertex: its events do other things (Edge.cpp:162-170)
     const double rho = c.rho, g = w + 2e-3;
@@ -178,24 +182,59 @@ __device__ inline double pp_curve_clear_after(const PPCurve& c, const double* ri
     for (int s = 0; s < 3; s++) {
         ccx[s] = ((typ[s] == 0) ? (ubx[s] - sb[s]) : (ubx[s] + sb[s])) * rho + c.qx;   // centre of the segment's circle (pp_curve_seg)
         ccy[s] = ((typ[s] == 0) ? (uby[s] + cb[s]) : (uby[s] - cb[s])) * rho + c.qy;
-        sag[s] = (len[s] <= 3.14159) ? rho * (1.0 - cos(0.5 * len[s])) * (1.0 + 1e-9) + 1e-6 : INFINITY;
+        sag[s] = (len[s] <= 3.14159) ? rho * (len[s] * len[s] * 0.125) * (1.0 + 1e-9) + 1e-6 : INFINITY;   // 1 - cos(a/2) <= a^2/8
     }
     const double rr = rho * (1.0 + 1e-9) + 1e-6;
     double tfar = 0.0;
-    for (int i = 0; i < n; i++) {
-        const double sx = ribbons4[4 * i], sy = ribbons4[4 * i + 1], ex = ribbons4[4 * i + 2], ey = ribbons4[4 * i + 3];
-        const double bx0 = fmin(sx, ex) - g, bx1 = fmax(sx, ex) + g, by0 = fmin(sy, ey) - g, by1 = fmax(sy, ey) + g;
-        for (int s = 0; s < 3; s++) {
-            if (!(len[s] > 0.0)) continue;
-            if (typ[s] != 1) {
+    for (int s = 2; s >= 0 && tfar == 0.0; s--) {        // from the end of the curve: the last segment that touches decides
+        if (!(len[s] > 0.0)) continue;
+        if (typ[s] != 1) {
+            // which boxes can this arc touch at all?
+            unsigned long long may = 0ull;
+            for (int i = 0; i < n; i++) {
+                const double sx = ribbons4[4 * i], sy = ribbons4[4 * i + 1], ex = ribbons4[4 * i + 2], ey = ribbons4[4 * i + 3];
+                const double bx0 = fmin(sx, ex) - g, bx1 = fmax(sx, ex) + g, by0 = fmin(sy, ey) - g, by1 = fmax(sy, ey) + g;
                 bool touch = (ccx[s] + rr >= bx0) & (ccx[s] - rr <= bx1) & (ccy[s] + rr >= by0) & (ccy[s] - rr <= by1);
                 if (touch && sag[s] < INFINITY) {
                     const double x0 = fmin(px[s], px[s + 1]) - sag[s], x1 = fmax(px[s], px[s + 1]) + sag[s];
                     const double y0 = fmin(py[s], py[s + 1]) - sag[s], y1 = fmax(py[s], py[s + 1]) + sag[s];
                     touch = (x1 >= bx0) & (x0 <= bx1) & (y1 >= by0) & (y0 <= by1);
                 }
-                if (touch) tfar = fmax(tfar, lo[s] + len[s]);
-            } else {
+                if (touch) may |= 1ull << i;
+            }
+            if (may == 0ull) continue;
+            // the arc in PP_CLEAR_SUB pieces (each inside its chord's box grown by its sagitta): the last piece that touches a box
+            double qx_[PP_CLEAR_SUB + 1], qy_[PP_CLEAR_SUB + 1];
+            qx_[0] = px[s]; qy_[0] = py[s]; qx_[PP_CLEAR_SUB] = px[s + 1]; qy_[PP_CLEAR_SUB] = py[s + 1];
+            const double sub = len[s] / PP_CLEAR_SUB;
+            {
+                // the division points by rotating the radius vector (their error, ~1e-15, disappears in the margins)
+                double sd, cd;
+                pp_sincos_bounded((typ[s] == 0) ? sub : -sub, &sd, &cd);
+                double rx = px[s] - ccx[s], ry = py[s] - ccy[s];
+                for (int j = 1; j < PP_CLEAR_SUB; j++) {
+                    const double nx = rx * cd - ry * sd, ny = rx * sd + ry * cd;
+                    rx = nx; ry = ny;
+                    qx_[j] = ccx[s] + rx; qy_[j] = ccy[s] + ry;
+                }
+            }
+            const double sg = rho * (sub * sub * 0.125) * (1.0 + 1e-9) + 1e-5;          // sagitta bound, and room for the rotations' rounding
+            int last = -1;
+            for (int i = 0; i < n; i++) {
+                if (!((may >> i) & 1ull)) continue;
+                const double sx = ribbons4[4 * i], sy = ribbons4[4 * i + 1], ex = ribbons4[4 * i + 2], ey = ribbons4[4 * i + 3];
+                const double bx0 = fmin(sx, ex) - g, bx1 = fmax(sx, ex) + g, by0 = fmin(sy, ey) - g, by1 = fmax(sy, ey) + g;
+                for (int j = PP_CLEAR_SUB - 1; j > last; j--) {
+                    const double x0 = fmin(qx_[j], qx_[j + 1]) - sg, x1 = fmax(qx_[j], qx_[j + 1]) + sg;
+                    const double y0 = fmin(qy_[j], qy_[j + 1]) - sg, y1 = fmax(qy_[j], qy_[j + 1]) + sg;
+                    if ((x1 >= bx0) & (x0 <= bx1) & (y1 >= by0) & (y0 <= by1)) { last = j; break; }
+                }
+            }
+            if (last >= 0) tfar = fmax(tfar, lo[s] + fmin(len[s], sub * (double)(last + 1) * (1.0 + 1e-12)));
+        } else {
+            for (int i = 0; i < n; i++) {
+                const double sx = ribbons4[4 * i], sy = ribbons4[4 * i + 1], ex = ribbons4[4 * i + 2], ey = ribbons4[4 * i + 3];
+                const double bx0 = fmin(sx, ex) - g, bx1 = fmax(sx, ex) + g, by0 = fmin(sy, ey) - g, by1 = fmax(sy, ey) + g;
                 // clip P(u) = P0 + u * d, u in [0, L], against the box (slabs); d = (cos, sin) of the base heading
                 const double L = len[s] * rho, dx = cb[s], dy = sb[s];
                 double u0 = -1e-6, u1 = L + 1e-6;
