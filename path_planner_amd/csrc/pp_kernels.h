@@ -384,9 +384,11 @@ __global__ __launch_bounds__(256) void pp_k_solve_edges(PPParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Edge costing = three launches over the same edge list, one wavefront-sized piece of work each:
+// Edge costing = four launches over the same edge list (the fourth, pp_k_heuristic, further down), one wavefront-sized piece
+// of work each:
 //
-//   pp_k_solve_edges  (lane per edge)  phase 0: Vertex::connect + Edge::computeApproxCost: Dubins solve, curve constants
+//   pp_k_solve_edges  (lane per edge)  phase 0: Vertex::connect + Edge::computeApproxCost: Dubins solve, curve constants,
+//                                      and from where on the curve is clear of the vertex's ribbons (pp_curve_clear_after)
 //   pp_k_pose_sweep   (wave per edge)  phase A: 64 consecutive collision-check steps at a time: closed-form pose,
 //                                      occupancy lookup, dynamic-obstacle box tests  ->  the edge's "track"
 //   pp_k_cover_sweep  (wave per edge)  phase B: the sequential coverage state machine of Edge.cpp:153-171, visited only
