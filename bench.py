@@ -126,9 +126,11 @@ def main():
         # the whole edge's (descriptor, source vertex, ribbons in and out, record, grid bits); the cover sweep is the
         # kernel that reads the ribbons and writes the record and the child ribbons.
         bytes_per_edge = 88 + 32 + 32 * R + 56 * M / 4.0 + 150 + steps_mean / 8.0
-        flops_per_edge = 1000 + steps_mean * (70 + 21 * M)               # pose + cover sweeps; the heuristic kernel is ~4e4 more
+        flops_per_edge = 1000 + steps_mean * (70 + 21 * M) + 4e4        # solve + sweeps + heuristic
         ach_gbs = bytes_per_edge * n_edges_launch / (kern_ms * 1e-3) / 1e9
-        ach_tf = flops_per_edge * n_edges_launch / ((pose_ms + cover_ms) * 1e-3) / 1e12
+        # over the whole costing launch: the cover sweep's wave also runs the edge's heuristic (PP_FUSE_HEUR), so the kernels
+        # are not priced separately
+        ach_tf = flops_per_edge * n_edges_launch / (launch_ms * 1e-3) / 1e12
         # what goes through HBM between the kernels of one launch: the solved curve (384 B), the pose
         # sweep's summary (16 B) and its per-chunk words (12 B per 64 steps); poses are recomputed, not stored
         workspace_bytes_per_edge = 384 + 16 + 12.0 * (steps_mean / 64.0)
@@ -168,6 +170,8 @@ def main():
                          "traffic": traffic, "kernel": "pp_k_cover_sweep", "kernel_ms": kern_ms,
                          "kernels_ms": {"pp_k_solve_edges": solve_ms, "pp_k_pose_sweep": pose_ms, "pp_k_cover_sweep": cover_ms,
                                         "pp_k_heuristic": heur_ms},
+                         "kernels_note": "pp_k_cover_sweep includes the edges' heuristic (same wavefront, PP_FUSE_HEUR); "
+                                         "pp_k_heuristic is what is left in separate heuristic kernels (the 12-ribbon pass)",
                          "algorithmic_bytes_per_edge": bytes_per_edge, "workspace_bytes_per_edge": workspace_bytes_per_edge,
                          "collision_sweep_hbm": sweep_hbm,
                          "note": "all four kernels are fp64-VALU bound, not HBM bound (SURVEY 8d): see valu_fp64"},

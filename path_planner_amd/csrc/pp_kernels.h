@@ -9,6 +9,7 @@ struct PPParams {
     double max_speed, slow_speed, rho, rho_cov, horizon, tmin, inc_d, sst, ribw, cpf, tpf;
     double inv_inc_d;                    // 1 / inc_d (host division): first guess of a quotient that is then verified
     int heuristic, tsp_k;
+    int fuse_h;                          // the cover sweep's wave goes straight on to the edge's heuristic (see PP_FUSE_HEUR)
     double h_rho;                        // RibbonManager::m_TurningRadius of the Dubins-TSP heuristics
     // world
     PPGrid grid;
@@ -1029,12 +1030,30 @@ __global__ __launch_bounds__(PP_WPB * 64, 4) void pp_k_pose_sweep_gaussian(PPPar
     for (PP_EACH_EDGE(idx, 1, PP_Q_POSE, p.n_edges, 1))
         pp_pose_sweep_edge<true>(p, p.ws_base + idx);
 }
+// The wave that finished an edge's cover sweep goes straight on to the edge's heuristic (point heuristics, binary-obstacle
+// sweep; the Dubins heuristics and the 12-ribbon pass keep their own kernels): the child ribbons and the record it needs were
+// just written by the same wave, there is no second launch, and the two phases' stalls fall at different times in the four
+// waves of a SIMD.  Cover sweep + heuristic 2.26 -> 2.18 ms (tools/ablate.py fuse0).
+#ifndef PP_FUSE_HEUR
+#define PP_FUSE_HEUR 1
+#endif
+template <bool DUBINS, int MAXN>
+__device__ __forceinline__ void pp_heuristic_edge(const PPParams& p, const long long e, double* lds_wave);
+#define PP_COVER_LDS ((PP_FUSE_HEUR) ? (PPTsp<PP_TSP_MAX>::LDS > PP_WAVE * 4 ? PPTsp<PP_TSP_MAX>::LDS : PP_WAVE * 4) : PP_WAVE * 4)
 __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep(PPParams p) {
-    __shared__ double lds_all[PP_WPB][PP_WAVE * 4];
+    __shared__ double lds_all[PP_WPB][PP_COVER_LDS];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     PPQueue qs = pp_queue_init();
-    for (PP_EACH_EDGE(idx, 2, PP_Q_COVER, p.n_edges, PP_Q_CHUNK_COVER))
-        pp_cover_sweep_edge<false>(p, p.ws_base + idx, pp_edge_position(p, p.e_base + idx), lds_all[wave]);
+    for (PP_EACH_EDGE(idx, 2, PP_Q_COVER, p.n_edges, PP_Q_CHUNK_COVER)) {
+        const long long eg = pp_edge_position(p, p.e_base + idx);
+        pp_cover_sweep_edge<false>(p, p.ws_base + idx, eg, lds_all[wave]);
+#if PP_FUSE_HEUR
+        if (p.fuse_h) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // the record and the child ribbons this wave just wrote
+            pp_heuristic_edge<false, PP_TSP_MAX>(p, eg, lds_all[wave]);
+        }
+#endif
+    }
 }
 __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep_gaussian(PPParams p) {
     __shared__ double lds_all[PP_WPB][PP_WAVE * 4];

@@ -540,6 +540,7 @@ static void fill_params(ppgpu_ctx* c, PPParams& p) {
     p.inv_inc_d = 1.0 / p.inc_d;
     p.cpf = g.collision_penalty_factor; p.tpf = g.time_penalty_factor;
     p.heuristic = g.heuristic; p.tsp_k = g.tsp_k; p.h_rho = g.heuristic_turning_radius;
+    p.fuse_h = 0;
     p.grid = PPGrid{c->grid.p, c->rows, c->cols, c->wpr, c->res, c->res > 0 ? 1.0 / c->res : 0.0};
     p.obst = c->obst.p; p.n_obst = c->n_obst; p.obst_model = c->obst_model;
     p.verts = c->verts.p; p.ribbons = c->ribbons.p; p.tgrid = c->tgrid.p; p.ng = c->ng; p.nverts = c->nverts;
@@ -654,6 +655,9 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         if ((rc = c->work.reserve(PP_WORK_WORDS, false, c->stream))) return rc;
         p.work = c->work.p;
     }
+    const bool dubinsH = p.heuristic == PPGPU_H_TSP_DUBINS_ALL || p.heuristic == PPGPU_H_TSP_DUBINS_K;
+    const bool gaussianSweep = p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN;
+    p.fuse_h = (PP_FUSE_HEUR && !dubinsH && !gaussianSweep) ? 1 : 0;
     for (long long e0 = 0; e0 < total; e0 += slice) {
         p.e_base = e0; p.ws_base = 0; p.n_edges = (total - e0 < slice) ? (total - e0) : slice;
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
@@ -674,7 +678,7 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     p.n_edges = total;
     if (p.heuristic == PPGPU_H_TSP_DUBINS_ALL || p.heuristic == PPGPU_H_TSP_DUBINS_K)
         hipLaunchKernelGGL(pp_k_heuristic_dubins, dim3(resident_grid(c, 4, pp_k_heuristic_dubins, total)), dim3(PP_H_WPB * 64), 0, c->stream, p);
-    else
+    else if (!p.fuse_h)
         hipLaunchKernelGGL(pp_k_heuristic, dim3(resident_grid(c, 5, pp_k_heuristic, total)), dim3(PP_H_WPB * 64), 0, c->stream, p);
     // child lists of 9..12 ribbons under the K variant: a second pass that touches only those edges (the others cost it one
     // 8-byte read each)
