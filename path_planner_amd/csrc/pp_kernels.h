@@ -637,6 +637,11 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
 }
 
 // e = the edge's slot in the workspace, eg = its position in the caller's edge list, lds = 256 doubles private to the wave
+#ifndef PP_FUSE_HEUR
+#define PP_FUSE_HEUR 1
+#endif
+template <int MAXN>
+__device__ __forceinline__ double pp_h_point_from_pts(const PPParams& p, double* lds_wave, int nrib);   // further down, with the heuristics
 template <bool GAUSSIAN>
 __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const long long e, const long long eg, double* lds) {
     const int lane = pp_lane();
@@ -957,7 +962,8 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
     const double trueCost = tc * p.tpf + penalty;                                 // :199
     const double g = srcG + trueCost;                                             // Vertex::setCurrentCost
 
-    // h and f are filled in by pp_k_heuristic from the child ribbons written below
+    // h and f are filled in after the record is stored: by this wave from the ribbons it still holds (PP_FUSE_HEUR, below), or
+    // by pp_k_heuristic* from the child ribbons
     const double h = 0;
 
     if (infeasible) flags |= PPGPU_F_INFEASIBLE;
@@ -1014,6 +1020,47 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
             c[0] = rib.sx; c[1] = rib.sy; c[2] = rib.ex; c[3] = rib.ey;
         }
     }
+#if PP_FUSE_HEUR
+    // The edge's heuristic, by this wave, from the ribbons it still holds in registers (point heuristics; the record and the child
+    // ribbons are stored, so nothing of the sweep is live any more): what pp_heuristic_edge<false, PP_TSP_MAX> would do.
+    if (!GAUSSIAN && p.fuse_h && !throwsRef && nrib > 0 && nrib <= p.stride) {          // = pp_heuristic_edge<false, PP_TSP_MAX>
+        const bool tsp = p.heuristic != PPGPU_H_MAX_DISTANCE;
+        bool leaveToBigPass = false;
+        const unsigned flags0 = flags;
+        double hdist = 0;
+        if (tsp && nrib > PP_TSP_MAX) {
+            if (pp_tsp_big_ok(p.heuristic, p.tsp_k, nrib)) leaveToBigPass = true;    // pp_k_heuristic_big fills it in
+            else flags |= PPGPU_F_RIBBON_OVF;
+        } else if (!tsp && nrib > 31) {
+            // MaxDistance over a long list (RibbonManager.cpp:234-248), ribbon by ribbon in list order
+            double sumLength = 0, mn = PP_DBL_MAX, mx = 0;
+            for (int i = 0; i < nrib; i++) {
+                const double sx = pp_readlane(rib.sx, i), sy = pp_readlane(rib.sy, i), ex = pp_readlane(rib.ex, i), ey = pp_readlane(rib.ey, i);
+                sumLength += sqrt(pp_sq_len(sx, sy, ex, ey)) - 2 * p.ribw;
+                const double dStart = pp_dist(sx, sy, endX, endY);
+                const double dEnd = pp_dist(ex, ey, endX, endY);
+                mn = fmin(fmin(mn, dEnd), dStart);
+                mx = fmax(fmax(mx, dEnd), dStart);
+            }
+            hdist = fmax(sumLength + mn, mx);
+        } else {
+            pp_wave_lds_fence();                                   // the event machinery is done with this scratch
+            if (lane == 0) { lds[0] = endX; lds[1] = endY; }
+            if (lane < nrib) {
+                lds[2 * (1 + 2 * lane)] = rib.sx; lds[2 * (1 + 2 * lane) + 1] = rib.sy;
+                lds[2 * (2 + 2 * lane)] = rib.ex; lds[2 * (2 + 2 * lane) + 1] = rib.ey;
+            }
+            pp_wave_lds_fence();
+            hdist = pp_h_point_from_pts<PP_TSP_MAX>(p, lds, nrib);
+            pp_wave_lds_fence();
+        }
+        if (!leaveToBigPass) {
+            const double hh = hdist / p.max_speed * p.tpf;
+            if (lane == 0) { rec->h = hh; rec->f = g + hh; if (flags != flags0) rec->flags = flags | ((nrib > p.stride) ? PPGPU_F_RIBBON_OVF : 0u); }
+        }
+    }
+#endif
+
 }
 
 #ifndef PP_POSE_MIN_WAVES
@@ -1034,11 +1081,6 @@ __global__ __launch_bounds__(PP_WPB * 64, 4) void pp_k_pose_sweep_gaussian(PPPar
 // sweep; the Dubins heuristics and the 12-ribbon pass keep their own kernels): the child ribbons and the record it needs were
 // just written by the same wave, there is no second launch, and the two phases' stalls fall at different times in the four
 // waves of a SIMD.  Cover sweep + heuristic 2.26 -> 2.18 ms (tools/ablate.py fuse0).
-#ifndef PP_FUSE_HEUR
-#define PP_FUSE_HEUR 1
-#endif
-template <bool DUBINS, int MAXN>
-__device__ __forceinline__ void pp_heuristic_edge(const PPParams& p, const long long e, double* lds_wave);
 #define PP_COVER_LDS ((PP_FUSE_HEUR) ? (PPTsp<PP_TSP_MAX>::LDS > PP_WAVE * 4 ? PPTsp<PP_TSP_MAX>::LDS : PP_WAVE * 4) : PP_WAVE * 4)
 __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep(PPParams p) {
     __shared__ double lds_all[PP_WPB][PP_COVER_LDS];
@@ -1047,12 +1089,6 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep(PP
     for (PP_EACH_EDGE(idx, 2, PP_Q_COVER, p.n_edges, PP_Q_CHUNK_COVER)) {
         const long long eg = pp_edge_position(p, p.e_base + idx);
         pp_cover_sweep_edge<false>(p, p.ws_base + idx, eg, lds_all[wave]);
-#if PP_FUSE_HEUR
-        if (p.fuse_h) {
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // the record and the child ribbons this wave just wrote
-            pp_heuristic_edge<false, PP_TSP_MAX>(p, eg, lds_all[wave]);
-        }
-#endif
     }
 }
 __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep_gaussian(PPParams p) {
@@ -1074,6 +1110,32 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep_ga
 // distances between oriented ribbon endpoints.  A separate instantiation so that the six-word solve does not set the
 // register budget of the common kernel.  MAXN = 8: every edge; MAXN = 12: a second pass that only touches the edges whose
 // 9..12 child ribbons the first pass left for it (pp_tsp_big_ok).
+// MaxDistance / TspPointRobotNoSplit{All,K}Ribbons from the points staged in the wave's LDS (x,y of the query point, then
+// start / end of every ribbon): distance table, nearest-endpoint table, enumeration.  nrib <= MAXN for the TSP variants.
+template <int MAXN>
+__device__ __forceinline__ double pp_h_point_from_pts(const PPParams& p, double* lds_wave, int nrib) {
+    typedef PPTsp<MAXN> TS;
+    const int lane = pp_lane();
+    double* pts = lds_wave;
+    double* T = lds_wave + PP_WAVE * 2;
+    double* KM = T + TS::PTS * (TS::PTS - 1);
+    if (p.heuristic == PPGPU_H_MAX_DISTANCE) return pp_h_max_distance(pts, nrib, p.ribw);
+    const int npts = 2 * nrib + 1;
+    const int ncol = npts - 1;
+    for (int idx = lane; idx < npts * ncol; idx += PP_WAVE) {      // all distances, once
+        const int pp = (int)pp_udiv_small((unsigned)idx, (unsigned)ncol), qq = 1 + (idx - pp * ncol);
+        T[pp * (TS::PTS - 1) + (qq - 1)] = pp_dist(pts[2 * pp], pts[2 * pp + 1], pts[2 * qq], pts[2 * qq + 1]);
+    }
+    pp_wave_lds_fence();
+    for (int idx = lane; idx < npts * nrib; idx += PP_WAVE) {
+        const int pp = (int)pp_udiv_small((unsigned)idx, (unsigned)nrib), ri = idx - pp * nrib;
+        KM[pp * MAXN + ri] = fmin(pp_h_T<MAXN>(T, pp, 1 + 2 * ri), pp_h_T<MAXN>(T, pp, 2 + 2 * ri));
+    }
+    pp_wave_lds_fence();
+    if (p.heuristic == PPGPU_H_TSP_POINT_ALL) return pp_h_tsp_point<MAXN>(T, KM, nrib, p.ribw, MAXN, false);
+    return pp_h_tsp_point<MAXN>(T, KM, nrib, p.ribw, p.tsp_k, true);
+}
+
 template <bool DUBINS, int MAXN>
 __device__ __forceinline__ void pp_heuristic_edge(const PPParams& p, const long long e, double* lds_wave) {
     typedef PPTsp<MAXN> TS;
@@ -1116,21 +1178,8 @@ __device__ __forceinline__ void pp_heuristic_edge(const PPParams& p, const long 
             pp_wave_lds_fence();
             const int npts = 2 * nrib + 1;
             const int ncol = npts - 1;
-            if (!tsp) {
-                hdist = pp_h_max_distance(pts, nrib, p.ribw);
-            } else if (!DUBINS) {
-                for (int idx = lane; idx < npts * ncol; idx += PP_WAVE) {      // all distances, once
-                    const int pp = (int)pp_udiv_small((unsigned)idx, (unsigned)ncol), qq = 1 + (idx - pp * ncol);
-                    T[pp * (TS::PTS - 1) + (qq - 1)] = pp_dist(pts[2 * pp], pts[2 * pp + 1], pts[2 * qq], pts[2 * qq + 1]);
-                }
-                pp_wave_lds_fence();
-                for (int idx = lane; idx < npts * nrib; idx += PP_WAVE) {
-                    const int pp = (int)pp_udiv_small((unsigned)idx, (unsigned)nrib), ri = idx - pp * nrib;
-                    KM[pp * MAXN + ri] = fmin(pp_h_T<MAXN>(T, pp, 1 + 2 * ri), pp_h_T<MAXN>(T, pp, 2 + 2 * ri));
-                }
-                pp_wave_lds_fence();
-                if (p.heuristic == PPGPU_H_TSP_POINT_ALL) hdist = pp_h_tsp_point<MAXN>(T, KM, nrib, p.ribw, MAXN, false);
-                else hdist = pp_h_tsp_point<MAXN>(T, KM, nrib, p.ribw, p.tsp_k, true);
+            if (!tsp || !DUBINS) {
+                hdist = pp_h_point_from_pts<MAXN>(p, lds_wave, nrib);
             } else {
                 // Oriented endpoints (Ribbon::startAsState / endAsState, Ribbon.cpp:60-70: at one end, heading towards the
                 // other); the query pose passes the child's HEADING where the callee says yaw (Vertex.cpp:51) — kept.
