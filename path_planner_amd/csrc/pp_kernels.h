@@ -641,7 +641,8 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
 #define PP_FUSE_HEUR 1
 #endif
 template <int MAXN>
-__device__ __forceinline__ double pp_h_point_from_pts(const PPParams& p, double* lds_wave, int nrib);   // further down, with the heuristics
+__device__ __forceinline__ double pp_h_point_from_pts(int heuristic, int tsp_k, double ribw, double* lds_wave, int nrib);   // further down, with the heuristics
+
 template <bool GAUSSIAN>
 __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const long long e, const long long eg, double* lds) {
     const int lane = pp_lane();
@@ -1051,7 +1052,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                 lds[2 * (2 + 2 * lane)] = rib.ex; lds[2 * (2 + 2 * lane) + 1] = rib.ey;
             }
             pp_wave_lds_fence();
-            hdist = pp_h_point_from_pts<PP_TSP_MAX>(p, lds, nrib);
+            hdist = pp_h_point_from_pts<PP_TSP_MAX>(p.heuristic, p.tsp_k, p.ribw, lds, nrib);
             pp_wave_lds_fence();
         }
         if (!leaveToBigPass) {
@@ -1113,13 +1114,13 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep_ga
 // MaxDistance / TspPointRobotNoSplit{All,K}Ribbons from the points staged in the wave's LDS (x,y of the query point, then
 // start / end of every ribbon): distance table, nearest-endpoint table, enumeration.  nrib <= MAXN for the TSP variants.
 template <int MAXN>
-__device__ __forceinline__ double pp_h_point_from_pts(const PPParams& p, double* lds_wave, int nrib) {
+__device__ __forceinline__ double pp_h_point_from_pts(int heuristic, int tsp_k, double ribw, double* lds_wave, int nrib) {
     typedef PPTsp<MAXN> TS;
     const int lane = pp_lane();
     double* pts = lds_wave;
     double* T = lds_wave + PP_WAVE * 2;
     double* KM = T + TS::PTS * (TS::PTS - 1);
-    if (p.heuristic == PPGPU_H_MAX_DISTANCE) return pp_h_max_distance(pts, nrib, p.ribw);
+    if (heuristic == PPGPU_H_MAX_DISTANCE) return pp_h_max_distance(pts, nrib, ribw);
     const int npts = 2 * nrib + 1;
     const int ncol = npts - 1;
     for (int idx = lane; idx < npts * ncol; idx += PP_WAVE) {      // all distances, once
@@ -1132,9 +1133,10 @@ __device__ __forceinline__ double pp_h_point_from_pts(const PPParams& p, double*
         KM[pp * MAXN + ri] = fmin(pp_h_T<MAXN>(T, pp, 1 + 2 * ri), pp_h_T<MAXN>(T, pp, 2 + 2 * ri));
     }
     pp_wave_lds_fence();
-    if (p.heuristic == PPGPU_H_TSP_POINT_ALL) return pp_h_tsp_point<MAXN>(T, KM, nrib, p.ribw, MAXN, false);
-    return pp_h_tsp_point<MAXN>(T, KM, nrib, p.ribw, p.tsp_k, true);
+    if (heuristic == PPGPU_H_TSP_POINT_ALL) return pp_h_tsp_point<MAXN>(T, KM, nrib, ribw, MAXN, false);
+    return pp_h_tsp_point<MAXN>(T, KM, nrib, ribw, tsp_k, true);
 }
+
 
 template <bool DUBINS, int MAXN>
 __device__ __forceinline__ void pp_heuristic_edge(const PPParams& p, const long long e, double* lds_wave) {
@@ -1179,7 +1181,7 @@ __device__ __forceinline__ void pp_heuristic_edge(const PPParams& p, const long 
             const int npts = 2 * nrib + 1;
             const int ncol = npts - 1;
             if (!tsp || !DUBINS) {
-                hdist = pp_h_point_from_pts<MAXN>(p, lds_wave, nrib);
+                hdist = pp_h_point_from_pts<MAXN>(p.heuristic, p.tsp_k, p.ribw, lds_wave, nrib);
             } else {
                 // Oriented endpoints (Ribbon::startAsState / endAsState, Ribbon.cpp:60-70: at one end, heading towards the
                 // other); the query pose passes the child's HEADING where the callee says yaw (Vertex.cpp:51) — kept.
