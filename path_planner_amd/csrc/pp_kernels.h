@@ -1057,7 +1057,11 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
         }
         if (!leaveToBigPass) {
             const double hh = hdist / p.max_speed * p.tpf;
+#ifndef PP_ABL_NO_HPATCH
             if (lane == 0) { rec->h = hh; rec->f = g + hh; if (flags != flags0) rec->flags = flags | ((nrib > p.stride) ? PPGPU_F_RIBBON_OVF : 0u); }
+#else
+            if (hh < 0) rec->h = hh;
+#endif
         }
     }
 #endif
