@@ -39,6 +39,20 @@ struct HostProfile {
     }
 };
 HostProfile g_prof;
+// PPAMD_DUMP_EDGES=<file>: every costed edge the search consumes, in consumption order, 16 doubles per line in the layout of the
+// oracle's edge dump (source state, Dubins parameters and type, radius, coverage flag, infeasible, true cost, g, h, end time)
+struct EdgeDump {
+    FILE* f = nullptr;
+    EdgeDump() { if (const char* p = std::getenv("PPAMD_DUMP_EDGES")) f = std::fopen(p, "w"); }
+    ~EdgeDump() { if (f) std::fclose(f); }
+    void write(const State& src, const ppgpu_edge_result& r, double rho, bool cov) {
+        if (!f) return;
+        std::fprintf(f, "%.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %d %.17g %d %d %.17g %.17g %.17g %.17g\n", src.x(), src.y(), src.heading(),
+                     src.speed(), src.time(), r.param[0], r.param[1], r.param[2], (int)(r.info & 0xff), rho, cov ? 1 : 0,
+                     (r.flags & PPGPU_F_INFEASIBLE) ? 1 : 0, r.true_cost, r.g, r.h, r.end_time);
+    }
+};
+EdgeDump g_dump;
 struct Lap {
     int slot; double t0;
     explicit Lap(int s) : slot(s), t0(g_prof.on ? HostProfile::now() : 0) {}
@@ -323,6 +337,10 @@ int GpuAStarPlanner::costStateEdges(int source, const std::vector<State>& target
     std::vector<double> child;
     const int stride = costEdgeList(edges, (int)m_Nodes[source].ribbons.get().size(), res, child);
     for (size_t i = 0; i < n; i++) {
+        {
+            const bool cov = (cfgBits[i] & PPGPU_EDGE_COVERAGE) != 0;
+            g_dump.write(m_Nodes[source].state, res[i], cov ? m_Config.coverageTurningRadius() : m_Config.turningRadius(), cov);
+        }
         m_Nodes.push_back(makeChild(source, cfgBits[i], res[i], child.data() + i * (size_t)stride * 4));
         visualizeTrajectory(m_Nodes.back());
         pushVertexQueue((int)m_Nodes.size() - 1);
@@ -429,6 +447,10 @@ void GpuAStarPlanner::expand(int source) {
         std::memcpy(&r, costed.records.data() + e * sizeof(ppgpu_edge_result), sizeof(r));
         // an infeasible edge is never pushed (SamplingBasedPlanner.cpp:8): no vertex is made for it, unless the search is being
         // watched (its sweep is streamed all the same) or the record carries an error (makeChild throws what the reference throws)
+        {
+            const bool cov = (costed.cfgBits[e] & PPGPU_EDGE_COVERAGE) != 0;
+            g_dump.write(m_Nodes[source].state, r, cov ? m_Config.coverageTurningRadius() : m_Config.turningRadius(), cov);
+        }
         const bool plainInfeasible = (r.flags & PPGPU_F_INFEASIBLE) && !(r.flags & (PPGPU_F_THROWS | PPGPU_F_RIBBON_OVF | PPGPU_F_DUBINS_ERR));
         if (plainInfeasible && !watch) continue;
         m_Nodes.push_back(makeChild(source, costed.cfgBits[e], r, costed.childRibbons.data() + e * (size_t)costed.stride * 4));
