@@ -183,6 +183,16 @@ int ppo_ribbons_nearest_endpoint(const double* ribbons4, int n, const double* s5
     out5[0] = s.x; out5[1] = s.y; out5[2] = s.heading; out5[3] = s.speed; out5[4] = s.time;
     return 0;
 }
+// RibbonManager::findNearStatesOnRibbons (RibbonManager.cpp:296-379): the Brown-path seeds of AStarPlanner.cpp:40-43
+int ppo_ribbons_near_states(const double* ribbons4, int n, const double* start5, double radius, double* out5, int cap) {
+    World w;
+    RibbonManager rm = make_rm(w, ribbons4, n, -1);
+    std::vector<State> v = rm.findNearStatesOnRibbons(State(start5[0], start5[1], start5[2], start5[3], start5[4]), radius);
+    for (size_t i = 0; i < v.size() && (int)i < cap; i++) {
+        out5[5 * i] = v[i].x; out5[5 * i + 1] = v[i].y; out5[5 * i + 2] = v[i].heading; out5[5 * i + 3] = v[i].speed; out5[5 * i + 4] = v[i].time;
+    }
+    return (int)v.size();
+}
 void ppo_ribbons_project(const double* ribbons4, int n, double* s5) {
     World w;
     RibbonManager rm = make_rm(w, ribbons4, n, -1);

@@ -35,21 +35,30 @@ private:
     double m_Extremes[4] = {-DBL_MAX, DBL_MAX, -DBL_MAX, DBL_MAX};
 };
 
+// GridWorldMap: the text occupancy grid of the reference's tests and simulator (GridWorldMap.cpp:10-93).  File format: first
+// line the cell size in metres, then one text line per row, '#' = blocked, the LAST line being y = 0; the grid is as wide as
+// the shortest line; everything outside [0, cols * res) x [0, rows * res) is blocked.
+// Stored the way the device wants it: one bit per cell, 64 cells per word, row 0 = y in [0, res).
 class GridWorldMap : public Map {
 public:
-    explicit GridWorldMap(const std::string& path);                           // GridWorldMap.cpp:10-82
+    explicit GridWorldMap(const std::string& path);
     static std::shared_ptr<GridWorldMap> fromText(const std::string& text);
-    bool isBlocked(double x, double y) const override;                        // :84-93
-    const double* extremes() const override { return m_Extremes; }
-    double resolution() const override { return m_Resolution; }
+    bool isBlocked(double x, double y) const override;
+    const double* extremes() const override { return m_Box; }
+    double resolution() const override { return m_CellSize; }
     void rasterize(std::vector<uint8_t>& cells, int& rows, int& cols, double& res) const override;
+    int rows() const { return m_Rows; }
+    int cols() const { return m_Cols; }
 
 private:
     GridWorldMap() = default;
-    void load(std::istream& in);
-    std::vector<std::vector<bool>> m_Blocked;
-    double m_Resolution = 0;
-    double m_Extremes[4] = {0, 0, 0, 0};
+    void parse(std::istream& in);
+    bool cell(size_t row, size_t col) const { return (m_Bits[row * m_WordsPerRow + (col >> 6)] >> (col & 63)) & 1u; }
+    std::vector<uint64_t> m_Bits;
+    int m_Rows = 0, m_Cols = 0;
+    size_t m_WordsPerRow = 0;
+    double m_CellSize = 0;
+    double m_Box[4] = {0, 0, 0, 0};      // minX, maxX, minY, maxY
 };
 
 class DynamicObstaclesManager {
@@ -64,67 +73,82 @@ public:
     virtual void deviceRows(std::vector<double>& rows) const { rows.clear(); }
 };
 
+// Obstacle tracks keyed by MMSI, kept as a dense array in the order the contacts were first reported (the row order the device
+// receives; the reference keeps an unordered_map, whose iteration order is unspecified — for the binary model the result is a
+// count and cannot depend on it) with a side index from MMSI to slot.  forget() moves the last track into the freed slot.
+template <typename Track>
+class TrackTable {
+public:
+    Track* find(uint32_t mmsi) {
+        const auto it = m_Slot.find(mmsi);
+        return it == m_Slot.end() ? nullptr : &m_Tracks[it->second];
+    }
+    void put(uint32_t mmsi, const Track& t) {
+        if (Track* have = find(mmsi)) { *have = t; return; }
+        m_Slot[mmsi] = m_Tracks.size();
+        m_Tracks.push_back(t);
+        m_Mmsi.push_back(mmsi);
+    }
+    void drop(uint32_t mmsi) {
+        const auto it = m_Slot.find(mmsi);
+        if (it == m_Slot.end()) return;
+        const size_t slot = it->second, last = m_Tracks.size() - 1;
+        if (slot != last) { m_Tracks[slot] = m_Tracks[last]; m_Mmsi[slot] = m_Mmsi[last]; m_Slot[m_Mmsi[slot]] = slot; }
+        m_Tracks.pop_back(); m_Mmsi.pop_back();
+        m_Slot.erase(it);
+    }
+    const std::vector<Track>& tracks() const { return m_Tracks; }
+    void mute(uint32_t mmsi) { m_Muted.insert(mmsi); }
+    void unmute(uint32_t mmsi) { m_Muted.erase(mmsi); }
+    bool muted(uint32_t mmsi) const { return m_Muted.count(mmsi) != 0; }
+
+private:
+    std::vector<Track> m_Tracks;
+    std::vector<uint32_t> m_Mmsi;
+    std::unordered_map<uint32_t, size_t> m_Slot;
+    std::unordered_set<uint32_t> m_Muted;
+};
+
+// BinaryDynamicObstaclesManager (.h:14-47, .cpp:4-35): each contact is a box of Width x Length (each 2 m larger for the strict
+// test) moving at constant speed along its heading; collisionExists counts the boxes that hold the query point at the query
+// time.  cos/sin of the contact's yaw are taken once, when the contact is reported (the same libm calls the reference makes
+// per query).
 class BinaryDynamicObstaclesManager : public DynamicObstaclesManager {
 public:
     typedef std::shared_ptr<BinaryDynamicObstaclesManager> SharedPtr;
-    struct Obstacle {
-        double X, Y, Yaw, Speed, Time, Width, Length, Heading;
-        Obstacle(double x, double y, double heading, double speed, double time, double width, double length)
-            : X(x), Y(y), Yaw(M_PI_2 - heading), Speed(speed), Time(time), Width(width), Length(length), Heading(heading) {}
-        void project(double desiredTime) {
-            double dt = desiredTime - Time;
-            double dx = Speed * dt * std::cos(Yaw);
-            double dy = Speed * dt * std::sin(Yaw);
-            X += dx; Y += dy;
-        }
-    };
+    struct Track { double x, y, heading, speed, time, width, length, cosYaw, sinYaw; };
     void update(uint32_t mmsi, double x, double y, double heading, double speed, double time, double width, double length);
-    void forget(uint32_t mmsi) { m_Obstacles.erase(mmsi); }
-    void addIgnore(uint32_t mmsi) { m_Ignored.emplace(mmsi); }
-    void removeIgnore(uint32_t mmsi) { m_Ignored.erase(mmsi); }
-    double collisionExists(double x, double y, double time, bool strict) const override;   // .cpp:4-22
-    const std::unordered_map<uint32_t, Obstacle>& get() const { return m_Obstacles; }
+    void forget(uint32_t mmsi) { m_Table.drop(mmsi); }
+    void addIgnore(uint32_t mmsi) { m_Table.mute(mmsi); }
+    void removeIgnore(uint32_t mmsi) { m_Table.unmute(mmsi); }
+    double collisionExists(double x, double y, double time, bool strict) const override;
+    size_t size() const { return m_Table.tracks().size(); }
     int deviceModel() const override { return 1; }
     void deviceRows(std::vector<double>& rows7) const override;
 
 private:
-    std::unordered_map<uint32_t, Obstacle> m_Obstacles;
-    std::unordered_set<uint32_t> m_Ignored;
+    TrackTable<Track> m_Table;
 };
 
-// GaussianDynamicObstaclesManager.{h,cpp}, without Eigen: the 2x2 covariance is four doubles (row-major) and inverse /
-// determinant / quadratic form are written out in the order Eigen's fixed-size code evaluates them.
+// GaussianDynamicObstaclesManager (.h:19-49, .cpp:3-47), without Eigen: a contact is a bivariate normal that moves like a binary
+// contact's box; the inverse covariance and the normalisation are computed when the contact is reported, in the order Eigen's
+// fixed-size 2x2 code evaluates them; collisionExists is the sum of the densities in report order, 0 below 1e-5.
 class GaussianDynamicObstaclesManager : public DynamicObstaclesManager {
 public:
     typedef std::shared_ptr<GaussianDynamicObstaclesManager> SharedPtr;
-    struct Obstacle {
-        double X, Y, Yaw, Speed, Time, Heading;
-        double covariance[4];
-        Obstacle(double x, double y, double heading, double speed, double time)
-            : X(x), Y(y), Yaw(M_PI_2 - heading), Speed(speed), Time(time), Heading(heading), covariance{30, 10, 10, 30} {}
-        Obstacle(double x, double y, double heading, double speed, double time, const double cov[4])
-            : X(x), Y(y), Yaw(M_PI_2 - heading), Speed(speed), Time(time), Heading(heading), covariance{cov[0], cov[1], cov[2], cov[3]} {}
-        void project(double desiredTime) {
-            double dt = desiredTime - Time;
-            double dx = Speed * dt * std::cos(Yaw);
-            double dy = Speed * dt * std::sin(Yaw);
-            X += dx; Y += dy;
-        }
-        double pdf(double x, double y) const;
-    };
-    void update(uint32_t mmsi, double x, double y, double heading, double speed, double time);
+    struct Track { double x, y, heading, speed, time, cosYaw, sinYaw, cov[4], inv[4], norm; };
+    void update(uint32_t mmsi, double x, double y, double heading, double speed, double time);   // covariance [[30,10],[10,30]]
     void update(uint32_t mmsi, double x, double y, double heading, double speed, double time, const double covariance[4]);
-    void forget(uint32_t mmsi) { m_Obstacles.erase(mmsi); }
-    void addIgnore(uint32_t mmsi) { m_Ignored.emplace(mmsi); }
-    void removeIgnore(uint32_t mmsi) { m_Ignored.erase(mmsi); }
-    double collisionExists(double x, double y, double time, bool strict) const override;   // .cpp:3-13
-    const std::unordered_map<uint32_t, Obstacle>& get() const { return m_Obstacles; }
+    void forget(uint32_t mmsi) { m_Table.drop(mmsi); }
+    void addIgnore(uint32_t mmsi) { m_Table.mute(mmsi); }
+    void removeIgnore(uint32_t mmsi) { m_Table.unmute(mmsi); }
+    double collisionExists(double x, double y, double time, bool strict) const override;
+    size_t size() const { return m_Table.tracks().size(); }
     int deviceModel() const override { return 2; }
     void deviceRows(std::vector<double>& rows9) const override;
 
 private:
-    std::unordered_map<uint32_t, Obstacle> m_Obstacles;
-    std::unordered_set<uint32_t> m_Ignored;
+    TrackTable<Track> m_Table;
 };
 
 // Visualizer.h: owns the file the search is dumped to (the text format visualizer.py:485-547 reads)

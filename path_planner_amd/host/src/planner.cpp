@@ -95,8 +95,7 @@ void GpuAStarPlanner::check(int rc, const char* what) const {
 }
 
 static void ribbonsToArray(const RibbonManager& rm, std::vector<double>& out) {
-    out.clear();
-    for (const auto& r : rm.get()) out.insert(out.end(), {r.start().first, r.start().second, r.end().first, r.end().second});
+    out.assign(rm.rows(), rm.rows() + 4 * (size_t)rm.count());   // the manager keeps its list in the device's row layout
 }
 
 static ppgpu_vertex makeVertex(const GpuAStarPlanner::Node& n) {
@@ -105,7 +104,7 @@ static ppgpu_vertex makeVertex(const GpuAStarPlanner::Node& n) {
     v.g = n.g;
     v.coverage_completed_time = n.ribbons.coverageCompletedTime();
     v.ribbon_offset = 0;
-    v.ribbon_count = (int32_t)n.ribbons.get().size();
+    v.ribbon_count = (int32_t)n.ribbons.count();
     return v;
 }
 
@@ -267,7 +266,7 @@ GpuAStarPlanner::Node GpuAStarPlanner::makeChild(int source, unsigned cfgBits, c
     if (r.flags & PPGPU_F_THROWS) throw std::runtime_error("Edge cost evaluation failed: invalid time in sample for Dubins path");
     if (r.flags & (PPGPU_F_RIBBON_OVF | PPGPU_F_DUBINS_ERR))
         throw std::runtime_error("Edge cost evaluation exceeded a device capacity (flags " + std::to_string(r.flags) + ", child ribbons " +
-                                 std::to_string((r.info >> 8) & 0xff) + ", parent ribbons " + std::to_string(m_Nodes[source].ribbons.get().size()) + ")");
+                                 std::to_string((r.info >> 8) & 0xff) + ", parent ribbons " + std::to_string(m_Nodes[source].ribbons.count()) + ")");
     const Node& src = m_Nodes[source];
     Node c;
     c.parent = source;
@@ -335,7 +334,7 @@ int GpuAStarPlanner::costStateEdges(int source, const std::vector<State>& target
     }
     std::vector<ppgpu_edge_result> res;
     std::vector<double> child;
-    const int stride = costEdgeList(edges, (int)m_Nodes[source].ribbons.get().size(), res, child);
+    const int stride = costEdgeList(edges, (int)m_Nodes[source].ribbons.count(), res, child);
     for (size_t i = 0; i < n; i++) {
         {
             const bool cov = (cfgBits[i] & PPGPU_EDGE_COVERAGE) != 0;

@@ -1,66 +1,58 @@
-// State — see include/path_planner_amd/State.h (mirror of path_planner_common/src/state/State.cpp)
+// State — out-of-line members (interface and provenance: include/path_planner_amd/State.h).
+// Every function evaluates the reference's formula in the reference's operation order, because the results are compared
+// bit for bit with the reference object's (tests/golden/state_ops.json); how the code is laid out is this build's.
 #include "path_planner_amd/State.h"
+
+#include <cstdio>
 
 namespace ppamd {
 
+namespace {
+std::string fiveNumbers(double a, double b, double c, double d, double e) {
+    char buf[5 * 330];                               // std::to_string(double) prints "%f": at most 318 characters each
+    std::snprintf(buf, sizeof(buf), "%f %f %f %f %f", a, b, c, d, e);
+    return buf;
+}
+}  // namespace
+
 State State::push(double timeInterval) const {
-    State s;
-    double displacement = timeInterval * speed();
-    s.x() = x() + std::sin(heading()) * displacement;
-    s.y() = y() + std::cos(heading()) * displacement;
-    s.heading() = heading();
-    s.speed() = speed();
-    s.time() = time() + timeInterval;
-    return s;
+    // the vehicle keeps heading and speed; heading is measured from north, so x grows with its sine
+    const double run = timeInterval * speed();
+    return State(x() + std::sin(heading()) * run, y() + std::cos(heading()) * run, heading(), speed(), time() + timeInterval);
 }
 
 void State::move(double distance) {
-    x() += std::cos(yaw()) * distance;
-    y() += std::sin(yaw()) * distance;
+    const double a = yaw();
+    m_V[X] += std::cos(a) * distance;
+    m_V[Y] += std::sin(a) * distance;
 }
 
-std::string State::toString() const {
-    return std::to_string(x()) + " " + std::to_string(y()) + " " + std::to_string(heading() * 180 / M_PI) + " " +
-           std::to_string(speed()) + " " + std::to_string(time());
-}
+std::string State::toString() const { return fiveNumbers(x(), y(), heading() * 180 / M_PI, speed(), time()); }
 
-std::string State::toStringRad() const {
-    return std::to_string(x()) + " " + std::to_string(y()) + " " + std::to_string(heading()) + " " + std::to_string(speed()) +
-           " " + std::to_string(time());
-}
+std::string State::toStringRad() const { return fiveNumbers(x(), y(), heading(), speed(), time()); }
 
-double State::headingTo(double x1, double y1) const {
-    double dx = x1 - x();
-    double dy = y1 - y();
-    double h = M_PI_2 - std::atan2(dy, dx);
-    if (h < 0) h += 2 * M_PI;
-    return h;
-}
+double State::headingTo(double x1, double y1) const { return flipAngle(std::atan2(y1 - y(), x1 - x())); }
 
-void State::setHeadingTowards(double x1, double y1) {
-    heading() = headingTo(x1, y1);
-    if (heading() < 0) heading() += 2 * M_PI;
+double State::headingDifference(double otherHeading) const {
+    const double turn = 2 * M_PI;
+    const double raw = std::fmod(otherHeading - heading(), turn);
+    return std::fmod(raw + 3 * M_PI, turn) - M_PI;
 }
 
 State State::interpolate(const State& other, double desiredTime) const {
-    double dt = other.time() - time();
-    double dx = (other.x() - x()) / dt;
-    double dy = (other.y() - y()) / dt;
-    double dh = headingDifference(other) / dt;
-    double ds = (other.speed() - speed()) / dt;
-    dt = desiredTime - time();
-    State s = *this;
-    s.x() += dx * dt;
-    s.y() += dy * dt;
-    s.heading() = heading() + (dh * dt);
+    // linear in every component, the heading along the shorter way round; rates first, then rate * elapsed
+    const double span = other.time() - time();
+    const double elapsed = desiredTime - time();
+    const double rate[4] = {(other.x() - x()) / span, (other.y() - y()) / span, headingDifference(other) / span,
+                            (other.speed() - speed()) / span};
+    State s(*this);
+    s.x() += rate[X] * elapsed;
+    s.y() += rate[Y] * elapsed;
+    s.heading() = heading() + (rate[Heading] * elapsed);
     if (s.heading() >= 2 * M_PI) s.heading() -= 2 * M_PI;
-    s.speed() += ds * dt;
+    s.speed() += rate[Speed] * elapsed;
     s.time() = desiredTime;
     return s;
-}
-
-double State::headingDifference(double otherHeading) const {
-    return (std::fmod(std::fmod((otherHeading - heading()), 2 * M_PI) + 3 * M_PI, 2 * M_PI) - M_PI);
 }
 
 }  // namespace ppamd

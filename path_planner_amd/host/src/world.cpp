@@ -1,151 +1,159 @@
-// Map / GridWorldMap / BinaryDynamicObstaclesManager — host mirrors, plus the snapshots the device consumes
+// The world the planner reads — occupancy map and moving contacts — on the host, and the snapshots of it the device receives
+// (interface and provenance: include/path_planner_amd/World.h).  Query results equal the reference's objects' (the fixtures
+// tests/golden/{grid_map,base_map,binary_obstacles}.json were produced by them); storage and code are this build's: a bit grid
+// and dense track tables.
 #include "path_planner_amd/World.h"
 
-#include <algorithm>
-#include <fstream>
+#include <cmath>
 #include <sstream>
 #include <stdexcept>
-#include <tuple>
 
 namespace ppamd {
 
+// ------------------------------------------------------------------------------------------------ maps
 void Map::rasterize(std::vector<uint8_t>& cells, int& rows, int& cols, double& res) const {
-    const double* e = extremes();
+    // Any map that answers isBlocked/extremes/resolution can feed the device: sample it at the cell centres of a grid anchored
+    // at the origin.  A map without a cell size or without finite bounds (the base Map) uploads as "no grid".
+    const double* box = extremes();
     res = resolution();
-    if (!(res > 0) || e[1] >= DBL_MAX || e[3] >= DBL_MAX || e[0] != 0 || e[2] != 0) {
-        cells.clear(); rows = cols = 0; res = 0;   // unbounded / resolution-less map: nothing is ever blocked on the device either
-        return;
-    }
-    cols = (int)std::ceil(e[1] / res);
-    rows = (int)std::ceil(e[3] / res);
-    cells.assign((size_t)rows * cols, 0);
+    const bool gridLike = res > 0 && box[0] == 0 && box[2] == 0 && box[1] < DBL_MAX && box[3] < DBL_MAX;
+    if (!gridLike) { cells.clear(); rows = cols = 0; res = 0; return; }
+    cols = (int)std::ceil(box[1] / res);
+    rows = (int)std::ceil(box[3] / res);
+    cells.resize((size_t)rows * cols);
+    size_t at = 0;
     for (int r = 0; r < rows; r++)
-        for (int c = 0; c < cols; c++)
-            cells[(size_t)r * cols + c] = isBlocked((c + 0.5) * res, (r + 0.5) * res) ? 1 : 0;
+        for (int c = 0; c < cols; c++) cells[at++] = isBlocked((c + 0.5) * res, (r + 0.5) * res) ? 1 : 0;
 }
 
 GridWorldMap::GridWorldMap(const std::string& path) {
-    std::ifstream infile(path);
-    if (!infile) throw std::runtime_error("GridWorldMap: cannot open " + path);
-    load(infile);
+    std::ifstream file(path);
+    if (!file) throw std::runtime_error("GridWorldMap: cannot open " + path);
+    parse(file);
 }
 
 std::shared_ptr<GridWorldMap> GridWorldMap::fromText(const std::string& text) {
     std::shared_ptr<GridWorldMap> m(new GridWorldMap());
     std::istringstream in(text);
-    m->load(in);
+    m->parse(in);
     return m;
 }
 
-void GridWorldMap::load(std::istream& infile) {   // GridWorldMap.cpp:10-82
-    std::string line;
-    std::vector<std::string> lines;
-    std::getline(infile, line);
-    std::istringstream s(line);
-    s >> m_Resolution;
-    int cols = -1, rows = 0;
-    while (std::getline(infile, line)) {
-        if (cols == -1) cols = (int)line.length();
-        else if ((int)line.length() < cols) cols = (int)line.length();
-        rows++;
-        lines.push_back(line);
+void GridWorldMap::parse(std::istream& in) {
+    std::string header;
+    std::getline(in, header);
+    std::istringstream(header) >> m_CellSize;
+    // text rows top to bottom; the grid is as wide as the narrowest of them
+    std::vector<std::string> text;
+    size_t width = std::string::npos;
+    for (std::string row; std::getline(in, row);) {
+        width = std::min(width, row.size());
+        text.push_back(std::move(row));
     }
-    if (rows == 0 || cols <= 0) throw std::runtime_error("GridWorldMap: empty map");
-    std::reverse(lines.begin(), lines.end());
-    m_Blocked = std::vector<std::vector<bool>>(rows, std::vector<bool>(cols, false));
-    m_Extremes[0] = 0; m_Extremes[1] = m_Blocked.front().size() * m_Resolution;
-    m_Extremes[2] = 0; m_Extremes[3] = m_Blocked.size() * m_Resolution;
-    for (int y = 0; y < rows; y++)
-        for (int x = 0; x < cols; x++)
-            if (lines[y][x] == '#') m_Blocked[y][x] = true;
+    if (text.empty() || width == 0 || width == std::string::npos) throw std::runtime_error("GridWorldMap: the file holds no cells");
+    m_Rows = (int)text.size();
+    m_Cols = (int)width;
+    m_WordsPerRow = (width + 63) / 64;
+    m_Bits.assign((size_t)m_Rows * m_WordsPerRow, 0);
+    for (size_t r = 0; r < text.size(); r++) {
+        const std::string& line = text[text.size() - 1 - r];        // the last text line is row 0 (y = 0)
+        uint64_t* words = &m_Bits[r * m_WordsPerRow];
+        for (size_t c = 0; c < width; c++)
+            if (line[c] == '#') words[c >> 6] |= uint64_t(1) << (c & 63);
+    }
+    m_Box[0] = 0; m_Box[1] = (size_t)m_Cols * m_CellSize;
+    m_Box[2] = 0; m_Box[3] = (size_t)m_Rows * m_CellSize;
 }
 
 bool GridWorldMap::isBlocked(double x, double y) const {
-    if (x < 0 || x / m_Resolution >= m_Blocked.front().size()) return true;
-    if (y < 0 || y / m_Resolution >= m_Blocked.size()) return true;
-    return m_Blocked.at(y / m_Resolution).at(x / m_Resolution);
+    // cell = (size_t)(coordinate / cell size); a negative coordinate or a quotient at or beyond the grid's extent is outside,
+    // and outside is blocked (GridWorldMap.cpp:84-93)
+    const double qx = x / m_CellSize, qy = y / m_CellSize;
+    const bool outside = x < 0 || y < 0 || !(qx < (size_t)m_Cols) || !(qy < (size_t)m_Rows);   // NaN is outside too
+    return outside || cell((size_t)qy, (size_t)qx);
 }
 
 void GridWorldMap::rasterize(std::vector<uint8_t>& cells, int& rows, int& cols, double& res) const {
-    rows = (int)m_Blocked.size();
-    cols = (int)m_Blocked.front().size();
-    res = m_Resolution;
-    cells.assign((size_t)rows * cols, 0);
+    rows = m_Rows; cols = m_Cols; res = m_CellSize;
+    cells.resize((size_t)rows * cols);
+    size_t at = 0;
     for (int r = 0; r < rows; r++)
-        for (int c = 0; c < cols; c++)
-            if (m_Blocked[r][c]) cells[(size_t)r * cols + c] = 1;
+        for (int c = 0; c < cols; c++) cells[at++] = cell((size_t)r, (size_t)c) ? 1 : 0;
 }
 
-void BinaryDynamicObstaclesManager::update(uint32_t mmsi, double x, double y, double heading, double speed, double time,
-                                           double width, double length) {
-    if (m_Ignored.find(mmsi) != m_Ignored.end()) return;
-    auto result = m_Obstacles.emplace(std::piecewise_construct, std::forward_as_tuple(mmsi),
-                                      std::forward_as_tuple(x, y, heading, speed, time, width, length));
-    if (!result.second) result.first->second = Obstacle(x, y, heading, speed, time, width, length);
+// ------------------------------------------------------------------------------------------------ contacts as boxes
+void BinaryDynamicObstaclesManager::update(uint32_t mmsi, double x, double y, double heading, double speed, double time, double width,
+                                           double length) {
+    if (m_Table.muted(mmsi)) return;
+    const double yaw = M_PI_2 - heading;                       // Obstacle(...): Yaw(M_PI_2 - heading) (.h:17-19), not wrapped
+    m_Table.put(mmsi, Track{x, y, heading, speed, time, width, length, std::cos(yaw), std::sin(yaw)});
 }
 
 double BinaryDynamicObstaclesManager::collisionExists(double x, double y, double time, bool strict) const {
-    double sum = 0;
-    for (auto o : m_Obstacles) {
-        auto& obstacle = o.second;
-        if (strict) { obstacle.Width += 2; obstacle.Length += 2; }
-        obstacle.project(time);
-        double translatedX = x - obstacle.X;
-        double translatedY = y - obstacle.Y;
-        double rotatedX = translatedX * std::cos(obstacle.Yaw) - translatedY * std::sin(obstacle.Yaw);
-        double rotatedY = translatedX * std::sin(obstacle.Yaw) + translatedY * std::cos(obstacle.Yaw);
-        if (std::fabs(rotatedX) < obstacle.Length / 2 && std::fabs(rotatedY) < obstacle.Width / 2) sum++;
+    const double grow = strict ? 2 : 0;
+    double inside = 0;
+    for (const Track& t : m_Table.tracks()) {
+        // where the contact is at the query time, then the query point in the contact's frame (rotation by +yaw, as the
+        // reference has it), then the box test with strict inequalities
+        const double elapsed = time - t.time;
+        const double cx = t.x + t.speed * elapsed * t.cosYaw, cy = t.y + t.speed * elapsed * t.sinYaw;
+        const double rx = x - cx, ry = y - cy;
+        const double along = rx * t.cosYaw - ry * t.sinYaw, athwart = rx * t.sinYaw + ry * t.cosYaw;
+        if (std::fabs(along) < (t.length + grow) / 2 && std::fabs(athwart) < (t.width + grow) / 2) inside += 1;
     }
-    return sum;
+    return inside;
 }
 
 void BinaryDynamicObstaclesManager::deviceRows(std::vector<double>& rows7) const {
     rows7.clear();
-    for (const auto& kv : m_Obstacles) {
-        const Obstacle& o = kv.second;
-        rows7.insert(rows7.end(), {o.X, o.Y, o.Heading, o.Speed, o.Time, o.Width, o.Length});
-    }
+    for (const Track& t : m_Table.tracks()) rows7.insert(rows7.end(), {t.x, t.y, t.heading, t.speed, t.time, t.width, t.length});
 }
 
-// ---------------------------------------------------------------- GaussianDynamicObstaclesManager
-double GaussianDynamicObstaclesManager::Obstacle::pdf(double x, double y) const {   // .h:38-43
+// ------------------------------------------------------------------------------------------------ contacts as densities
+namespace {
+GaussianDynamicObstaclesManager::Track gaussianTrack(double x, double y, double heading, double speed, double time, const double cov[4]) {
+    GaussianDynamicObstaclesManager::Track t{};
+    t.x = x; t.y = y; t.heading = heading; t.speed = speed; t.time = time;
+    const double yaw = M_PI_2 - heading;
+    t.cosYaw = std::cos(yaw); t.sinYaw = std::sin(yaw);
+    for (int i = 0; i < 4; i++) t.cov[i] = cov[i];
+    // inverse and determinant of a 2x2 the way Eigen's fixed-size code forms them: det = a d - c b, inverse = adjugate * (1 / det)
+    const double det = cov[0] * cov[3] - cov[2] * cov[1];
+    const double invDet = 1.0 / det;
+    t.inv[0] = cov[3] * invDet; t.inv[1] = -cov[1] * invDet; t.inv[2] = -cov[2] * invDet; t.inv[3] = cov[0] * invDet;
     const double twoPi = 2 * M_PI;
-    const double det = covariance[0] * covariance[3] - covariance[2] * covariance[1];
-    const double invdet = 1.0 / det;
-    const double i00 = covariance[3] * invdet, i10 = -covariance[2] * invdet, i01 = -covariance[1] * invdet, i11 = covariance[0] * invdet;
-    const double vx = x - X, vy = y - Y;
-    const double r0 = vx * i00 + vy * i10, r1 = vx * i01 + vy * i11;
-    const double quadform = r0 * vx + r1 * vy;
-    const double norm = 1.0 / twoPi / std::sqrt(det);
-    return norm * std::exp(-0.5 * quadform);
+    t.norm = 1.0 / twoPi / std::sqrt(det);
+    return t;
 }
-double GaussianDynamicObstaclesManager::collisionExists(double x, double y, double time, bool) const {   // .cpp:3-13
-    double sum = 0;
-    for (auto o : m_Obstacles) {
-        auto& obstacle = o.second;
-        obstacle.project(time);
-        sum += obstacle.pdf(x, y);
-    }
-    if (sum < 1e-5) return 0;
-    return sum;
+}  // namespace
+
+void GaussianDynamicObstaclesManager::update(uint32_t mmsi, double x, double y, double heading, double speed, double time) {
+    static const double defaultCovariance[4] = {30, 10, 10, 30};   // GaussianDynamicObstaclesManager.h:23-26
+    update(mmsi, x, y, heading, speed, time, defaultCovariance);
 }
-void GaussianDynamicObstaclesManager::update(uint32_t mmsi, double x, double y, double heading, double speed, double time) {   // .cpp:15-26
-    if (m_Ignored.count(mmsi)) return;
-    auto result = m_Obstacles.emplace(mmsi, Obstacle(x, y, heading, speed, time));
-    if (!result.second) result.first->second = Obstacle(x, y, heading, speed, time);
-}
+
 void GaussianDynamicObstaclesManager::update(uint32_t mmsi, double x, double y, double heading, double speed, double time,
-                                             const double covariance[4]) {   // .cpp:36-47
-    if (m_Ignored.count(mmsi)) return;
-    auto result = m_Obstacles.emplace(mmsi, Obstacle(x, y, heading, speed, time, covariance));
-    if (!result.second) result.first->second = Obstacle(x, y, heading, speed, time, covariance);
+                                             const double covariance[4]) {
+    if (m_Table.muted(mmsi)) return;
+    m_Table.put(mmsi, gaussianTrack(x, y, heading, speed, time, covariance));
 }
+
+double GaussianDynamicObstaclesManager::collisionExists(double x, double y, double time, bool) const {
+    double density = 0;
+    for (const Track& t : m_Table.tracks()) {
+        const double elapsed = time - t.time;
+        const double vx = x - (t.x + t.speed * elapsed * t.cosYaw), vy = y - (t.y + t.speed * elapsed * t.sinYaw);
+        // (v^T Sigma^-1) v, row vector times matrix first
+        const double r0 = vx * t.inv[0] + vy * t.inv[2], r1 = vx * t.inv[1] + vy * t.inv[3];
+        density += t.norm * std::exp(-0.5 * (r0 * vx + r1 * vy));
+    }
+    return density < 1e-5 ? 0 : density;
+}
+
 void GaussianDynamicObstaclesManager::deviceRows(std::vector<double>& rows9) const {
     rows9.clear();
-    for (const auto& kv : m_Obstacles) {
-        const Obstacle& o = kv.second;
-        rows9.insert(rows9.end(), {o.X, o.Y, o.Heading, o.Speed, o.Time, o.covariance[0], o.covariance[1], o.covariance[2], o.covariance[3]});
-    }
+    for (const Track& t : m_Table.tracks())
+        rows9.insert(rows9.end(), {t.x, t.y, t.heading, t.speed, t.time, t.cov[0], t.cov[1], t.cov[2], t.cov[3]});
 }
 
 }  // namespace ppamd

@@ -64,6 +64,7 @@ for _n, _r, _a in [
     ("ppo_ribbons_heuristic", dbl, [vp, i32, i32, i32, dbl, dbl, dbl, dbl]),
     ("ppo_ribbons_nearest_endpoint", i32, [vp, i32, vp, vp]),
     ("ppo_ribbons_project", None, [vp, i32, vp]),
+    ("ppo_ribbons_near_states", i32, [vp, i32, vp, dbl, vp, i32]),
     ("ppo_ribbon_projection", None, [vp, dbl, dbl, vp]),
     ("ppo_ribbon_contains", i32, [vp, dbl, dbl, i32]),
     ("ppo_ribbon_contains_projection", i32, [vp, dbl, dbl]),
