@@ -250,6 +250,15 @@ int ppgpu_dubins_lengths(ppgpu_ctx* ctx, int32_t v0, int32_t nv, double* d_lengt
 int ppgpu_select_nearest(ppgpu_ctx* ctx, int32_t v0, int32_t nv, int32_t k,
                          int32_t* h_sample_index, double* h_length);
 
+/* The same k samples per (vertex, radius), in the ORDER SamplingBasedPlanner::expand pushes their children: the front-to-back
+ * order of the reference's `bestSamples` heap array when its nearest-first scan of the samples ends (std::push_heap / std::pop_heap
+ * on approximate cost, SamplingBasedPlanner.cpp:82-133,134-149).  Which child std::pop_heap surfaces first among children of
+ * exactly equal f depends on it.  Vertices [0, nv) (v0 must be 0); h_sample_index receives nv*2*k entries (-1 = fewer than k).
+ * A list the device cannot replay (k >= 64, more candidates than its scratch holds, two candidates of exactly equal cost inside
+ * the heap) keeps ascending length and is counted in *h_fallbacks (may be NULL) and in ppgpu_order_fallbacks(). */
+int ppgpu_expand_order(ppgpu_ctx* ctx, int32_t v0, int32_t nv, int32_t k, int32_t* h_sample_index, uint32_t* h_fallbacks);
+uint64_t ppgpu_order_fallbacks(ppgpu_ctx* ctx);
+
 /* --------------------------------------------------------------- edge costing */
 
 /* Dense form: every vertex in [v0,v0+nv) x every sample in [s0,s0+ns) x the
@@ -272,7 +281,7 @@ int ppgpu_cost_edges_list(ppgpu_ctx* ctx, int64_t n, const uint64_t* d_edges,
  * vertex's edges in the order expand() pushes them —
  *     the vertex's nearest-point-to-cover target (h_nearest, 3 doubles {x, y, heading} per vertex, x = NaN: none; :64-81)
  *       at each speed {max, slow if distinct} and each radius {turning, coverage if distinct},
- *     then, per radius, its k winners in ascending Dubins length, each at each speed (:134-149)
+ *     then, per radius, its k winners in the order of the reference's heap array (ppgpu_expand_order), each at each speed (:134-149)
  * — cost them (Vertex::connect + Edge::computeTrueCost + computeApproxToGo) and return descriptors, records and child ribbons
  * compacted vertex by vertex.  Output arrays hold ppgpu_expand_capacity(nv, k) entries; *n_edges receives the count.
  * Synchronous; replaces the open-vertex array and the explicit targets of the handle. */

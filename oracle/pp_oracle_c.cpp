@@ -564,6 +564,56 @@ void ppo_edge_event_kinds(void* w, const ppgpu_vertex* verts, const double* pool
     }
 }
 
+// The sample scan of SamplingBasedPlanner::expand (SamplingBasedPlanner.cpp:82-133) on its own, with sample indices kept: heapify
+// the samples by Euclidean distance from the source, visit nearest first, per radius keep a max-heap of the k best by approximate
+// cost, stop a radius once its heap is full and the worst kept LENGTH is not above the next distance.  out_idx[r * k + j] = sample
+// index at position j of radius r's heap ARRAY when the scan ends (-1 beyond its size): the order in which expand() then costs
+// and pushes the children (:134-149).  `samples` keeps the order it is given in (the reference's vector is permuted by the scan;
+// with distinct distances the visit order does not depend on the starting permutation).
+void ppo_expand_order(void* w, const double* src5, long n, const double* sx, const double* sy, const double* sh, int k, int* out_idx) {
+    World* W = (World*)w;
+    Config cfg = make_config(*W);
+    struct Item { State s; int idx; };
+    std::vector<Item> items((size_t)n);
+    for (long i = 0; i < n; i++) { items[(size_t)i].s = State(sx[i], sy[i], sh[i], cfg.maxSpeed, 0); items[(size_t)i].idx = (int)i; }
+    const State origin(src5[0], src5[1], src5[2], src5[3], src5[4]);
+    auto comp = [&](const Item& a, const Item& b) { return a.s.distanceTo(origin) > b.s.distanceTo(origin); };
+    const double radii[2] = {cfg.turningRadius, cfg.coverageTurningRadius == cfg.turningRadius ? -1 : cfg.coverageTurningRadius};
+    struct Cand { double cost, length; int idx; };
+    std::vector<Cand> temps;
+    auto dubinsComp = [&](int a, int b) { return temps[(size_t)a].cost < temps[(size_t)b].cost; };
+    std::vector<int> heaps[2];
+    bool done[2] = {false, false};
+    std::make_heap(items.begin(), items.end(), comp);
+    for (size_t i = 0; i < items.size() && (!done[0] || !done[1]); i++) {
+        Item sample = items.front();
+        std::pop_heap(items.begin(), items.end() - (long)i, comp);
+        for (int j = 0; j < 2; j++) {
+            if (done[j]) continue;
+            if (radii[j] <= 0) { done[j] = true; continue; }
+            auto& best = heaps[j];
+            if (best.size() < (size_t)k || temps[(size_t)best.front()].length > sample.s.distanceTo(origin)) {
+                if (origin.distanceTo(sample.s) > cfg.collisionCheckingIncrement) {
+                    sample.s.speed = cfg.maxSpeed;
+                    DubinsWrapper wr;
+                    wr.set(origin, sample.s, radii[j]);
+                    temps.push_back(Cand{wr.length() / sample.s.speed * 1.0, wr.length(), sample.idx});
+                    best.push_back((int)temps.size() - 1);
+                    std::push_heap(best.begin(), best.end(), dubinsComp);
+                    if (best.size() > (size_t)k) {
+                        std::pop_heap(best.begin(), best.end(), dubinsComp);
+                        best.pop_back();
+                    }
+                }
+            } else {
+                done[j] = true;
+            }
+        }
+    }
+    for (int j = 0; j < 2; j++)
+        for (int q = 0; q < k; q++) out_idx[j * k + q] = q < (int)heaps[j].size() ? temps[(size_t)heaps[j][(size_t)q]].idx : -1;
+}
+
 // SamplingBasedPlanner::expand on a root vertex, the way the reference's ExpandTest1Ribbons drives it
 // (test_planner.cpp:1061-1082): a ribbon-less StateGenerator whose first `gen_skip` states are consumed
 // elsewhere, addSamples(generator, n_samples), expand(root), then pop the whole queue.

@@ -49,6 +49,8 @@ def _load():
         "ppgpu_num_samples": (i64, [vp]),
         "ppgpu_dubins_lengths": (C.c_int, [vp, i32, i32, vp]),
         "ppgpu_select_nearest": (C.c_int, [vp, i32, i32, i32, vp, vp]),
+        "ppgpu_expand_order": (C.c_int, [vp, i32, i32, i32, vp, C.POINTER(u32)]),
+        "ppgpu_order_fallbacks": (u64, [vp]),
         "ppgpu_cost_edges_dense": (C.c_int, [vp, i32, i32, i64, i64, u32, vp, vp, i32]),
         "ppgpu_cost_edges_list": (C.c_int, [vp, i64, vp, vp, vp, i32]),
         "ppgpu_cost_edges_host": (C.c_int, [vp, i64, vp, vp, vp, i32]),
@@ -199,6 +201,16 @@ class Context:
         ln = np.zeros((nv, 2, k), dtype=np.float64)
         self._ck(LIB.ppgpu_select_nearest(self._h, v0, nv, k, _ptr(idx), _ptr(ln)), "ppgpu_select_nearest")
         return idx, ln
+
+    def expand_order(self, nv, k):
+        """The k winners per (vertex, radius) in the order expand() pushes them (the reference's heap array); (idx, fallbacks)."""
+        idx = np.zeros((nv, 2, k), dtype=np.int32)
+        fb = u32(0)
+        self._ck(LIB.ppgpu_expand_order(self._h, 0, nv, k, _ptr(idx), C.byref(fb)), "ppgpu_expand_order")
+        return idx, int(fb.value)
+
+    def order_fallbacks(self):
+        return int(LIB.ppgpu_order_fallbacks(self._h))
 
     def cost_edges_dense(self, v0, nv, s0, ns, cfg_mask, d_results, d_child=None, stride=0):
         self._ck(LIB.ppgpu_cost_edges_dense(self._h, v0, nv, s0, ns, cfg_mask, _ptr(d_results), _ptr(d_child), stride),

@@ -1374,6 +1374,170 @@ __global__ __launch_bounds__(256) void pp_k_select_nearest(const double* lengths
 }
 
 // ------------------------------------------------------------------------------------------
+// The ORDER in which SamplingBasedPlanner::expand pushes the k winners of a radius (SamplingBasedPlanner.cpp:82-149): it visits
+// the samples nearest-first by Euclidean distance, keeps a max-heap of the k best by approximate cost (std::push_heap, and
+// std::pop_heap once the heap holds k + 1), stops once the heap is full and its worst LENGTH is not above the next distance, and
+// then walks the heap ARRAY front to back.  Which vertex std::pop_heap later surfaces among children of exactly equal f depends
+// on that order, so it is replayed here: one 256-thread workgroup per (vertex, radius).
+//   1. candidates = valid samples (farther than the increment) with distance <= the k-th smallest length (pp_k_select_nearest):
+//      everything the scan can visit before it stops (a winner's distance is at most its length), compacted into LDS;
+//   2. bitonic sort by (distance, sample index);
+//   3. wave 0 replays the scan with the heap held one slot per lane (parent/child moves are v_readlane and a lane-select, no memory),
+//      following libstdc++'s __push_heap / __adjust_heap step for step.  A candidate whose cost is strictly above the heap's
+//      root, pushed onto a full heap of pairwise distinct costs and popped again, leaves the array exactly as it was (the hole
+//      sinks along the path the push shifted down and every element returns to its slot), so only the candidates at or below
+//      the current root — a few dozen of the hundreds to thousands — are taken through the exact steps.
+// More than PP_ORD_CAP candidates are sorted in a global scratch instead of LDS (same code, slower); more than the scratch holds,
+// k above 64, or equal costs inside a heap fall back to ascending length and raise *fallbacks (the caller reports it).
+#define PP_ORD_CAP 4096
+struct PPOrdHeap { double cost, len; int idx; };
+__device__ __forceinline__ void pp_ord_set(PPOrdHeap& h, int slot, double cost, double len, int idx) {   // slot and values are wave-uniform
+    const bool mine = pp_lane() == slot;
+    h.cost = mine ? cost : h.cost;
+    h.len = mine ? len : h.len;
+    h.idx = mine ? idx : h.idx;
+}
+__device__ __forceinline__ void pp_ord_move(PPOrdHeap& h, int to, int from) {
+    pp_ord_set(h, to, pp_readlane(h.cost, from), pp_readlane(h.len, from), pp_readlane_i(h.idx, from));
+}
+// std::__push_heap(first, holeIndex, topIndex = 0, value, comp = cost <)
+__device__ __forceinline__ void pp_ord_sift_up(PPOrdHeap& h, int hole, double cost, double len, int idx) {
+    while (hole > 0) {
+        const int parent = (hole - 1) >> 1;
+        if (!(pp_readlane(h.cost, parent) < cost)) break;
+        pp_ord_move(h, hole, parent);
+        hole = parent;
+    }
+    pp_ord_set(h, hole, cost, len, idx);
+}
+// std::pop_heap on n + 1 elements: the last one is taken out as `value`, the root leaves, std::__adjust_heap(first, 0, n, value)
+__device__ __forceinline__ void pp_ord_pop(PPOrdHeap& h, int n) {
+    const double vc = pp_readlane(h.cost, n), vl = pp_readlane(h.len, n);
+    const int vi = pp_readlane_i(h.idx, n);
+    int hole = 0, second = 0;
+    while (second < (n - 1) / 2) {
+        second = 2 * (second + 1);
+        if (pp_readlane(h.cost, second) < pp_readlane(h.cost, second - 1)) second--;
+        pp_ord_move(h, hole, second);
+        hole = second;
+    }
+    if ((n & 1) == 0 && second == (n - 2) / 2) {
+        second = 2 * (second + 1);
+        pp_ord_move(h, hole, second - 1);
+        hole = second - 1;
+    }
+    pp_ord_sift_up(h, hole, vc, vl, vi);
+}
+template <typename KP, typename IP>
+__device__ __forceinline__ void pp_ord_bitonic(KP key, IP val, int n2) {   // ascending by (key, val); n2 a power of two; whole workgroup
+    for (int size = 2; size <= n2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = (int)threadIdx.x; t < (n2 >> 1); t += (int)blockDim.x) {
+                const int i = ((t / stride) * stride << 1) + (t % stride), j = i + stride;
+                const double ki = key[i], kj = key[j];
+                const int vi = val[i], vj = val[j];
+                const bool up = (i & size) == 0;
+                const bool gt = ki > kj || (ki == kj && vi > vj);
+                if (gt == up) { key[i] = kj; key[j] = ki; val[i] = vj; val[j] = vi; }
+            }
+        }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void pp_k_expand_order(const double* lengths, const ppgpu_vertex* verts, const double* sx, const double* sy,
+                                                         long long ns, int k, double max_speed, double tpf, int two_radii,
+                                                         const int* sel_idx, const double* sel_len, double* g_key, int* g_val,
+                                                         long long g_cap, int* out_idx, unsigned* fallbacks) {
+    __shared__ double cd[PP_ORD_CAP];
+    __shared__ int ci[PP_ORD_CAP];
+    __shared__ int count;
+    const int vr = blockIdx.x, v = vr >> 1, r = vr & 1;
+    const int tid = (int)threadIdx.x;
+    int* out = out_idx + (size_t)vr * k;
+    const int* wi = sel_idx + (size_t)vr * k;
+    const double* wl = sel_len + (size_t)vr * k;
+    if ((r == 1 && !two_radii) || wi[0] < 0) {               // radius not in use (:60-63,97-100), or no sample farther than the increment
+        for (int j = tid; j < k; j += 256) out[j] = (r == 1 && !two_radii) ? -1 : wi[j];
+        return;
+    }
+    const double* L = lengths + ((size_t)v * ns) * 2 + r;
+    const bool fullSet = wi[k - 1] >= 0;
+    const double bound = fullSet ? wl[k - 1] * (1.0 + 1e-9) : INFINITY;   // fewer than k valid samples: the scan visits them all
+    const double vx = verts[v].x, vy = verts[v].y;
+    if (tid == 0) count = 0;
+    __syncthreads();
+    // 1. candidates, distance = State::distanceTo (State.h:177-179) of the sample to the source
+    double* gk = g_key + (size_t)vr * g_cap;
+    int* gv = g_val + (size_t)vr * g_cap;
+    for (long long s = tid; s < ns; s += 256) {
+        if (!(L[s * 2] >= 0)) continue;
+        const double d = sqrt((sx[s] - vx) * (sx[s] - vx) + (sy[s] - vy) * (sy[s] - vy));
+        if (d > bound) continue;
+        const int slot = atomicAdd(&count, 1);
+        if (slot < PP_ORD_CAP) { cd[slot] = d; ci[slot] = (int)s; }
+        if (slot < g_cap) { gk[slot] = d; gv[slot] = (int)s; }      // kept too, in case LDS overflows
+    }
+    __syncthreads();
+    const int M = count;
+    bool fallback = k >= PP_WAVE;                              // the heap holds k + 1 entries for a moment, one per lane
+    const bool inLds = M <= PP_ORD_CAP;
+    int n2 = 64;
+    while (n2 < M) n2 <<= 1;
+    if (!fallback) {
+        // 2. sort
+        if (inLds) {
+            for (int i = M + tid; i < n2; i += 256) { cd[i] = INFINITY; ci[i] = 0x7fffffff; }
+            pp_ord_bitonic(cd, ci, n2);
+        } else if ((long long)n2 <= g_cap) {
+            for (int i = M + tid; i < n2; i += 256) { gk[i] = INFINITY; gv[i] = 0x7fffffff; }
+            pp_ord_bitonic(gk, gv, n2);
+        } else {
+            fallback = true;
+        }
+    }
+    if (tid >= PP_WAVE) return;
+    // 3. replay (wave 0)
+    const int lane = tid;
+    PPOrdHeap h;
+    h.cost = INFINITY; h.len = INFINITY; h.idx = -1;
+    int hsize = 0;
+    bool dup = false, stopped = false;
+    if (!fallback) {
+        for (int base = 0; base < M && !stopped && !dup; base += PP_WAVE) {
+            const int c = base + lane;
+            const bool have = c < M;
+            const double d = have ? (inLds ? cd[c] : gk[c]) : INFINITY;
+            const int idx = have ? (inLds ? ci[c] : gv[c]) : -1;
+            const double len = have ? L[(size_t)idx * 2] : INFINITY;
+            const double cost = len / max_speed * tpf;                 // Edge::computeApproxCost (Edge.cpp:17)
+            // the candidates of this chunk that can change the heap: every one while it is not full, afterwards those at or below the
+            // root's cost as it stands at the start of the chunk (the root only ever gets cheaper)
+            unsigned long long todo = (hsize < k) ? __ballot(have) : __ballot(have & (cost <= pp_readlane(h.cost, 0)));
+            while (todo) {
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const double dj = pp_readlane(d, j), lj = pp_readlane(len, j), cj = pp_readlane(cost, j);
+                const int ij = pp_readlane_i(idx, j);
+                if (hsize >= k) {
+                    if (!(pp_readlane(h.len, 0) > dj)) { stopped = true; break; }        // :104-106, else branch :130-132
+                    if (cj > pp_readlane(h.cost, 0)) continue;                            // the root moved since the chunk began: a no-op
+                }
+                if (__ballot((lane < hsize) & (h.cost == cj)) != 0ull) { dup = true; break; }
+                pp_ord_sift_up(h, hsize, cj, lj, ij);                                     // push_back + std::push_heap
+                hsize++;
+                if (hsize > k) { hsize--; pp_ord_pop(h, hsize); }                         // std::pop_heap + pop_back
+            }
+        }
+    }
+    if (fallback || dup) {
+        if (lane == 0) atomicAdd(fallbacks, 1u);
+        for (int j = lane; j < k; j += PP_WAVE) out[j] = wi[j];
+        return;
+    }
+    if (lane < k) out[lane] = (lane < hsize) ? h.idx : -1;      // the heap array, front to back
+}
+
+// ------------------------------------------------------------------------------------------
 // ppgpu_expand_host uploads one block {vertices | ribbons | explicit target x, y, heading per vertex | has-target flags} in one
 // copy; this puts its parts where the other kernels expect them (vertex array, ribbon pool, the slots behind the stored
 // samples, flags).  Everything is 8-byte words except the flags.

@@ -106,6 +106,10 @@ struct ppgpu_ctx {
     bool ev_valid = false;
     int max_vertex_ribbons = 0;
     DevBuf<int> tmp_idx;
+    DevBuf<double> ord_key;             // pp_k_expand_order: candidate scratch beyond what LDS holds, push-order output, fallback counter
+    DevBuf<int> ord_val, ord_idx;
+    DevBuf<unsigned> ord_fallbacks;
+    unsigned long long order_fallbacks = 0;   // (vertex, radius) lists of ppgpu_expand_host / ppgpu_expand_order that fell back to ascending length
     DevBuf<unsigned char> dstage_in, dstage_out;            // device ends of ppgpu_expand_host's single upload / download
     void* stage_in = nullptr; size_t stage_in_cap = 0;      // pinned host staging of ppgpu_expand_host
     void* stage_out = nullptr; size_t stage_out_cap = 0;
@@ -154,6 +158,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->sx.release(); c->sy.release(); c->sh.release(); c->samp_ribbons.release();
     c->s_bytes.release(); c->s_u64.release(); c->s_u32a.release(); c->s_u32b.release(); c->s_cand.release();
     c->tmp_edges.release(); c->tmp_wedges.release(); c->partial.release(); c->tmp_results.release(); c->tmp_child.release();
+    c->ord_key.release(); c->ord_val.release(); c->ord_idx.release(); c->ord_fallbacks.release();
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     c->setup.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
     c->track_summary.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->work.release(); c->dstage_in.release(); c->dstage_out.release();
@@ -589,6 +594,50 @@ int ppgpu_select_nearest(ppgpu_ctx* c, int32_t v0, int32_t nv, int32_t k, int32_
     return PPGPU_OK;
 }
 
+// After pp_k_dubins_lengths + pp_k_select_nearest for vertices [0, nv) (results in c->tmp_lengths / tmp_idx / tmp_len_out): the
+// winners of every (vertex, radius) in the reference's push order -> c->ord_idx.  Asynchronous; *c->ord_fallbacks.p counts lists
+// that kept ascending length.
+static int launch_expand_order(ppgpu_ctx* c, int nv, int k) {
+    const long long ns = c->n_samples;
+    long long cap = 64;
+    while (cap < ns && cap < 65536) cap <<= 1;
+    int rc;
+    if ((rc = c->ord_key.reserve((size_t)nv * 2 * cap, false, c->stream)) || (rc = c->ord_val.reserve((size_t)nv * 2 * cap, false, c->stream)) ||
+        (rc = c->ord_idx.reserve((size_t)nv * 2 * k, false, c->stream)) || (rc = c->ord_fallbacks.reserve(1, false, c->stream)))
+        return rc;
+    HIP_TRY(hipMemsetAsync(c->ord_fallbacks.p, 0, sizeof(unsigned), c->stream));
+    const int two_radii = (c->cfg.coverage_turning_radius != c->cfg.turning_radius) ? 1 : 0;
+    hipLaunchKernelGGL(pp_k_expand_order, dim3((unsigned)(nv * 2)), dim3(256), 0, c->stream, c->tmp_lengths.p, c->verts.p, c->sx.p, c->sy.p, ns, k,
+                       c->cfg.max_speed, c->cfg.time_penalty_factor, two_radii, c->tmp_idx.p, c->tmp_len_out.p, c->ord_key.p, c->ord_val.p, cap,
+                       c->ord_idx.p, c->ord_fallbacks.p);
+    HIP_TRY(hipGetLastError());
+    return PPGPU_OK;
+}
+
+int ppgpu_expand_order(ppgpu_ctx* c, int32_t v0, int32_t nv, int32_t k, int32_t* h_idx, uint32_t* h_fallbacks) {
+    int rc = require_world(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (k <= 0 || !h_idx || v0 != 0 || nv <= 0 || nv > c->nverts) return fail(PPGPU_EINVAL, "expand_order: bad arguments (v0 must be 0)");
+    const long long ns = c->n_samples;
+    const size_t nout = (size_t)nv * 2 * k;
+    if ((rc = c->tmp_lengths.reserve((size_t)nv * ns * 2, false, c->stream)) || (rc = c->tmp_idx.reserve(nout, false, c->stream)) ||
+        (rc = c->tmp_len_out.reserve(nout, false, c->stream)))
+        return rc;
+    if ((rc = ppgpu_dubins_lengths(c, 0, nv, c->tmp_lengths.p))) return rc;
+    hipLaunchKernelGGL(pp_k_select_nearest, dim3((unsigned)(nv * 2)), dim3(256), 0, c->stream, c->tmp_lengths.p, ns, k, c->tmp_idx.p, c->tmp_len_out.p);
+    if ((rc = launch_expand_order(c, nv, k))) return rc;
+    unsigned fb = 0;
+    HIP_TRY(hipMemcpyAsync(h_idx, c->ord_idx.p, nout * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&fb, c->ord_fallbacks.p, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->order_fallbacks += fb;
+    if (h_fallbacks) *h_fallbacks = fb;
+    return PPGPU_OK;
+}
+
+uint64_t ppgpu_order_fallbacks(ppgpu_ctx* c) { return c ? c->order_fallbacks : 0; }
+
 // ------------------------------------------------------------------------------ edge costing
 int64_t ppgpu_dense_edge_count(int32_t nv, int64_t ns, uint32_t cfg_mask) {
     return (int64_t)nv * ns * (int64_t)__builtin_popcount(cfg_mask & 0xFu);
@@ -913,11 +962,12 @@ int ppgpu_expand_host(ppgpu_ctx* c, int32_t nv, const ppgpu_vertex* hv, int32_t 
         hipLaunchKernelGGL(pp_k_dubins_lengths, dim3((unsigned)((ns + 255) / 256), (unsigned)nv), dim3(256), 0, st, c->verts.p, 0, c->sx.p, c->sy.p,
                            c->sh.p, ns, c->cfg.turning_radius, c->cfg.coverage_turning_radius, c->cfg.collision_checking_increment, c->tmp_lengths.p);
         hipLaunchKernelGGL(pp_k_select_nearest, dim3((unsigned)(nv * 2)), dim3(256), 0, st, c->tmp_lengths.p, ns, k, c->tmp_idx.p, c->tmp_len_out.p);
+        if ((rc = launch_expand_order(c, nv, k))) return rc;   // the winners in the order expand() pushes them
     }
     const double slow = c->cfg.slow_speed <= 0 ? c->cfg.max_speed : c->cfg.slow_speed;     // PlannerConfig::slowSpeed()
     const int two_speeds = (slow != c->cfg.max_speed) ? 1 : 0;                              // SamplingBasedPlanner.cpp:57-59
     const int two_radii = (c->cfg.coverage_turning_radius != c->cfg.turning_radius) ? 1 : 0;  // :60-63
-    hipLaunchKernelGGL(pp_k_build_expand_edges, dim3((unsigned)((nv + 63) / 64)), dim3(64), 0, st, nv, k, select ? c->tmp_idx.p : nullptr,
+    hipLaunchKernelGGL(pp_k_build_expand_edges, dim3((unsigned)((nv + 63) / 64)), dim3(64), 0, st, nv, k, select ? c->ord_idx.p : nullptr,
                        c->s_bytes.p, ns, two_speeds, two_radii, E, d_edges);
     HIP_TRY(hipGetLastError());
     // ---- cost the whole list
@@ -929,10 +979,14 @@ int ppgpu_expand_host(ppgpu_ctx* c, int32_t nv, const ppgpu_vertex* hv, int32_t 
     p.n_edges = cap;
     p.out = d_results; p.child = d_child; p.stride = stride;
     if ((rc = launch_cost(c, p))) return rc;
-    if ((rc = stage_reserve(&c->stage_out, &c->stage_out_cap, out_bytes))) return rc;
+    if ((rc = stage_reserve(&c->stage_out, &c->stage_out_cap, out_bytes + 16))) return rc;
     char* sout = (char*)c->stage_out;
     HIP_TRY(hipMemcpyAsync(sout, c->dstage_out.p, out_bytes, hipMemcpyDeviceToHost, st));
+    unsigned* fb = (unsigned*)(sout + out_bytes);          // pinned, behind the block
+    *fb = 0;
+    if (select) HIP_TRY(hipMemcpyAsync(fb, c->ord_fallbacks.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    c->order_fallbacks += *fb;
     const uint64_t* se = (const uint64_t*)(sout + q_e);
     const ppgpu_edge_result* sr = (const ppgpu_edge_result*)(sout + q_r);
     const double* sc = (const double*)(sout + q_c);

@@ -49,6 +49,9 @@ public:
     // this build's knobs
     void setPlanningTimeSeconds(double s) { m_PlanningTimeSeconds = s; }   // reference: c_PlanningTimeSeconds = 0.85 (executive.h:183)
     void setSpeculation(int n) { m_PlannerConfig.setSpeculation(n); }
+    // the devices every cycle's planner works on (default: device 0).  The contexts are process-level (GpuContext::shared) and
+    // are held here for the life of the executive, so no cycle pays for device allocations an earlier cycle already made.
+    void setDevices(const std::vector<int>& devices) { m_Contexts = GpuContext::shared(devices); }
     bool waitUntilInactive(double seconds);
     unsigned long cycles() const { return m_Cycles; }
     unsigned long emptyPlans() const { return m_EmptyPlans; }
@@ -63,7 +66,8 @@ private:
     TrajectoryPublisher* m_TrajectoryPublisher;
     PlannerConfig m_PlannerConfig;
     RibbonManager m_RibbonManager;
-    std::mutex m_RibbonManagerMutex, m_MapMutex, m_PlannerStateMutex;
+    std::mutex m_RibbonManagerMutex, m_MapMutex, m_PlannerStateMutex, m_ObstaclesMutex;
+    std::vector<std::shared_ptr<GpuContext>> m_Contexts;
     std::condition_variable m_CancelCV;
     PlannerState m_PlannerState = PlannerState::Inactive;
     std::future<void> m_PlanningFuture;

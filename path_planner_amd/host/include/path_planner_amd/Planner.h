@@ -6,7 +6,11 @@
 // The A* control flow, the open list and the clock polling stay on the host in the reference's order, so that with the same
 // injected clock and seed the same vertices are expanded in the same order.
 #pragma once
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -36,6 +40,8 @@ public:
         // extra, for parity checks against the CPU oracle
         long FirstGoalIteration = -1;
         unsigned long EdgesCosted = 0;
+        unsigned long HostHeuristics = 0;     // children whose ribbon list exceeded the device's TSP enumeration: h computed on the host
+        unsigned long OrderFallbacks = 0;     // (vertex, radius) lists whose push order the device could not replay (ppgpu_order_fallbacks)
     };
     Planner();
     virtual ~Planner() = default;
@@ -51,6 +57,10 @@ protected:
 
 // Process-level device handle: stream, persistent buffers (the reference builds a new planner every cycle,
 // executive.cpp:85-90, so nothing device-side may live in the planner object).  Throws std::runtime_error.
+// shared(device) hands out ONE context per device for the life of the process: the cache holds a strong reference, so the
+// buffers a cycle grew (samples, workspace, pinned staging) are there for the next cycle's planner; releaseShared() drops them.
+// Each context owns one host thread bound to its device: a planner that is given several contexts runs its per-device work
+// there (run()), so the devices of a node cost their parts of a batch at the same time.
 class GpuContext {
 public:
     explicit GpuContext(int device = 0);
@@ -58,15 +68,32 @@ public:
     GpuContext(const GpuContext&) = delete;
     GpuContext& operator=(const GpuContext&) = delete;
     ppgpu_ctx* handle() const { return m_Handle; }
-    static std::shared_ptr<GpuContext> shared(int device = 0);   // one per device per process
+    int device() const { return m_Device; }
+    static std::shared_ptr<GpuContext> shared(int device = 0);   // one per device per process, kept until releaseShared()
+    static std::vector<std::shared_ptr<GpuContext>> shared(const std::vector<int>& devices);
+    static void releaseShared();
+    // run `job` on this context's thread; wait() blocks until it has finished and rethrows what it threw
+    void run(std::function<void()> job);
+    void wait();
 
 private:
     ppgpu_ctx* m_Handle = nullptr;
+    int m_Device = 0;
+    std::thread m_Thread;
+    std::mutex m_Mutex;
+    std::condition_variable m_Wake;
+    std::function<void()> m_Job;
+    bool m_Busy = false, m_Quit = false;
+    std::exception_ptr m_Error;
+    void serve();
 };
 
 class GpuAStarPlanner : public Planner {
 public:
-    explicit GpuAStarPlanner(std::shared_ptr<GpuContext> ctx = GpuContext::shared()) : m_Ctx(std::move(ctx)) {}
+    explicit GpuAStarPlanner(std::shared_ptr<GpuContext> ctx = GpuContext::shared()) : m_Ctx(ctx), m_Ctxs{ctx} {}
+    // several devices of one node: world and samples are replicated on each (the sampler stream is deterministic: every device
+    // draws the same samples itself), the open vertices of a batch are dealt across them, records come back to the host search
+    explicit GpuAStarPlanner(std::vector<std::shared_ptr<GpuContext>> ctxs) : m_Ctx(ctxs.at(0)), m_Ctxs(std::move(ctxs)) {}
     Stats plan(const RibbonManager& ribbonManager, const State& start, PlannerConfig config, const DubinsPlan& previousPlan,
                double timeRemaining) override;
 
@@ -85,7 +112,8 @@ public:
     };
 
 private:
-    std::shared_ptr<GpuContext> m_Ctx;
+    std::shared_ptr<GpuContext> m_Ctx;                    // device 0 of this planner: sampling read-back, wrapper edges, explicit targets
+    std::vector<std::shared_ptr<GpuContext>> m_Ctxs;      // all of them (m_Ctxs[0] == m_Ctx)
     std::vector<Node> m_Nodes;
     std::vector<int> m_Queue;      // binary heap of node indices, min f (AStarPlanner.cpp:6-10)
     int m_Best = -1;
@@ -108,8 +136,9 @@ private:
     bool goalCondition(const Node& v) const;
     void expand(int source);
     void expandBatch(const std::vector<int>& sources);
+    void expandOn(GpuContext& ctx, const std::vector<int>& sources, std::vector<std::pair<int, Costed>>& out, unsigned long& edgesCosted) const;
     int costEdgeList(const std::vector<uint64_t>& edges, int maxParentRibbons, std::vector<::ppgpu_edge_result>& res, std::vector<double>& child);
-    Node makeChild(int source, unsigned cfgBits, const ::ppgpu_edge_result& r, const double* childRibbons);
+    Node makeChild(int source, unsigned cfgBits, const ::ppgpu_edge_result& r, const double* childRibbons, int stride);
     int aStar(double endTime);
     void addSamples(long n);
     int depth(int v) const;

@@ -60,6 +60,7 @@ void Executive::clearRibbons() {
 }
 
 void Executive::updateDynamicObstacle(uint32_t mmsi, State o, double width, double length) {   // both models are kept current (:313-319)
+    std::lock_guard<std::mutex> guard(m_ObstaclesMutex);
     m_BinaryDynamicObstaclesManager->update(mmsi, o.x(), o.y(), o.heading(), o.speed(), o.time(), width, length);
     m_GaussianDynamicObstaclesManager->update(mmsi, o.x(), o.y(), o.heading(), o.speed(), o.time());
 }
@@ -146,6 +147,14 @@ void Executive::planLoop() {
     const double missionStart = out.getTime();
     double collisionsSeen = 0;   // sum over cycles of collisionExists at the vehicle's reported state (:158-167)
 
+    // every run starts without contacts: the node reports the live ones again within a second (executive.cpp:46-50)
+    {
+        std::lock_guard<std::mutex> guard(m_ObstaclesMutex);
+        m_BinaryDynamicObstaclesManager = std::make_shared<BinaryDynamicObstaclesManager>();
+        m_GaussianDynamicObstaclesManager = std::make_shared<GaussianDynamicObstaclesManager>();
+    }
+    if (m_Contexts.empty()) m_Contexts = GpuContext::shared(std::vector<int>{0});
+
     auto cancelled = [this] {
         std::unique_lock<std::mutex> guard(m_PlannerStateMutex);
         return m_PlannerState == PlannerState::Cancelled;
@@ -196,20 +205,23 @@ void Executive::planLoop() {
             }
             if (!c_ReusePlanEnabled) cyc.last.Plan = DubinsPlan();
             if (!cyc.last.Plan.empty()) cyc.last.Plan.changeIntoSuffix(cyc.from.time());   // what is left of the last plan (:146)
-            const DynamicObstaclesManager& reportModel = m_UseGaussianDynamicObstacles
-                                                             ? static_cast<const DynamicObstaclesManager&>(*m_GaussianDynamicObstaclesManager)
-                                                             : static_cast<const DynamicObstaclesManager&>(*m_BinaryDynamicObstaclesManager);
-            const double hitNow = reportModel.DynamicObstaclesManager::collisionExists(m_LastState, false);   // base class on purpose (:160-165)
+            // this cycle's snapshot of the contacts: the callbacks keep updating the live managers while the planner reads its copy
+            DynamicObstaclesManager::SharedPtr contacts;
+            {
+                std::lock_guard<std::mutex> guard(m_ObstaclesMutex);
+                if (m_UseGaussianDynamicObstacles) contacts = std::make_shared<GaussianDynamicObstaclesManager>(*m_GaussianDynamicObstaclesManager);
+                else contacts = std::make_shared<BinaryDynamicObstaclesManager>(*m_BinaryDynamicObstaclesManager);
+            }
+            const double hitNow = contacts->DynamicObstaclesManager::collisionExists(m_LastState, false);   // base class on purpose (:160-165)
             collisionsSeen += hitNow;
             m_Cycles++;
 
             // ---- solve(): one plan() call with whatever is left of this cycle's time budget
             try {
                 if (m_IgnoreDynamicObstacles) m_PlannerConfig.setObstaclesManager(std::make_shared<DynamicObstaclesManager>());
-                else if (m_UseGaussianDynamicObstacles) m_PlannerConfig.setObstaclesManager(m_GaussianDynamicObstaclesManager);
-                else m_PlannerConfig.setObstaclesManager(m_BinaryDynamicObstaclesManager);
+                else m_PlannerConfig.setObstaclesManager(contacts);
                 ribbons.coverBetween(m_LastState.x(), m_LastState.y(), cyc.from.x(), cyc.from.y(), false);   // up to where we plan from (:186)
-                GpuAStarPlanner planner;                                          // stateless: a new one every cycle (:85-90)
+                GpuAStarPlanner planner(m_Contexts);                              // stateless: a new one every cycle (:85-90); the device contexts persist
                 cyc.last = planner.plan(ribbons, cyc.from, m_PlannerConfig, cyc.last.Plan, cycleStart + m_PlanningTimeSeconds - out.getTime());
             } catch (const std::exception& e) {                                   // logged, plan dropped, loop continues (:191-195)
                 std::cerr << "Exception thrown while planning: " << e.what() << " - proceeding without a plan." << std::endl;

@@ -18,6 +18,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <utility>
 
 #include "../../../include/ppgpu.h"
 
@@ -72,21 +73,83 @@ Planner::Stats Planner::plan(const RibbonManager&, const State&, PlannerConfig c
 }
 
 // ------------------------------------------------------------------------------------------------ GpuContext
-GpuContext::GpuContext(int device) {
+GpuContext::GpuContext(int device) : m_Device(device) {
     if (ppgpu_create(device, &m_Handle) != PPGPU_OK) throw std::runtime_error(std::string("ppgpu_create: ") + ppgpu_last_error());
+    m_Thread = std::thread(&GpuContext::serve, this);
 }
-GpuContext::~GpuContext() { ppgpu_destroy(m_Handle); }
+
+GpuContext::~GpuContext() {
+    {
+        std::lock_guard<std::mutex> lock(m_Mutex);
+        m_Quit = true;
+    }
+    m_Wake.notify_all();
+    if (m_Thread.joinable()) m_Thread.join();
+    ppgpu_destroy(m_Handle);
+}
+
+void GpuContext::serve() {
+    std::unique_lock<std::mutex> lock(m_Mutex);
+    for (;;) {
+        m_Wake.wait(lock, [this] { return m_Quit || (m_Busy && m_Job); });
+        if (m_Quit) return;
+        std::function<void()> job = std::move(m_Job);
+        m_Job = nullptr;
+        lock.unlock();
+        std::exception_ptr err;
+        try { job(); } catch (...) { err = std::current_exception(); }
+        lock.lock();
+        m_Error = err;
+        m_Busy = false;
+        m_Wake.notify_all();
+    }
+}
+
+void GpuContext::run(std::function<void()> job) {
+    std::unique_lock<std::mutex> lock(m_Mutex);
+    m_Wake.wait(lock, [this] { return !m_Busy; });
+    m_Job = std::move(job);
+    m_Busy = true;
+    m_Error = nullptr;
+    m_Wake.notify_all();
+}
+
+void GpuContext::wait() {
+    std::unique_lock<std::mutex> lock(m_Mutex);
+    m_Wake.wait(lock, [this] { return !m_Busy; });
+    if (m_Error) {
+        std::exception_ptr e = m_Error;
+        m_Error = nullptr;
+        std::rethrow_exception(e);
+    }
+}
+
+namespace {
+std::mutex g_ctxMutex;
+// deliberately never destroyed: contexts must not outlive the HIP runtime's own static teardown
+std::map<int, std::shared_ptr<GpuContext>>& contextCache() {
+    static auto* cache = new std::map<int, std::shared_ptr<GpuContext>>();
+    return *cache;
+}
+}  // namespace
 
 std::shared_ptr<GpuContext> GpuContext::shared(int device) {
-    static std::mutex mtx;
-    static std::map<int, std::weak_ptr<GpuContext>> cache;
-    std::lock_guard<std::mutex> lock(mtx);
-    auto sp = cache[device].lock();
-    if (!sp) {
-        sp = std::make_shared<GpuContext>(device);
-        cache[device] = sp;
-    }
+    std::lock_guard<std::mutex> lock(g_ctxMutex);
+    std::shared_ptr<GpuContext>& sp = contextCache()[device];
+    if (!sp) sp = std::make_shared<GpuContext>(device);
     return sp;
+}
+
+std::vector<std::shared_ptr<GpuContext>> GpuContext::shared(const std::vector<int>& devices) {
+    std::vector<std::shared_ptr<GpuContext>> out;
+    for (int d : devices) out.push_back(shared(d));
+    if (out.empty()) out.push_back(shared(0));
+    return out;
+}
+
+void GpuContext::releaseShared() {
+    std::lock_guard<std::mutex> lock(g_ctxMutex);
+    contextCache().clear();
 }
 
 // ------------------------------------------------------------------------------------------------ helpers
@@ -116,7 +179,6 @@ int GpuAStarPlanner::depth(int v) const {
 
 // ------------------------------------------------------------------------------------------------ world upload
 void GpuAStarPlanner::uploadWorld(const State& start) {
-    ppgpu_ctx* h = m_Ctx->handle();
     ppgpu_config c{};
     c.max_speed = m_Config.maxSpeed();
     c.slow_speed = m_Config.slowSpeed();
@@ -133,21 +195,23 @@ void GpuAStarPlanner::uploadWorld(const State& start) {
     c.heuristic = (int32_t)m_RibbonManager.heuristic();
     c.tsp_k = m_RibbonManager.k();
     c.branching_factor = m_Config.branchingFactor();
-    check(ppgpu_set_config(h, &c), "ppgpu_set_config");
-
     std::vector<uint8_t> cells;
     int rows = 0, cols = 0;
     double res = 0;
     if (m_Config.map()) m_Config.map()->rasterize(cells, rows, cols, res);
-    check(ppgpu_set_grid(h, rows ? cells.data() : nullptr, rows, cols, res), "ppgpu_set_grid");
-
     std::vector<double> orows;
     const DynamicObstaclesManager& om = m_Config.obstaclesManager();
     om.deviceRows(orows);
-    if (om.deviceModel() == PPGPU_OBST_GAUSSIAN)
-        check(ppgpu_set_gaussian_obstacles(h, (int32_t)(orows.size() / 9), orows.empty() ? nullptr : orows.data(), 1), "ppgpu_set_gaussian_obstacles");
-    else
-        check(ppgpu_set_obstacles(h, om.deviceModel(), (int32_t)(orows.size() / 7), orows.empty() ? nullptr : orows.data()), "ppgpu_set_obstacles");
+    // the snapshot is replicated on every device of the planner (SURVEY 8 e: grid, obstacles and config are broadcast once per replan)
+    for (const auto& ctx : m_Ctxs) {
+        ppgpu_ctx* h = ctx->handle();
+        check(ppgpu_set_config(h, &c), "ppgpu_set_config");
+        check(ppgpu_set_grid(h, rows ? cells.data() : nullptr, rows, cols, res), "ppgpu_set_grid");
+        if (om.deviceModel() == PPGPU_OBST_GAUSSIAN)
+            check(ppgpu_set_gaussian_obstacles(h, (int32_t)(orows.size() / 9), orows.empty() ? nullptr : orows.data(), 1), "ppgpu_set_gaussian_obstacles");
+        else
+            check(ppgpu_set_obstacles(h, om.deviceModel(), (int32_t)(orows.size() / 7), orows.empty() ? nullptr : orows.data()), "ppgpu_set_obstacles");
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ open list
@@ -250,11 +314,24 @@ bool GpuAStarPlanner::goalCondition(const Node& v) const {   // :42-50
 void GpuAStarPlanner::addSamples(long n) {   // SamplingBasedPlanner::addSamples (:157-168)
     Lap lap(5);
     int64_t total = 0;
-    long left = n;
-    while (left > 0) {   // the device sampler takes at most 524288 attempts per call
-        long chunk = std::min<long>(left, 524288);
-        check(ppgpu_sampler_add(m_Ctx->handle(), chunk, &total), "ppgpu_sampler_add");
-        left -= chunk;
+    // every device draws the same attempts from the same generator state itself (the stream is a pure function of seed and
+    // position): nothing is copied between devices
+    auto draw = [this, n](GpuContext& ctx, int64_t& kept) {
+        long left = n;
+        while (left > 0) {   // the device sampler takes at most 524288 attempts per call
+            long chunk = std::min<long>(left, 524288);
+            check(ppgpu_sampler_add(ctx.handle(), chunk, &kept), "ppgpu_sampler_add");
+            left -= chunk;
+        }
+    };
+    if (m_Ctxs.size() == 1) {
+        draw(*m_Ctx, total);
+    } else {
+        std::vector<int64_t> kept(m_Ctxs.size(), 0);
+        for (size_t d = 0; d < m_Ctxs.size(); d++) m_Ctxs[d]->run([&, d] { draw(*m_Ctxs[d], kept[d]); });
+        for (auto& ctx : m_Ctxs) ctx->wait();
+        total = kept[0];
+        for (int64_t t : kept) if (t != total) throw std::runtime_error("the devices disagree on the sample set");
     }
     if (n > 0) m_NumSamples = (long)total;
     m_Speculated.clear();   // children costed ahead were chosen among the old samples
@@ -262,11 +339,15 @@ void GpuAStarPlanner::addSamples(long n) {   // SamplingBasedPlanner::addSamples
 
 // ------------------------------------------------------------------------------------------------ edges
 // The child Node of one costed edge (what Vertex::connect + Edge::computeTrueCost + Vertex::computeApproxToGo leave behind)
-GpuAStarPlanner::Node GpuAStarPlanner::makeChild(int source, unsigned cfgBits, const ppgpu_edge_result& r, const double* childRibbons) {
+GpuAStarPlanner::Node GpuAStarPlanner::makeChild(int source, unsigned cfgBits, const ppgpu_edge_result& r, const double* childRibbons, int stride) {
     if (r.flags & PPGPU_F_THROWS) throw std::runtime_error("Edge cost evaluation failed: invalid time in sample for Dubins path");
-    if (r.flags & (PPGPU_F_RIBBON_OVF | PPGPU_F_DUBINS_ERR))
+    const int nChild = (int)((r.info >> 8) & 0xff);
+    // PPGPU_F_RIBBON_OVF on a list that came back whole means only that the device's TSP enumeration stops at 8 (12) ribbons: the
+    // reference enumerates any length (RibbonManager.cpp:53-140), so h is computed here, with the same arithmetic as the root's
+    const bool hostHeuristic = (r.flags & PPGPU_F_RIBBON_OVF) && nChild <= stride;
+    if ((r.flags & PPGPU_F_DUBINS_ERR) || ((r.flags & PPGPU_F_RIBBON_OVF) && !hostHeuristic))
         throw std::runtime_error("Edge cost evaluation exceeded a device capacity (flags " + std::to_string(r.flags) + ", child ribbons " +
-                                 std::to_string((r.info >> 8) & 0xff) + ", parent ribbons " + std::to_string(m_Nodes[source].ribbons.count()) + ")");
+                                 std::to_string(nChild) + ", parent ribbons " + std::to_string(m_Nodes[source].ribbons.count()) + ")");
     const Node& src = m_Nodes[source];
     Node c;
     c.parent = source;
@@ -278,7 +359,11 @@ GpuAStarPlanner::Node GpuAStarPlanner::makeChild(int source, unsigned cfgBits, c
     c.g = r.g;
     c.h = r.h;
     c.ribbons = src.ribbons;   // keeps heuristic, K, turning radius
-    c.ribbons.assign(childRibbons, (int)((r.info >> 8) & 0xff), r.coverage_completed_time);
+    c.ribbons.assign(childRibbons, nChild, r.coverage_completed_time);
+    if (hostHeuristic) {       // Vertex::computeApproxToGo (Vertex.cpp:49-64): the child's heading goes where the callee says yaw
+        c.h = c.ribbons.approximateDistanceUntilDone(c.state.x(), c.state.y(), c.state.heading()) / m_Config.maxSpeed() * kTimePenaltyFactor;
+        m_Stats.HostHeuristics++;
+    }
     DubinsPath p;
     p.qi[0] = src.state.x(); p.qi[1] = src.state.y(); p.qi[2] = src.state.yaw();
     p.param[0] = r.param[0]; p.param[1] = r.param[1]; p.param[2] = r.param[2];
@@ -340,7 +425,7 @@ int GpuAStarPlanner::costStateEdges(int source, const std::vector<State>& target
             const bool cov = (cfgBits[i] & PPGPU_EDGE_COVERAGE) != 0;
             g_dump.write(m_Nodes[source].state, res[i], cov ? m_Config.coverageTurningRadius() : m_Config.turningRadius(), cov);
         }
-        m_Nodes.push_back(makeChild(source, cfgBits[i], res[i], child.data() + i * (size_t)stride * 4));
+        m_Nodes.push_back(makeChild(source, cfgBits[i], res[i], child.data() + i * (size_t)stride * 4, stride));
         visualizeTrajectory(m_Nodes.back());
         pushVertexQueue((int)m_Nodes.size() - 1);
     }
@@ -349,21 +434,22 @@ int GpuAStarPlanner::costStateEdges(int source, const std::vector<State>& target
 
 // SamplingBasedPlanner::expand (:52-151) for several open vertices in ONE device round trip: every vertex's edges are what
 // expand() would build for it alone (nearest ribbon endpoint at each speed and radius, then the k nearest samples per radius
-// at each speed), in that order; the children are kept aside, not pushed.
-void GpuAStarPlanner::expandBatch(const std::vector<int>& sources) {
-    ppgpu_ctx* h = m_Ctx->handle();
+// at each speed, in the order of the reference's heap array), in that order; the children are kept aside, not pushed.
+// Reads the search tree, writes only `out` / `edgesCosted`: several of these run at once on different devices.
+void GpuAStarPlanner::expandOn(GpuContext& ctx, const std::vector<int>& sources, std::vector<std::pair<int, Costed>>& out,
+                               unsigned long& edgesCosted) const {
+    ppgpu_ctx* h = ctx.handle();
     const int M = (int)sources.size();
-    g_prof.trips++;
     std::unique_ptr<Lap> lap(new Lap(1));
     // these vertices become the device's open-vertex array
     std::vector<ppgpu_vertex> verts((size_t)M);
-    std::vector<double> pool, rib;
+    std::vector<double> pool;
     int maxParent = 0;
     for (int i = 0; i < M; i++) {
-        verts[i] = makeVertex(m_Nodes[sources[i]]);
+        const Node& n = m_Nodes[sources[i]];
+        verts[i] = makeVertex(n);
         verts[i].ribbon_offset = (int32_t)(pool.size() / 4);
-        ribbonsToArray(m_Nodes[sources[i]].ribbons, rib);
-        pool.insert(pool.end(), rib.begin(), rib.end());
+        pool.insert(pool.end(), n.ribbons.rows(), n.ribbons.rows() + 4 * (size_t)n.ribbons.count());
         maxParent = std::max(maxParent, (int)verts[i].ribbon_count);
     }
     // nearest point to cover (:64-81): one explicit target per vertex that has one (computed on the host, as in the reference)
@@ -390,7 +476,7 @@ void GpuAStarPlanner::expandBatch(const std::vector<int>& sources) {
         check(ppgpu_expand_host(h, M, verts.data(), (int32_t)(pool.size() / 4), pool.empty() ? nullptr : pool.data(), nearest.data(), k, &n,
                                 edges.data(), res.data(), child.data(), stride),
               "ppgpu_expand_host");
-        m_Stats.EdgesCosted += (unsigned long)n;
+        edgesCosted += (unsigned long)n;
         bool retry = false;
         if (stride < kRibbonStride)
             for (int64_t i = 0; i < n && !retry; i++)
@@ -399,15 +485,42 @@ void GpuAStarPlanner::expandBatch(const std::vector<int>& sources) {
         stride = kRibbonStride;       // some child does not fit: again at the device's full per-vertex capacity
     }
     lap.reset(new Lap(3));
-    for (int i = 0; i < M; i++) m_Speculated[sources[i]].stride = stride;   // an entry even when a vertex has no edges at all
+    out.clear();
+    out.resize((size_t)M);
+    for (int i = 0; i < M; i++) { out[i].first = sources[i]; out[i].second.stride = stride; }   // an entry even when a vertex has no edges at all
     for (int64_t e = 0; e < n; e++) {
         const int owner = (int)((edges[e] >> 32) & 0xffffffu);
-        Costed& c = m_Speculated[sources[owner]];
+        Costed& c = out[(size_t)owner].second;
         c.cfgBits.push_back((unsigned)(edges[e] >> 56));
         const unsigned char* r = reinterpret_cast<const unsigned char*>(&res[e]);
         c.records.insert(c.records.end(), r, r + sizeof(ppgpu_edge_result));
         const double* cr = child.data() + (size_t)e * stride * 4;
         c.childRibbons.insert(c.childRibbons.end(), cr, cr + (size_t)stride * 4);
+    }
+}
+
+// One batch of open vertices: on one device as it is; on several, dealt round-robin (the batch is sorted by f, so every device
+// gets vertices of every priority and the one the search is waiting for sits first on device 0), one host thread per device.
+void GpuAStarPlanner::expandBatch(const std::vector<int>& sources) {
+    g_prof.trips++;
+    const size_t D = std::min(m_Ctxs.size(), sources.size());
+    std::vector<std::vector<std::pair<int, Costed>>> parts(std::max<size_t>(D, 1));
+    std::vector<unsigned long> costed(parts.size(), 0);
+    if (D <= 1) {
+        expandOn(*m_Ctx, sources, parts[0], costed[0]);
+    } else {
+        std::vector<std::vector<int>> share(D);
+        for (size_t i = 0; i < sources.size(); i++) share[i % D].push_back(sources[i]);
+        for (size_t d = 0; d < D; d++) m_Ctxs[d]->run([&, d] { expandOn(*m_Ctxs[d], share[d], parts[d], costed[d]); });
+        std::exception_ptr first;
+        for (size_t d = 0; d < D; d++) {
+            try { m_Ctxs[d]->wait(); } catch (...) { if (!first) first = std::current_exception(); }
+        }
+        if (first) std::rethrow_exception(first);
+    }
+    for (size_t d = 0; d < parts.size(); d++) {
+        m_Stats.EdgesCosted += costed[d];
+        for (auto& kv : parts[d]) m_Speculated[kv.first] = std::move(kv.second);
     }
 }
 
@@ -450,9 +563,10 @@ void GpuAStarPlanner::expand(int source) {
             const bool cov = (costed.cfgBits[e] & PPGPU_EDGE_COVERAGE) != 0;
             g_dump.write(m_Nodes[source].state, r, cov ? m_Config.coverageTurningRadius() : m_Config.turningRadius(), cov);
         }
-        const bool plainInfeasible = (r.flags & PPGPU_F_INFEASIBLE) && !(r.flags & (PPGPU_F_THROWS | PPGPU_F_RIBBON_OVF | PPGPU_F_DUBINS_ERR));
+        const bool truncated = (r.flags & PPGPU_F_RIBBON_OVF) && (int)((r.info >> 8) & 0xff) > costed.stride;
+        const bool plainInfeasible = (r.flags & PPGPU_F_INFEASIBLE) && !(r.flags & (PPGPU_F_THROWS | PPGPU_F_DUBINS_ERR)) && !truncated;
         if (plainInfeasible && !watch) continue;
-        m_Nodes.push_back(makeChild(source, costed.cfgBits[e], r, costed.childRibbons.data() + e * (size_t)costed.stride * 4));
+        m_Nodes.push_back(makeChild(source, costed.cfgBits[e], r, costed.childRibbons.data() + e * (size_t)costed.stride * 4, costed.stride));
         visualizeTrajectory(m_Nodes.back());   // in the reference each edge streams its sweep, then its vertex is pushed
         pushVertexQueue((int)m_Nodes.size() - 1);
     }
@@ -506,6 +620,8 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
     m_Speculated.clear();
     m_NumSamples = 0;
     ppgpu_ctx* h = m_Ctx->handle();
+    unsigned long orderFallbacksBefore = 0;
+    for (const auto& ctx : m_Ctxs) orderFallbacksBefore += (unsigned long)ppgpu_order_fallbacks(ctx->handle());
     uploadWorld(start);
 
     double minSpeed = m_Config.maxSpeed(), maxSpeed = m_Config.maxSpeed();
@@ -521,7 +637,8 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
     {
         std::vector<double> rib;
         ribbonsToArray(m_RibbonManager, rib);
-        check(ppgpu_sampler_init(h, bounds, seed, (int32_t)(rib.size() / 4), rib.empty() ? nullptr : rib.data()), "ppgpu_sampler_init");
+        for (const auto& ctx : m_Ctxs)
+            check(ppgpu_sampler_init(ctx->handle(), bounds, seed, (int32_t)(rib.size() / 4), rib.empty() ? nullptr : rib.data()), "ppgpu_sampler_init");
     }
     // root (:35-37)
     Node root;
@@ -578,7 +695,10 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
                 check(ppgpu_cost_wrapper_edges_host(h, 1, &we, &r, child.data(), kRibbonStride), "ppgpu_cost_wrapper_edges_host");
                 m_Stats.EdgesCosted++;
                 if (r.flags & PPGPU_F_THROWS) throw std::runtime_error("Invalid time in sample for Dubins path (previous plan)");
-                if (r.flags & (PPGPU_F_RIBBON_OVF | PPGPU_F_DUBINS_ERR)) throw std::runtime_error("Edge cost evaluation exceeded a device capacity");
+                const int nChild = (int)((r.info >> 8) & 0xff);
+                const bool hostHeuristic = (r.flags & PPGPU_F_RIBBON_OVF) && nChild <= kRibbonStride;
+                if ((r.flags & PPGPU_F_DUBINS_ERR) || ((r.flags & PPGPU_F_RIBBON_OVF) && !hostHeuristic))
+                    throw std::runtime_error("Edge cost evaluation exceeded a device capacity");
                 Node c;
                 c.parent = lastPlanEnd;
                 c.state = State(r.end_x, r.end_y, r.end_heading, r.end_speed, r.end_time);
@@ -588,7 +708,11 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
                 c.steps = (int)(r.info >> 16);
                 c.g = r.g; c.h = r.h;
                 c.ribbons = m_Nodes[lastPlanEnd].ribbons;
-                c.ribbons.assign(child.data(), (int)((r.info >> 8) & 0xff), r.coverage_completed_time);
+                c.ribbons.assign(child.data(), nChild, r.coverage_completed_time);
+                if (hostHeuristic) {
+                    c.h = c.ribbons.approximateDistanceUntilDone(c.state.x(), c.state.y(), c.state.heading()) / m_Config.maxSpeed() * kTimePenaltyFactor;
+                    m_Stats.HostHeuristics++;
+                }
                 c.wrapper = p;
                 if (!c.infeasible && r.end_time < c.wrapper.getEndTime()) c.wrapper.updateEndTime(r.end_time);
                 m_Nodes.push_back(std::move(c));
@@ -664,6 +788,8 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
         m_Stats.PlanHValue = m_Nodes[m_Best].h;
         m_Stats.Plan = tracePlan(m_Best);
     }
+    for (const auto& ctx : m_Ctxs) m_Stats.OrderFallbacks += (unsigned long)ppgpu_order_fallbacks(ctx->handle());
+    m_Stats.OrderFallbacks -= orderFallbacksBefore;
     g_prof.report("plan()");
     return m_Stats;
 }

@@ -74,6 +74,7 @@ int main(int argc, char** argv) {
     int flags[3] = {0, 0, 0};
     double planningTime = 0.1, maxSeconds = 60;
     int speculation = 16;
+    std::vector<int> devices;
     std::string line;
     while (std::getline(in, line)) {
         std::istringstream s(line);
@@ -87,18 +88,25 @@ int main(int argc, char** argv) {
         else if (k == "planning_time") s >> planningTime;
         else if (k == "max_seconds") s >> maxSeconds;
         else if (k == "speculation") s >> speculation;
+        else if (k == "devices") { int d; while (s >> d) devices.push_back(d); }
     }
     SimulatedVehicle vehicle(start);
     vehicle.setLookahead(planningTime);
     Executive exec(&vehicle);
     exec.setPlanningTimeSeconds(planningTime);
     exec.setSpeculation(speculation);
+    if (!devices.empty()) exec.setDevices(devices);
     exec.setConfiguration(cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], (int)cfg[5], (int)cfg[6], cfg[7], cfg[8], cfg[9], (int)cfg[10], flags[0] != 0, flags[1] != 0,
                           flags[2] != 0, false);
     if (!mapFile.empty()) exec.refreshMap(mapFile, 0, 0);
     for (auto& r : ribs) exec.addRibbon(r[0], r[1], r[2], r[3]);
-    uint32_t mmsi = 1;
-    for (auto& o : obst) exec.updateDynamicObstacle(mmsi++, State(o[0], o[1], o[2], o[3], o[4]), o[5], o[6]);
+    // the node's contact callback: every contact is reported again and again while it is tracked (a planning run starts by
+    // forgetting all contacts, executive.cpp:46-50)
+    auto reportContacts = [&] {
+        uint32_t mmsi = 1;
+        for (auto& o : obst) exec.updateDynamicObstacle(mmsi++, State(o[0], o[1], o[2], o[3], o[4]), o[5], o[6]);
+    };
+    reportContacts();
     exec.updateCovered(start.x(), start.y(), start.speed(), start.heading(), start.time());
     exec.startPlanner();
     // the node's odometry callback: 20 Hz position updates feeding Executive::updateCovered (path_planner_node.cpp)
@@ -108,6 +116,7 @@ int main(int argc, char** argv) {
         std::this_thread::sleep_for(std::chrono::milliseconds(50));
         State p = vehicle.pose();
         exec.updateCovered(p.x(), p.y(), p.speed(), p.heading(), p.time());
+        reportContacts();
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() > maxSeconds) { timedOut = true; break; }
     }
     exec.cancelPlanner();

@@ -37,6 +37,7 @@ int main(int argc, char** argv) {
     int replans = 0;
     double replanStep = 0.1;
     uint32_t mmsi = 1;
+    std::vector<int> devices;
     std::string line;
     while (std::getline(in, line)) {
         std::istringstream s(line);
@@ -75,6 +76,8 @@ int main(int argc, char** argv) {
             config.setVisualizer(std::make_shared<Visualizer>(p));
         } else if (k == "clock") { s >> t0 >> dt;
         } else if (k == "time_remaining") { s >> timeRemaining;
+        } else if (k == "devices") {          // device ids of the planner; an id that repeats gets its own second context on that device
+            int d; while (s >> d) devices.push_back(d);
         } else if (k == "repeat") { s >> repeat;
         } else if (k == "replan") { s >> replans >> replanStep;   // N consecutive cycles, start moved replanStep seconds along the plan
         } else if (k == "real_clock") { int v; s >> v; realClock = v != 0;   // now() = t0 + wall seconds since plan() began
@@ -92,6 +95,18 @@ int main(int argc, char** argv) {
     config.setMap(map);
     if (haveObst) config.setObstaclesManager(obst);
     if (haveGauss) config.setObstaclesManager(gauss);
+    std::vector<std::shared_ptr<GpuContext>> contexts;
+    try {
+        for (size_t i = 0; i < devices.size(); i++) {
+            bool seen = false;
+            for (size_t j = 0; j < i; j++) seen = seen || devices[j] == devices[i];
+            contexts.push_back(seen ? std::make_shared<GpuContext>(devices[i]) : GpuContext::shared(devices[i]));
+        }
+        if (contexts.empty()) contexts.push_back(GpuContext::shared(0));
+    } catch (const std::exception& e) {
+        std::printf("{\"exception\": \"%s\"}\n", e.what());
+        return 1;
+    }
     try {
         Planner::Stats st;
         std::vector<double> wall;
@@ -104,7 +119,7 @@ int main(int argc, char** argv) {
             for (int cyc = 0; cyc < replans; cyc++) {
                 const auto w0 = std::chrono::steady_clock::now();
                 config.setNowFunction([&]() { return tNow + std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count(); });
-                GpuAStarPlanner planner;
+                GpuAStarPlanner planner(contexts);
                 st = planner.plan(rm, cur, config, prev, timeRemaining);
                 wall.push_back(1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count());
                 iters += st.Iterations; expanded += st.Expanded; samples += st.Samples;
@@ -116,12 +131,16 @@ int main(int argc, char** argv) {
                 cur.speed() = config.maxSpeed();
                 rm.cover(cur.x(), cur.y(), false);      // Executive::updateCovered: the vehicle covers as it moves
             }
+            // the first cycle of a process allocates the device buffers (they persist in the contexts): reported on its own,
+            // the percentiles are over the cycles after it
+            const double firstCycle = wall.front();
+            if (wall.size() > 1) wall.erase(wall.begin());
             std::sort(wall.begin(), wall.end());
             const double p50 = wall[wall.size() / 2], p99 = wall[std::min(wall.size() - 1, (size_t)(0.99 * wall.size()))];
-            std::printf("{\"replans\": %d, \"budget_ms\": %.3f, \"wall_ms_p50\": %.3f, \"wall_ms_p99\": %.3f, \"wall_ms_max\": %.3f, "
-                        "\"mean_iterations\": %.2f, \"mean_expanded\": %.1f, \"mean_samples\": %.1f, \"failed_plans\": %lu}\n",
-                        replans, 1e3 * timeRemaining, p50, p99, wall.back(), (double)iters / replans, (double)expanded / replans,
-                        (double)samples / replans, failures);
+            std::printf("{\"replans\": %d, \"budget_ms\": %.3f, \"first_cycle_ms\": %.3f, \"wall_ms_p50\": %.3f, \"wall_ms_p99\": %.3f, \"wall_ms_max\": %.3f, "
+                        "\"mean_iterations\": %.2f, \"mean_expanded\": %.1f, \"mean_samples\": %.1f, \"failed_plans\": %lu, \"devices\": %zu}\n",
+                        replans, 1e3 * timeRemaining, firstCycle, p50, p99, wall.back(), (double)iters / replans, (double)expanded / replans,
+                        (double)samples / replans, failures, contexts.size());
             return 0;
         }
         for (int rep = 0; rep < repeat; rep++) {
@@ -131,7 +150,7 @@ int main(int argc, char** argv) {
                 config.setNowFunction([&]() { return t0 + std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count(); });
             else
                 config.setNowFunction([&]() { return t0 + (double)(calls++) * dt; });
-            GpuAStarPlanner planner;   // a fresh planner every cycle, like Executive::planLoop (executive.cpp:85-90)
+            GpuAStarPlanner planner(contexts);   // a fresh planner every cycle, like Executive::planLoop (executive.cpp:85-90)
             st = planner.plan(rm, start, config, prev, timeRemaining);
             wall.push_back(1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count());
         }
@@ -139,9 +158,10 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "plan() wall ms: min %.3f median %.3f max %.3f over %d calls\n", wall.front(), wall[wall.size() / 2], wall.back(), repeat);
         std::printf("{\"samples\": %lu, \"generated\": %lu, \"expanded\": %lu, \"iterations\": %lu, \"plan_f\": %.17g, "
                     "\"plan_collision_penalty\": %.17g, \"plan_time_penalty\": %.17g, \"plan_h\": %.17g, \"plan_depth\": %lu, "
-                    "\"first_goal_iteration\": %ld, \"edges_costed\": %lu, \"wall_ms_median\": %.4f, \"wall_ms_max\": %.4f, \"plan\": [",
+                    "\"first_goal_iteration\": %ld, \"edges_costed\": %lu, \"host_heuristics\": %lu, \"order_fallbacks\": %lu, \"wall_ms_median\": %.4f, "
+                    "\"wall_ms_max\": %.4f, \"plan\": [",
                     st.Samples, st.Generated, st.Expanded, st.Iterations, st.PlanFValue, st.PlanCollisionPenalty, st.PlanTimePenalty,
-                    st.PlanHValue, st.PlanDepth, st.FirstGoalIteration, st.EdgesCosted, wall[wall.size() / 2], wall.back());
+                    st.PlanHValue, st.PlanDepth, st.FirstGoalIteration, st.EdgesCosted, st.HostHeuristics, st.OrderFallbacks, wall[wall.size() / 2], wall.back());
         bool first = true;
         for (const auto& w : st.Plan.get()) {
             const DubinsPath& p = w.unwrap();

@@ -122,13 +122,14 @@ def config2(n_samples=4096):
     return Workload("cfg2_1024_10pct_4096", grid, 0.2, None, rib, [c, c, 0, 2.5, 1], n_samples, 7, cfg)
 
 
-def config3(n_samples=65536, n_obst=16):
-    """2048x2048 grid res 0.1 m, 10 % blocked (seed 2), 16 moving boxes (seed 3), 5 ribbons, TSP K=2 heuristic."""
+def config3(n_samples=65536, n_obst=16, keep_free=None):
+    """2048x2048 grid res 0.1 m, 10 % blocked (seed 2), 16 moving boxes (seed 3) with positions uniform in the map (SURVEY 8 d;
+    keep_free = (x, y, radius) redraws boxes that start closer than radius to a point), 5 ribbons, TSP K=2 heuristic."""
     cfg = make_config(start_state_time=1.0, heuristic=H_TSP_POINT_K, tsp_k=2)
     ext = 2048 * 0.1
     c = ext / 2
     grid = blob_grid(2048, 0.1, 0.10, 2, (c, c))
-    obst = obstacles(n_obst, 3, ext, keep_free=(c, c, 40.0)) if n_obst else None
+    obst = obstacles(n_obst, 3, ext, keep_free=keep_free) if n_obst else None
     rib = [[c - 20, c + 12 + 8 * i, c + 20, c + 12 + 8 * i] for i in range(5)]
     return Workload("cfg3_2048_10pct_65536_obst%d" % n_obst, grid, 0.1, obst, rib, [c, c, 0, 2.5, 1], n_samples, 7, cfg,
                     n_vertices=64)

@@ -91,6 +91,7 @@ for _n, _r, _a in [
     ("ppo_dubins_lengths", i32, [vp, vp, i32, i32, i64, vp, vp, vp, vp]),
     ("ppo_plan", i32, [vp, i32, vp, dbl, vp, i32, i32, i32, vp, dbl, dbl, dbl, C.POINTER(PlanStats), vp, i32, vp, i32, vp, i64,
                         C.POINTER(i64)]),
+    ("ppo_expand_order", None, [vp, vp, i64, vp, vp, vp, i32, vp]),
     ("ppo_expand_once", i32, [vp, i32, vp, vp, vp, u64, i64, i32, vp, i32, vp, vp, vp]),
     ("ppo_edge_event_stats", None, [vp, vp, vp, vp, vp, vp, i64, vp, vp]),
     ("ppo_hardware_threads", i32, []),
@@ -190,9 +191,20 @@ class World:
         O.ppo_dubins_lengths(self.h, _p(v), v0, nv, sx.shape[0], _p(sx), _p(sy), _p(sh), _p(out))
         return out
 
+    def expand_order(self, src5, sx, sy, sh, k):
+        """Heap-array order of the k winners per radius after the sample scan of SamplingBasedPlanner::expand (2 x k, -1 = none)."""
+        O.ppo_world_set_config(self.h, C.byref(self.cfg))
+        s, sx, sy, sh = f64(src5), f64(sx), f64(sy), f64(sh)
+        out = np.full((2, k), -1, dtype=np.int32)
+        O.ppo_expand_order(self.h, _p(s), sx.shape[0], _p(sx), _p(sy), _p(sh), k, _p(out))
+        return out
+
     def plan(self, ribbons4, start5, time_remaining, clock_t0, clock_dt, initial_samples=100, cct=-1.0, prev11=None,
              use_brown_paths=False, dump_edges=0):
+        """AStarPlanner::plan as the REFERENCE runs it: every heuristic enumerates ribbon lists of any length (the default mirror
+        of the device's enumeration limit is for record-level comparisons; the host planner computes those h values itself)."""
         O.ppo_world_set_config(self.h, C.byref(self.cfg))
+        O.ppo_world_set_tsp_limit(self.h, 0)
         r = f64(ribbons4).reshape(-1, 4)
         s = f64(start5)
         st = PlanStats()
@@ -204,6 +216,7 @@ class World:
         rc = O.ppo_plan(self.h, r.shape[0], _p(r) if r.shape[0] else None, cct, _p(s), initial_samples, 1 if use_brown_paths else 0,
                         prev.shape[0], _p(prev) if prev.shape[0] else None, time_remaining, clock_t0, clock_dt, C.byref(st),
                         _p(plan), 64, _p(itf), 256, _p(dump), dump_edges, C.byref(ne))
+        O.ppo_world_set_tsp_limit(self.h, 8)
         return rc, st, plan[:max(st.plan_len, 0)].copy(), itf[:st.iterations].copy(), (dump[:min(ne.value, dump_edges)] if dump_edges else None)
 
 
@@ -283,10 +296,9 @@ def ribbons_nearest_endpoint(ribbons4, s5):
 
 
 # ---------------------------------------------------------------- the reference's own objects (optional)
-REF = None
-if os.path.exists(REF_SO):
-    REF = C.CDLL(REF_SO)
-    for _n, _r, _a in [
+# oracle/_ref/libpp_ref.so is loaded on first use of `oracle.REF`, and only CPU tests use it: a process that runs the GPU tests
+# never maps it (the reference build is a checker for this container, not something GPU-box processes load).
+_REF_SIGS = [
         ("ref_state_yaw", dbl, [dbl]),
         ("ref_state_heading_to", dbl, [dbl, dbl, dbl, dbl]),
         ("ref_state_move", None, [vp, dbl]),
@@ -316,5 +328,22 @@ if os.path.exists(REF_SO):
         ("ref_obst_free", None, [vp]),
         ("ref_obst_update", None, [vp, C.c_uint, dbl, dbl, dbl, dbl, dbl, dbl, dbl]),
         ("ref_obst_collision_exists", dbl, [vp, dbl, dbl, dbl, i32]),
-    ]:
-        _sig(REF, _n, _r, _a)
+]
+_ref_cache = []
+
+
+def _load_ref():
+    if not _ref_cache:
+        lib = None
+        if os.path.exists(REF_SO):
+            lib = C.CDLL(REF_SO)
+            for n, r, a in _REF_SIGS:
+                _sig(lib, n, r, a)
+        _ref_cache.append(lib)
+    return _ref_cache[0]
+
+
+def __getattr__(name):
+    if name == "REF":
+        return _load_ref()
+    raise AttributeError(name)

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+)?(?:int|int64_t|double|char\s*\*|const char\s*\*)\s+\*?\s*([a-z_0-9]+)\s*\(", txt, flags=re.M)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|int64_t|uint64_t|double|char\s*\*|const char\s*\*)\s+\*?\s*([a-z_0-9]+)\s*\(", txt, flags=re.M)
     return [n for n in names if n.startswith(("ppgpu_", "dubins_")) and n != "ppgpu_edge_pack"]
 
 
