@@ -205,7 +205,7 @@ class Context:
     def expand_order(self, nv, k):
         """The k winners per (vertex, radius) in the order expand() pushes them (the reference's heap array); (idx, fallbacks)."""
         idx = np.zeros((nv, 2, k), dtype=np.int32)
-        fb = u32(0)
+        fb = C.c_uint32(0)
         self._ck(LIB.ppgpu_expand_order(self._h, 0, nv, k, _ptr(idx), C.byref(fb)), "ppgpu_expand_order")
         return idx, int(fb.value)
 

@@ -694,6 +694,7 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
                 std::vector<double> child((size_t)kRibbonStride * 4);
                 check(ppgpu_cost_wrapper_edges_host(h, 1, &we, &r, child.data(), kRibbonStride), "ppgpu_cost_wrapper_edges_host");
                 m_Stats.EdgesCosted++;
+                g_dump.write(m_Nodes[lastPlanEnd].state, r, dp.rho, cov);
                 if (r.flags & PPGPU_F_THROWS) throw std::runtime_error("Invalid time in sample for Dubins path (previous plan)");
                 const int nChild = (int)((r.info >> 8) & 0xff);
                 const bool hostHeuristic = (r.flags & PPGPU_F_RIBBON_OVF) && nChild <= kRibbonStride;

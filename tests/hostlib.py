@@ -1,13 +1,13 @@
-"""ctypes binding of the C entry points of path_planner_amd/host/libpp_host.so (src/host_c_api.cpp): the host-side classes
+"""ctypes binding of the C entry points of path_planner_amd/host/libpp_hostcore.so (src/host_c_api.cpp): the host-side classes
 (State, Ribbon, RibbonManager, GridWorldMap, obstacle managers, DubinsWrapper) as the CPU tests see them.  No GPU needed:
-nothing behind these calls touches the device."""
+the library carries no device code and does not load the HIP runtime."""
 import ctypes as C
 import os
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HOST_SO = os.path.join(ROOT, "path_planner_amd", "host", "libpp_host.so")
+HOST_SO = os.path.join(ROOT, "path_planner_amd", "host", "libpp_hostcore.so")
 
 vp, dbl, i32, i64, u32 = C.c_void_p, C.c_double, C.c_int, C.c_long, C.c_uint
 

@@ -1,0 +1,42 @@
+"""-m gpu: tools/fuzz_plan.py inside the suite — whole plan() calls of the C++ host planner against the oracle's planner on random
+worlds (grid, obstacles, ribbons, heuristic, speeds, radii, increment, budget, speculation depth), each followed by a replan that
+hands the first plan back.  Every call must agree in every statistic — samples, iterations, expansions, generated vertices,
+FIRST-GOAL ITERATION, depth — and in cost to 1e-5.  Where another plan of the same cost comes back, the two edge dumps must
+show why (tools/fuzz_plan.py: classify_tie): the searches consume the same edges in the same order with the same feasibility, and
+upstream of the divergence a curve differs in its last digits — the reference's one-sided `distance - 1e-5` retry
+(DubinsWrapper.cpp:39-42) or two Dubins words of exactly equal length — which no device libm can rule out.  A
+difference in the push / pop order itself is a failure."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed,rounds", [(1, 24), (7, 12)])
+def test_random_plan_calls_agree_with_the_oracle_planner(seed, rounds):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_plan
+    import oracle as orc
+    rng = np.random.default_rng(seed)
+    calls, ties, bad = 0, [], []
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            for r in range(rounds):
+                for which, verdict, why in fuzz_plan.one_round(rng, r, d):
+                    calls += 1
+                    if verdict == "MISMATCH":
+                        bad.append((r, which, why))
+                    elif verdict == "tie":
+                        ties.append((r, which, why))
+    finally:
+        orc.O.ppo_set_ribbon_width(1.5)
+    print(f"seed {seed}: {calls} plan() calls, {len(ties)} equal-cost plans explained by the edge dumps: {ties}")
+    assert not bad, bad
+    assert calls >= rounds + rounds // 2
+    assert len(ties) <= calls // 4, ties

@@ -68,6 +68,21 @@ def _run_cli(path):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
+def _same_curve(a, b, n=17):
+    """Two plan segments {qi[3], param[3], rho, type, speed, start, end} trace the same poses (1e-4 m, 1e-4 rad)."""
+    import oracle as orc
+    for u in np.linspace(0.0, 1.0, n):
+        pa = orc.dubins_sample(a[:8], u * (a[10] - a[9]) * a[8] * (1 - 1e-9))
+        pb = orc.dubins_sample(b[:8], u * (b[10] - b[9]) * b[8] * (1 - 1e-9))
+        if pa[0] != 0 or pb[0] != 0:
+            return False
+        d = pa[1] - pb[1]
+        d[2] = (d[2] + np.pi) % (2 * np.pi) - np.pi
+        if np.max(np.abs(d)) > 1e-4:
+            return False
+    return True
+
+
 def _compare(host, st, plan):
     assert "exception" not in host, host
     assert host["samples"] == st.samples
@@ -90,10 +105,17 @@ def _compare(host, st, plan):
         assert np.all(np.abs(hp[1:, 9] - hp[:-1, 10]) < 1e-9)
         # segment by segment: same Dubins word, parameters / times / speed within 1e-5 — including among children of EXACTLY
         # equal f, which std::pop_heap surfaces in an order that depends on the order expand() pushed them in (the device
-        # replays the reference's heap-array order: ppgpu_expand_order)
+        # replays the reference's heap-array order: ppgpu_expand_order).  One thing may differ in name only: a curve with a
+        # zero-length arc is the same curve under two words (RSL / RSR with no final turn ...), their lengths tie exactly, and
+        # which of them `cost < best` keeps hangs on the last bit of libm's atan2; such a segment is
+        # compared as geometry.
         for a, b in zip(hp, plan):
-            assert a[7] == b[7], (hp, plan)
-            assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)) <= 1e-5, (hp, plan)
+            if a[7] == b[7]:
+                assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)) <= 1e-5, (hp, plan)
+            else:
+                assert min(a[3], a[5]) <= 1e-9 and min(b[3], b[5]) <= 1e-9, (hp, plan)
+                assert np.max(np.abs(a[8:] - b[8:]) / np.maximum(np.abs(b[8:]), 1.0)) <= 1e-5, (hp, plan)
+                assert _same_curve(a, b), (hp, plan)
     assert host.get("order_fallbacks", 0) == 0
 
 
@@ -334,15 +356,14 @@ def test_brown_path_seeds_are_costed_and_pushed_like_the_reference():
     placed beside a ribbon so that seeds exist; same statistics and plan as the oracle's planner with the option on, and the
     option must change the search (otherwise the test would pass without the code)."""
     import oracle as orc
-    import hostlib
     from path_planner_amd import workloads
     w = workloads.by_name("cfg2")
     c = float(w.start5[0])
-    w.start5 = np.array([c - 6.0, c + 2.0, 0.3, 2.5, 1.0])
+    w.start5 = np.array([c - 6.0, c + 4.0, 1.57, 2.5, 1.0])
     orc.O.ppo_set_ribbon_width(w.cfg.ribbon_width)
-    hostlib.H.pph_set_ribbon_width(w.cfg.ribbon_width)
-    seeds = hostlib.ribbons_near_states(w.ribbons4, w.start5, w.cfg.coverage_turning_radius)
-    assert len(seeds) >= 1
+    seeds = np.zeros((16, 5))
+    r4 = np.ascontiguousarray(w.ribbons4)
+    assert orc.O.ppo_ribbons_near_states(r4.ctypes.data, len(r4), w.start5.ctypes.data, w.cfg.coverage_turning_radius, seeds.ctypes.data, 16) >= 1
     world = orc.World(w.cfg, w.grid, w.res, w.obst)
     t0, dt, calls, init = 1000.0, 1e-3, 40, 128
     with tempfile.TemporaryDirectory() as d:
@@ -386,19 +407,23 @@ def test_several_device_contexts_give_the_same_plan():
 
 
 def test_children_with_long_ribbon_lists_do_not_abort_the_plan():
-    """TspPointRobotNoSplitAllRibbons on five parallel ribbons with the vehicle about to cross them all: children carry up to ten
-    pieces, more than the device's brute-force enumeration takes (8).  The reference enumerates any length; the host planner
+    """TspPointRobotNoSplitAllRibbons on five parallel ribbons with the vehicle about to cross them all near their ends (open
+    water, so nothing but the ribbons shapes the search): children carry up to ten pieces, more than the device's brute-force
+    enumeration takes (8).  The reference enumerates any length; the host planner
     computes h of those children itself instead of dropping the plan (the oracle's exhaustive recursion cannot finish ten
     ribbons, so the check here is that a plan comes back and that the host path was actually taken; the value itself is
     checked against the oracle at sizes it can do in tests/test_host_cpu.py and test_gpu_parity.py)."""
     from path_planner_amd import workloads
     w = workloads.by_name("cfg3")
     w.cfg.heuristic = 1
+    w.grid = np.zeros_like(w.grid)
+    w.obst = None
+    w.start5 = np.array([float(w.ribbons4[0][0]) + 2.0, float(w.ribbons4[0][1]) - 6.0, 0.0, 2.5, 1.0])
     with tempfile.TemporaryDirectory() as d:
         mp = os.path.join(d, "grid.map")
         _write_map(w.grid, w.res, mp)
         sc = os.path.join(d, "s.txt")
-        _scenario(w, sc, mp, 1000.0, 1e-3, 40, 512)
+        _scenario(w, sc, mp, 1000.0, 1e-3, 300, 256)
         host = _run_cli(sc)
     print({k: host[k] for k in host if k != "plan"})
     assert "exception" not in host, host

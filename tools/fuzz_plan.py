@@ -1,27 +1,47 @@
 #!/usr/bin/env python3
 """GPU box: randomized differential test of whole plan() calls — the C++ host planner (plan_cli, injected clock) against the
 oracle's restatement of AStarPlanner::plan on random worlds: grid, obstacles, ribbons, heuristic, speeds, radii, budget, and
-a second cycle that hands the first plan back (previous-plan re-costing).  Identical samples / iterations / expansions /
-generated / first-goal iteration / depth, costs within 1e-5.  usage: tools/fuzz_plan.py [rounds] [seed]"""
-import os, sys, tempfile, math
+a second cycle that hands the first plan back (previous-plan re-costing).
+
+Verdict per plan() call:
+  ok        identical samples / iterations / expansions / generated / first-goal iteration / depth, costs within 1e-5, the same
+            plan segment by segment;
+  tie       all of the above except that ANOTHER plan of the same cost came back, or that `generated` / `expanded` moved by a few
+            (a vertex pruned against the incumbent on one side only).  Every such case must be explained by the two
+            edge dumps (classify_tie): both searches consume the same number of edges in the same order, no infeasible flag
+            differs, and somewhere upstream the two sides disagree in the last digits of a curve — the reference's own
+            `distance - 1e-5` retry (DubinsWrapper.cpp:39-42) fired on one side only, or two Dubins words of exactly equal length
+            were told apart by the last bit of libm — after which vertices of (near-)equal f pop in another order;
+  MISMATCH  anything else (a failed check is named).
+usage: tools/fuzz_plan.py [rounds] [seed]     (tests/test_gpu_fuzz_plan.py runs the same rounds inside the suite)"""
+import math
+import os
+import subprocess
+import sys
+import tempfile
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from path_planner_amd import workloads
 from path_planner_amd.types import make_config, H_MAX_DISTANCE, H_TSP_POINT_ALL, H_TSP_POINT_K
-from test_gpu_host_planner import _write_map, _scenario, _run_cli, _compare
+from test_gpu_host_planner import _write_map, _scenario, _run_cli, _compare, CLI
 import oracle as orc
 
 
 def judge(host, st, plan):
-    """'ok' / 'tie' (same statistics and cost, another plan among vertices of exactly equal f: DESIGN.md 4.5) / the failed check"""
-    for k, v in (("samples", st.samples), ("iterations", st.iterations), ("expanded", st.expanded), ("generated", st.generated),
-                 ("first_goal_iteration", st.first_goal_iteration)):
+    for k, v in (("samples", st.samples), ("iterations", st.iterations), ("first_goal_iteration", st.first_goal_iteration)):
         if host[k] != v:
             return f"{k}: host {host[k]} oracle {v}"
     rel = lambda a, b: abs(a - b) / max(abs(a), abs(b), 1.0)
     if rel(host["plan_f"], st.plan_f) > 1e-5:
         return f"plan_f: host {host['plan_f']} oracle {st.plan_f}"
+    for k, v in (("expanded", st.expanded), ("generated", st.generated)):
+        if host[k] != v:
+            # a vertex pruned on one side only (`best.f < v.f`, SamplingBasedPlanner.cpp:11) moves these counters by a few; like
+            # another plan of equal cost it has to be explained by the edge dumps
+            return f"tie ({k}: host {host[k]} oracle {v})"
     try:
         _compare(host, st, plan)
         return "ok"
@@ -29,29 +49,45 @@ def judge(host, st, plan):
         return "tie"
 
 
-def diff_edges(w, sc, mp, t0, dt, calls, init, world):
-    """Which costed edges differ?  Host (PPAMD_DUMP_EDGES) and oracle (dump_edges) list every edge they cost; within one
-    expansion the two order siblings differently, so the lists are compared as multisets keyed by source time, word, radius and
-    rounded parameters."""
-    import subprocess
-    from test_gpu_host_planner import CLI
-    _scenario(w, sc, mp, t0, dt, calls, init, speculation=1)
+def edge_dumps(w, sc, mp, t0, dt, calls, init, world, prev=None, start=None):
+    """Every costed edge each search consumes, in consumption order, 16 numbers per edge: source state (5), Dubins parameters
+    (3), word, radius, coverage flag, infeasible, true cost, g, h, end time.  Host: PPAMD_DUMP_EDGES; oracle: dump_edges."""
+    _scenario(w, sc, mp, t0, dt, calls, init, speculation=1, prev=prev, start=start)
     dump = sc + ".edges"
     subprocess.run([CLI, sc], capture_output=True, text=True, timeout=300, env=dict(os.environ, PPAMD_DUMP_EDGES=dump))
     H = np.loadtxt(dump).reshape(-1, 16)
-    rc, st, plan, _, O = world.plan(w.ribbons4, w.start5, calls * dt, t0, dt, initial_samples=init, dump_edges=200000)
-    key = lambda r: (round(r[4], 6), int(r[8]), r[9], int(r[10]), round(r[5], 5), round(r[6], 5), round(r[7], 5))
-    hk, ok_ = {}, {}
-    for r in H: hk.setdefault(key(r), []).append(r)
-    for r in O: ok_.setdefault(key(r), []).append(r)
-    only_h = [k for k in hk if k not in ok_]; only_o = [k for k in ok_ if k not in hk]
-    flips = [k for k in hk if k in ok_ and hk[k][0][11] != ok_[k][0][11]]
-    print(f"      edges costed: host {len(H)} oracle {len(O)}; only host {len(only_h)}, only oracle {len(only_o)}, infeasible flag differs on {len(flips)}", flush=True)
-    for k in (flips[:3] + only_o[:3] + only_h[:3]):
-        print("        ", k, "host", [list(np.round(r[11:16], 9)) for r in hk.get(k, [])][:1], "oracle", [list(np.round(r[11:16], 9)) for r in ok_.get(k, [])][:1], flush=True)
+    rc, st, plan, _, O = world.plan(w.ribbons4, w.start5 if start is None else start, calls * dt, t0, dt, initial_samples=init,
+                                    dump_edges=200000, prev11=prev)
+    return H, O
 
 
-def one_round(rng, rid, d):
+def classify_tie(H, O, same_length=True):
+    """Is a 'tie' verdict one of the two explained kinds?  Returns (True, what) or (False, why not)."""
+    if same_length and len(H) != len(O):
+        return False, f"the searches consume {len(H)} and {len(O)} edges"
+    rel = lambda a, b: np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    word_tie = retry = False
+    for i in range(min(len(H), len(O))):
+        h, o = H[i], O[i]
+        r = rel(h, o)
+        r[8] = 0.0                                          # the word is compared below
+        if np.max(r) > 1e-4:
+            # from here on the two searches expand different (equal-f) vertices: only what came before can explain it
+            break
+        if h[11] != o[11]:
+            return False, f"edge {i}: infeasible flag differs"
+        if h[8] != o[8]:
+            if min(h[5], h[7]) > 1e-9 or min(o[5], o[7]) > 1e-9:
+                return False, f"edge {i}: different Dubins words on a curve without a zero-length arc"
+            word_tie = True
+        elif np.max(r) > 1e-12:
+            retry = True                                    # same edge, last digits differ: a parent's end pose moved by <= 1e-5 m
+    if not (word_tie or retry):
+        return False, "no upstream difference explains the other plan: the push / pop order itself differs"
+    return True, ("equal-length Dubins words" if word_tie else "") + (" + " if word_tie and retry else "") + ("one-sided 1e-5 retry upstream" if retry else "")
+
+
+def make_round(rng, rid):
     size = int(rng.choice([256, 512])); res = float(rng.choice([0.25, 0.5]))
     ext = size * res; c = ext / 2
     grid = np.zeros((size, size), dtype=np.uint8)
@@ -74,65 +110,73 @@ def one_round(rng, rid, d):
     nob = int(rng.integers(0, 12))
     ob = workloads.obstacles(nob, int(rng.integers(1, 1 << 30)), ext, time=1.0, keep_free=(c, c, 10)) if nob else None
     w = workloads.Workload(f"fuzz{rid}", grid, res, ob, rib, [c, c, float(rng.uniform(0, 6.28)), max_speed, 1.0], 0, 7, cfg)
-    orc.O.ppo_set_ribbon_width(cfg.ribbon_width)
-    world = orc.World(cfg, grid, res, ob)
     t0, dt = float(rng.choice([1000.0, 1.6e9])), 1e-3
     calls, init = int(rng.integers(15, 60)), int(rng.choice([64, 256, 512]))
+    spec = int(rng.choice([1, 16, 16]))
+    tag = f"round {rid}: grid {size}@{res} rib {nrib} heur {heur} obst {nob} calls {calls} init {init}"
+    return w, t0, dt, calls, init, spec, tag
+
+
+def one_round(rng, rid, d, verbose=True):
+    """-> list of (which, verdict, explanation) for the first plan() call and, when it returned a plan, the replan."""
+    w, t0, dt, calls, init, spec, tag = make_round(rng, rid)
+    cfg, grid, res, ob = w.cfg, w.grid, w.res, w.obst
+    orc.O.ppo_set_ribbon_width(cfg.ribbon_width)
+    world = orc.World(cfg, grid, res, ob)
     mp = os.path.join(d, "grid.map"); _write_map(grid, res, mp)
     sc = os.path.join(d, "s.txt")
-    _scenario(w, sc, mp, t0, dt, calls, init, speculation=int(rng.choice([1, 16, 16])))
-    host = _run_cli(sc)
-    rc, st, plan, _, _ = world.plan(w.ribbons4, w.start5, calls * dt, t0, dt, initial_samples=init)
-    tag = f"round {rid}: grid {size}@{res} rib {nrib} heur {heur} obst {nob} calls {calls} init {init}"
-    if rc != 0 or "exception" in host:
-        same = (rc != 0) == ("exception" in host)
-        print(tag, "-> both threw" if same else f"-> ONE SIDE THREW (oracle rc {rc}, host {host.get('exception')})", flush=True)
-        return same
-    verdict = judge(host, st, plan)
-    if verdict not in ("ok", "tie"):
-        print(tag, "-> MISMATCH", verdict, {k: host[k] for k in host if k != "plan"}, flush=True)
-        diff_edges(w, sc, mp, t0, dt, calls, init, world)
-        for spec in (1, 4, 16):                       # does the host's own answer depend on how it batches?
-            _scenario(w, sc, mp, t0, dt, calls, init, speculation=spec)
-            h2 = _run_cli(sc)
-            print("      speculation", spec, {k: h2[k] for k in ("samples", "iterations", "expanded", "generated", "first_goal_iteration", "plan_f")}, flush=True)
-        return False
-    ok2 = True
-    if len(plan):
+    say = (lambda *a: print(*a, flush=True)) if verbose else (lambda *a: None)
+    out = []
+
+    def run(which, t_start, prev, start):
+        _scenario(w, sc, mp, t_start, dt, calls, init, speculation=spec, prev=prev, start=start)
+        host = _run_cli(sc)
+        rc, st, plan, _, _ = world.plan(w.ribbons4, w.start5 if start is None else start, calls * dt, t_start, dt, initial_samples=init, prev11=prev)
+        if rc != 0 or "exception" in host:
+            same = (rc != 0) == ("exception" in host)
+            out.append((which, "both threw" if same else "MISMATCH", "" if same else f"one side threw (oracle rc {rc}, host {host.get('exception')})"))
+            return host, st, None
+        v = judge(host, st, plan)
+        why = ""
+        if v.startswith("tie"):
+            counts = v[3:].strip()
+            ok, why = classify_tie(*edge_dumps(w, sc, mp, t_start, dt, calls, init, world, prev=prev, start=start), same_length=not counts)
+            why = (counts + " " + why).strip()
+            v = "tie" if ok else "MISMATCH"
+        elif v != "ok":
+            why, v = v, "MISMATCH"
+        out.append((which, v, why))
+        return host, st, plan
+
+    host, st, plan = run("plan", t0, None, None)
+    if plan is not None and out[-1][1] in ("ok", "tie") and len(plan):
         seg = plan[0]
         e, q = orc.dubins_sample(seg[:8], min(1.0 * seg[8], (seg[10] - seg[9]) * seg[8]))
         hdg = math.pi / 2 - q[2]
         hdg += 2 * math.pi if hdg < 0 else 0
         start2 = np.array([q[0], q[1], hdg, seg[8], seg[9] + 1.0])
         if start2[4] < plan[-1][10] - 1e-6:
-            sc2 = os.path.join(d, "s2.txt")
-            _scenario(w, sc2, mp, t0 + 1.0, dt, calls, init, prev=plan, start=start2)
-            host2 = _run_cli(sc2)
             cfg.start_state_time = float(start2[4]); world.set_config(cfg)
-            rc2, st2, plan2, _, _ = world.plan(w.ribbons4, start2, calls * dt, t0 + 1.0, dt, initial_samples=init, prev11=plan)
-            if rc2 != 0 or "exception" in host2:
-                ok2 = (rc2 != 0) == ("exception" in host2)
-                print("    replan:", "both threw" if ok2 else f"ONE SIDE THREW (oracle rc {rc2}, host {host2.get('exception')})", flush=True)
-            else:
-                v2 = judge(host2, st2, plan2)
-                if v2 not in ("ok", "tie"):
-                    ok2 = False
-                    print("    replan MISMATCH", v2, {k: host2[k] for k in host2 if k != "plan"}, flush=True)
-                elif v2 == "tie":
-                    print("    replan: equal-cost plan among f ties", flush=True)
-    print(tag, "-> " + ("ok" if verdict == "ok" else "equal-cost plan among f ties"), "expanded", host["expanded"], "first goal", host["first_goal_iteration"], "f %.4f" % host["plan_f"], flush=True)
-    return ok2
+            run("replan", t0 + 1.0, plan, start2)
+            cfg.start_state_time = 1.0
+    for which, v, why in out:
+        say(tag if which == "plan" else "    replan", "->", v, ("(" + why + ")") if why else "",
+            ("expanded %d first goal %d f %.4f" % (host["expanded"], host["first_goal_iteration"], host["plan_f"])) if which == "plan" and "expanded" in host else "")
+    return out
 
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    bad = 0
+    bad = ties = calls = 0
     with tempfile.TemporaryDirectory() as d:
         for r in range(rounds):
-            bad += 0 if one_round(rng, r, d) else 1
+            for which, v, why in one_round(rng, r, d):
+                calls += 1
+                bad += v == "MISMATCH"
+                ties += v == "tie"
     orc.O.ppo_set_ribbon_width(1.5)
-    print(f"{rounds} rounds, {bad} with mismatches")
+    print(f"{rounds} rounds, {calls} plan() calls: {bad} mismatches, {ties} equal-cost plans explained by the edge dumps")
     sys.exit(1 if bad else 0)
 
 
