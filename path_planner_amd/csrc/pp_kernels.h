@@ -37,6 +37,7 @@ struct PPParams {
     double* track_pen;                   // Gaussian model only: [edge][ngp] collisionExists(step k) ...
     double* track_chunk_pen;             // ... and [edge][nch] its sum times the penalty factor over the chunk's executable steps
     struct PPTrackSummary* track_summary;
+    int2* track_far;                     // [edge] {first event the cover sweep's wave has to visit, last event before it} (pp_k_approach_events)
     unsigned long long* work;            // work-queue heads of the per-edge kernels (PP_Q_*), zeroed by pp_k_solve_edges
     unsigned* need_big;                  // set by the cover sweep when some child has 9..12 ribbons (pp_k_heuristic_big then has work)
     int ngp, nch;                        // steps per edge rounded up to whole 64-step chunks, and that many chunks
@@ -636,6 +637,95 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
     if (lane == 0) { sum->limit = limit; sum->blocked = blocked; sum->dub_err = anyErr; sum->pad = 0; }
 }
 
+// How many steps pass before the next coverage event: the loop of Edge.cpp:153-154 subtracts the increment from toCoverDistance
+// once per step while it is above the increment, so after an event that measured D the next one is m + 1 steps on, m = the
+// number of subtractions.  m is guessed as ceil(D / inc - 1) and accepted when the remainder is clearly inside (0, inc); within
+// 1e-12 of a boundary the subtraction runs literally.
+__device__ __forceinline__ int pp_event_stride(double D, double inc_d, double inv_inc_d, int ng) {
+    int m = 0;
+    if (D > inc_d) {
+        const double qd = D * inv_inc_d;                   // a guess good to an ulp or two; m0 is verified below
+        if (qd > (double)(ng + 2)) {
+            m = ng + 1;                                    // beyond the grid: never again
+        } else {
+            const int m0 = (int)ceil(qd - 1.0);
+            const double r = fma(-(double)m0, inc_d, D);   // D - m0*inc, one rounding
+            const double margin = (double)m0 * D * 5e-16 + 1e-12;
+            if (m0 >= 1 && r > margin && r < inc_d - margin) {
+                m = m0;                                    // the running subtraction cannot differ
+            } else {
+                double tc = D;                             // too close to call: do it the long way
+                while (tc > inc_d && m <= ng) { tc -= inc_d; m++; }
+            }
+        }
+    }
+    return m;
+}
+
+// The approach to the ribbons, one LANE per edge.  Until the vehicle first comes within reach of a ribbon (inside some
+// ribbon's bounding box grown by the ribbon width: the test of pp_ribbons_event's fast path) a coverage event changes nothing
+// and only yields the index of the next one, from the distance to the nearest ribbon endpoint.  That chain is sequential per
+// edge but independent across edges; walked by the edge's own wavefront it costs a 64-lane window of poses per event to use one
+// pose (2.5 of the 3.85 one-at-a-time events per edge at config 3).  Here 64 edges walk their chains side by side — pose,
+// boxes and distance per lane with the expressions of pp_window_pose / pp_ribbons_event, so every number is the one the
+// wavefront would have computed — and each hands over {next event, last event visited} where its chain meets a ribbon, runs
+// past the sweep's limit or end time, or passes the point from which the curve stays clear of all ribbons (PPEdgeSetup::tfar).
+// The cover sweep starts its state machine there instead of at step 0.
+__global__ __launch_bounds__(256) void pp_k_approach_events(PPParams p) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.n_edges) return;
+    const PPEdgeSetup* S = p.setup + p.ws_base + e;
+    int2 out; out.x = 0; out.y = -1;
+    const unsigned sflags = S->sflags;
+    const int dubType = S->type;
+    if (!(sflags & (PP_SETUP_MALFORMED | PP_SETUP_COLOCATED)) && dubType >= 0) {
+        const ppgpu_vertex* V = p.verts + S->vi;
+        const int nrib = V->ribbon_count;
+        const int limit = p.track_summary[p.ws_base + e].limit;
+        if (nrib > 0 && nrib <= PP_WAVE && limit > 0) {
+            const double* rp = p.ribbons + 4 * (size_t)V->ribbon_offset;
+            const double* tg = p.tgrid + (size_t)S->vi * p.ng;
+            const double wStart = S->wStart, speed = S->speed, length = S->length, rho = S->rho, rho_inv = S->rho_inv, qx = S->qx, qy = S->qy;
+            const double tfar = S->tfar, hi0 = S->seg[0].hi, hi1 = S->seg[1].hi;
+            const double endTime0 = fmin(p.horizon + 1e-12 + p.sst, S->wEnd);
+            const double w = p.ribw, grow = w + 1e-3, minLength0 = 2 * w;
+            bool tiny = false;
+            for (int i = 0; i < nrib; i++) tiny |= pp_sq_len(rp[4 * i], rp[4 * i + 1], rp[4 * i + 2], rp[4 * i + 3]) < minLength0 * minLength0 / (2.0 * 2.0);
+            int k = 0, lastEv = -1;
+            // a piece short enough to be erased makes every event a real one (Ribbon::covered is checked wherever the vehicle is)
+            while (!tiny) {
+                if (k >= limit) break;
+                const double t = tg[k];
+                if (!(t < endTime0)) break;
+                if ((t - wStart) * speed / rho > tfar) { k = 0x3fffffff; break; }       // the rest of the curve is clear: no event is visited
+                double dist = (t - wStart) * speed;                                     // DubinsWrapper.cpp:36
+                if (dist < 0 || dist > length) dist = dist - 1e-5;                      // EDUBPARAM retry, :39-42
+                if (dist < 0 || dist > length) break;                                   // the wavefront's code flags the error
+                const double tprime = (rho_inv != 0.0) ? dist * rho_inv : dist / rho;
+                const PPSeg* g = &S->seg[pp_seg_of(tprime, hi0, hi1)];
+                double ux, uy, uth;
+                pp_curve_seg(g->type, (tprime - g->o1) - g->o2, g->bx, g->by, g->bth, g->sb, g->cb, ux, uy, uth);
+                const double x = ux * rho + qx, y = uy * rho + qy;
+                bool inBox = false;
+                double q = PP_DBL_MAX;
+                for (int i = 0; i < nrib; i++) {
+                    const double sx = rp[4 * i], sy = rp[4 * i + 1], ex = rp[4 * i + 2], ey = rp[4 * i + 3];
+                    inBox |= (x >= fmin(sx, ex) - grow) & (x <= fmax(sx, ex) + grow) & (y >= fmin(sy, ey) - grow) & (y <= fmax(sy, ey) + grow);
+                    const double qS = (sx - x) * (sx - x) + (sy - y) * (sy - y);
+                    const double qE = (ex - x) * (ex - x) + (ey - y) * (ey - y);
+                    q = fmin(q, fmin(qE, qS));
+                }
+                if (inBox) break;                                                       // within reach of a ribbon: the wavefront takes over here
+                const double D = fmin(PP_DBL_MAX, sqrt(q));
+                lastEv = k;
+                k = k + pp_event_stride(D, p.inc_d, p.inv_inc_d, p.ng) + 1;
+            }
+            out.x = k; out.y = lastEv;
+        }
+    }
+    p.track_far[p.ws_base + e] = out;
+}
+
 // e = the edge's slot in the workspace, eg = its position in the caller's edge list, lds = 256 doubles private to the wave
 #ifndef PP_FUSE_HEUR
 #define PP_FUSE_HEUR 1
@@ -702,6 +792,12 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
     int rdt = -1;                       // `auto ribbonsDoneTime = -1;` is an int (Edge.cpp:92)
     int nextEvent = 0;                  // toCoverDistance starts at 0: step 0 is an event
     int lastEv = -1;
+#ifndef PP_NO_APPROACH
+    if (p.track_far) {                  // the approach was walked by pp_k_approach_events: start where it handed over
+        nextEvent = pp_const_i32(&p.track_far[e].x)[0];
+        lastEv = pp_const_i32(&p.track_far[e].y)[0];
+    }
+#endif
     const double w = p.ribw;
     const double inc_d = p.inc_d;
     const double runSpan = 64.0 * (p.inc_d / p.max_speed) * speed * (1.0 + 1e-9) + 1e-6;   // how far 64 steps can take the vehicle
@@ -833,23 +929,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                 dbgEvents++;
 #endif
                 // steps until toCoverDistance <= increment again (:153-154): m subtractions
-                int m = 0;
-                if (D > inc_d) {
-                    const double qd = D * p.inv_inc_d;                 // a guess good to an ulp or two; m0 is verified below
-                    if (qd > (double)(p.ng + 2)) {
-                        m = p.ng + 1;                                  // beyond the grid: never again
-                    } else {
-                        const int m0 = (int)ceil(qd - 1.0);
-                        const double r = fma(-(double)m0, inc_d, D);   // D - m0*inc, one rounding
-                        const double margin = (double)m0 * D * 5e-16 + 1e-12;
-                        if (m0 >= 1 && r > margin && r < inc_d - margin) {
-                            m = m0;                                    // the running subtraction cannot differ
-                        } else {
-                            double tc = D;                             // too close to call: do it the long way
-                            while (tc > inc_d && m <= p.ng) { tc -= inc_d; m++; }
-                        }
-                    }
-                }
+                const int m = pp_event_stride(D, inc_d, p.inv_inc_d, p.ng);
                 nextEvent = base + j + m + 1;
             }
         }

@@ -95,6 +95,7 @@ struct ppgpu_ctx {
     DevBuf<unsigned long long> track_eq;
     DevBuf<unsigned> track_chunk_hits;
     DevBuf<PPTrackSummary> track_summary;
+    DevBuf<int2> track_far;
     DevBuf<unsigned> need_big;
     DevBuf<unsigned long long> work;    // queue heads of the resident per-edge grids (PP_Q_*)
     int n_cu = 0;
@@ -161,7 +162,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->ord_key.release(); c->ord_val.release(); c->ord_idx.release(); c->ord_fallbacks.release();
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     c->setup.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
-    c->track_summary.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->work.release(); c->dstage_in.release(); c->dstage_out.release();
+    c->track_summary.release(); c->track_far.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->work.release(); c->dstage_in.release(); c->dstage_out.release();
     if (c->stage_in) (void)hipHostFree(c->stage_in);
     if (c->stage_out) (void)hipHostFree(c->stage_out);
     for (int i = 0; i < 5; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -688,14 +689,14 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
             (rc = c->track_hits.reserve(ws * p.ngp, false, c->stream)) ||
             (rc = c->track_eq.reserve(ws * p.nch, false, c->stream)) ||
             (rc = c->track_chunk_hits.reserve(ws * p.nch, false, c->stream)) ||
-            (rc = c->track_summary.reserve(ws, false, c->stream)))
+            (rc = c->track_summary.reserve(ws, false, c->stream)) || (rc = c->track_far.reserve(ws, false, c->stream)))
             return rc;
         if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN &&
             ((rc = c->track_pen.reserve(ws * p.ngp, false, c->stream)) || (rc = c->track_chunk_pen.reserve(ws * p.nch, false, c->stream))))
             return rc;
     }
     p.setup = c->setup.p; p.track_hits = c->track_hits.p; p.track_eq = c->track_eq.p;
-    p.track_chunk_hits = c->track_chunk_hits.p; p.track_summary = c->track_summary.p;
+    p.track_chunk_hits = c->track_chunk_hits.p; p.track_summary = c->track_summary.p; p.track_far = c->track_far.p;
     p.track_pen = c->track_pen.p; p.track_chunk_pen = c->track_chunk_pen.p;
     {
         int rc = c->need_big.reserve(1, false, c->stream);
@@ -717,6 +718,7 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         else
             hipLaunchKernelGGL(pp_k_pose_sweep, dim3(resident_grid(c, 1, pp_k_pose_sweep, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+        hipLaunchKernelGGL(pp_k_approach_events, dim3((unsigned)((p.n_edges + 255) / 256)), dim3(256), 0, c->stream, p);   // timed with the cover sweep
         if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN)
             hipLaunchKernelGGL(pp_k_cover_sweep_gaussian, dim3(resident_grid(c, 2, pp_k_cover_sweep_gaussian, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
         else
