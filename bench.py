@@ -32,6 +32,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=65536, help="sample attempts per GPU per step")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: SURVEY config 4 — ONE iteration batch of --total attempts split over the ranks "
+                         "(262 144 over 8 GPUs = 32 768 each) instead of --batch attempts per GPU")
+    ap.add_argument("--total", type=int, default=262144, help="sample attempts per step over all GPUs with --strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--open-vertex-run", action="store_true",
                     help="also time the 64-open-vertex x 4096-sample launch of SURVEY config 3 (extra launches: not in profiled runs)")
@@ -54,7 +58,10 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     w = workloads.config3()
-    B = args.batch
+    B = args.batch                                  # attempts per GPU per step (weak scaling: the default)
+    total_attempts = args.total if args.strong else B * world
+    if args.strong:
+        B = -(-total_attempts // world)             # the largest shard
     ctx = api.Context(local)
     stream = torch.cuda.Stream(dev)          # a real (non-null) stream shared by the kernels, torch events and RCCL
     torch.cuda.set_stream(stream)
@@ -73,7 +80,7 @@ def main():
 
     def step(timed):
         ctx.sampler_init(w.bounds6, w.seed, w.ribbons4)
-        lo, hi = sharding.shard_attempts(B * world, rank, world)   # this rank's slice of the iteration's batch
+        lo, hi = sharding.shard_attempts(total_attempts, rank, world)   # this rank's slice of the iteration's batch
         if lo:
             ctx.sampler_skip(lo)
         n = ctx.sampler_add(hi - lo)
@@ -140,6 +147,10 @@ def main():
         if os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
+                # the counters were collected in separate rocprofv3 --pmc passes (tools/traffic.sh) over a particular build of the
+                # kernels: they describe THIS run only if the kernel sources are still the ones they were measured on
+                if tj.get("kernel_sources_sha256") != kernel_sources_sha256():
+                    raise ValueError("profiles/traffic.json was measured on other kernel sources")
                 traffic = tj.get("hbm_bytes_per_launch")
                 # "achieved HBM GB/s on the collision sweep against the chip's peak" (BASELINE north_star): counter bytes of the
                 # pose sweep (collision checks) over its live kernel time.  Low is good here: the sweep is ALU-bound.
@@ -159,15 +170,20 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * t / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": w.name, "grid": "2048x2048 @0.1m, 10% blocked", "samples_per_iter_per_gpu": B,
-                       "dynamic_obstacles": M, "ribbons": R, "heuristic": "TspPointRobotNoSplitKRibbons K=2",
+            "config": {"workload": (f"cfg4_2048_10pct_{total_attempts}_obst{M}_over_{world}gpus" if args.strong else w.name),
+                       "grid": "2048x2048 @0.1m, 10% blocked", "samples_per_iter_per_gpu": B, "samples_per_iter_total": total_attempts,
+                       "dynamic_obstacles": M, "obstacle_placement": "uniform in the map (SURVEY 8d), seed 3",
+                       "ribbons": R, "heuristic": "TspPointRobotNoSplitKRibbons K=2",
                        "edges_per_iter_per_gpu": n_edges_launch, "sharding": "sample batch split by rank, 1 all-gather/iter"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "pp_k_cover_sweep", "kernel_ms": kern_ms,
+                         "achieved_is": "algorithmic bytes per edge (model, SURVEY 8d) x edges / the kernel's time measured live with HIP events",
+                         "traffic": traffic, "traffic_is": ("PMC bytes per launch from profiles/traffic.json, measured on these kernel sources"
+                                                            if traffic is not None else "null: no PMC pass on these kernel sources (tools/traffic.sh)"),
+                         "kernel": "pp_k_cover_sweep", "kernel_ms": kern_ms,
                          "kernels_ms": {"pp_k_solve_edges": solve_ms, "pp_k_pose_sweep": pose_ms, "pp_k_cover_sweep": cover_ms,
                                         "pp_k_heuristic": heur_ms},
                          "kernels_note": "pp_k_cover_sweep includes the edges' heuristic (same wavefront, PP_FUSE_HEUR); "
@@ -190,6 +206,15 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def kernel_sources_sha256():
+    """Identity of the kernel sources a PMC measurement belongs to (profiles/traffic.json carries the same stamp)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("ppgpu.hip", "pp_kernels.h", "pp_device.h", "pp_sampler.h"):
+        h.update(open(os.path.join(ROOT, "path_planner_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 
 def open_vertex_run(ctx, w, torch, dev):
@@ -250,11 +275,34 @@ def cpu_baseline_and_parity(ctx, w, gpu_res):
     cpu = world.cost_edges(w.root(), w.ribbons4, samples[:, 0], samples[:, 1], samples[:, 2], edges_for(n_multi), threads=cores)
     tm = time.perf_counter() - t0
     rep = compare_results(gpu_res[: 4 * n_multi], cpu)
+    # the reference's catkin build sets no optimisation level (pp/CMakeLists.txt:4-6): the same port built -O0, one thread
+    o0 = None
+    try:
+        import subprocess
+        lib0 = os.path.join(ROOT, "oracle", "libpp_oracle_O0.so")
+        if not os.path.exists(lib0):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "O0"])
+        n0 = min(len(samples), 512)
+        code = ("import sys,time,os,json;sys.path.insert(0,%r);sys.path.insert(0,%r);os.environ['PP_ORACLE_SO']=%r;"
+                "import numpy as np,oracle as orc;from path_planner_amd import workloads;from path_planner_amd.types import edge_pack;"
+                "w=workloads.config3();world=orc.World(w.cfg,w.grid,w.res,w.obst);s=np.load(sys.argv[1]);n=%d;ne=4*n;"
+                "e=edge_pack(np.zeros(ne,dtype=np.uint64),np.repeat(np.arange(n),4),np.tile(np.arange(4),n));t=time.perf_counter();"
+                "world.cost_edges(w.root(),w.ribbons4,s[:,0],s[:,1],s[:,2],e,threads=1);print(json.dumps(ne/(time.perf_counter()-t)))"
+                % (ROOT, os.path.join(ROOT, "tests"), lib0, n0))
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix=".npy") as f:
+            np.save(f.name, samples)
+            o0 = float(subprocess.check_output([sys.executable, "-c", code, f.name], timeout=120).decode().strip().splitlines()[-1])
+    except Exception:
+        o0 = None
     return {
         "cpu_baseline": {"value": 4 * n_multi / tm, "unit": "edges/s", "cores": cores, "kind": "port",
                          "sample": f"first {4 * n_multi} edges of the same launch, static chunks over {cores} threads; "
                                    f"single thread on the first {4 * n_single} edges: {4 * n_single / t1:.1f} edges/s",
-                         "single_thread_value": 4 * n_single / t1},
+                         "single_thread_value": 4 * n_single / t1,
+                         "single_thread_value_O0": o0,
+                         "note": "kind 'port': the oracle's restatement built -O2 (the figures above); single_thread_value_O0 is the same code "
+                                 "built -O0, the reference's default build type, on the first 2048 edges"},
         "parity": {"ok": rep["ok"], "edges_checked": rep["n"], "flags_equal": rep["flags_equal"], "worst_rel": rep["worst_rel"]},
     }
 
@@ -271,10 +319,14 @@ def first_goal_check():
         from test_gpu_host_planner import CLI, _run_cli, _scenario, _write_map
         if not os.path.exists(CLI):
             return {"first_goal": None}
-        w2 = workloads.by_name("cfg2")
+        # config 2's world with fine clutter (tools/find_late_goal.py): the first goal only appears after several doublings of the
+        # sample set, so the index is not trivially 0
+        from test_gpu_host_planner import LATE_GOALS, _late_goal_workload
+        name, frac, gseed, blob, init, _ = LATE_GOALS[0]
+        w2 = _late_goal_workload(name, frac, gseed, blob)
         orc.O.ppo_set_ribbon_width(w2.cfg.ribbon_width)
         world = orc.World(w2.cfg, w2.grid, w2.res, w2.obst)
-        t0, dt, calls, init = 1000.0, 1e-3, 40, 256
+        t0, dt, calls = 1000.0, 1e-3, 400
         with tempfile.TemporaryDirectory() as d:
             mp = os.path.join(d, "grid.map")
             _write_map(w2.grid, w2.res, mp)
@@ -282,7 +334,8 @@ def first_goal_check():
             _scenario(w2, sc, mp, t0, dt, calls, init)
             host = _run_cli(sc)
         rc, st, plan, _, _ = world.plan(w2.ribbons4, w2.start5, calls * dt, t0, dt, initial_samples=init)
-        return {"first_goal": {"workload": w2.name, "seed": "fixed by the injected clock", "iteration_gpu": host["first_goal_iteration"],
+        return {"first_goal": {"workload": w2.name + f" with {int(100 * frac)} % clutter (grid seed {gseed}, {blob}-cell blobs), {init} initial samples",
+                               "seed": "fixed by the injected clock", "iteration_gpu": host["first_goal_iteration"],
                                "iteration_cpu_oracle": int(st.first_goal_iteration), "plan_f_gpu": host["plan_f"], "plan_f_cpu_oracle": float(st.plan_f),
                                "identical_index": host["first_goal_iteration"] == int(st.first_goal_iteration),
                                "plan_f_rel_diff": abs(host["plan_f"] - float(st.plan_f)) / max(1.0, abs(float(st.plan_f)))}}

@@ -165,7 +165,7 @@ int ppgpu_set_stream(ppgpu_ctx* ctx, void* hip_stream);
 int ppgpu_synchronize(ppgpu_ctx* ctx);
 /* Measurement aid: with timing on, every costing launch records HIP events on the handle's stream between its four
  * kernels (curve solve, pose sweep, cover sweep, heuristic); ppgpu_last_timing waits for the last launch and returns their
- * durations in milliseconds.  For a launch that ran as several workspace slices the first three are the last slice's.
+ * durations in milliseconds.  For a launch that ran as several workspace slices the first three are summed over the slices.
  * With the point heuristics and the binary obstacle model the cover sweep's wavefront computes the edge's heuristic itself:
  * ms_cover then covers both and ms_heuristic only the separate pass over child lists of 9 to 12 ribbons.
  * The events cost a few microseconds per launch: leave timing off in production. */

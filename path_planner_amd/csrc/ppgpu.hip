@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -105,6 +106,7 @@ struct ppgpu_ctx {
     bool timing = false;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
+    double ms_earlier_slices[3] = {0, 0, 0};   // solve / pose / cover time of the slices before the last one of a sliced launch
     int max_vertex_ribbons = 0;
     DevBuf<int> tmp_idx;
     DevBuf<double> ord_key;             // pp_k_expand_order: candidate scratch beyond what LDS holds, push-order output, fallback counter
@@ -194,7 +196,8 @@ int ppgpu_last_timing(ppgpu_ctx* c, double* ms_solve, double* ms_pose, double* m
     HIP_TRY(hipEventSynchronize(c->ev[4]));
     float t[4] = {0, 0, 0, 0};
     for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&t[i], c->ev[i], c->ev[i + 1]));
-    *ms_solve = t[0]; *ms_pose = t[1]; *ms_cover = t[2]; *ms_heuristic = t[3];
+    *ms_solve = t[0] + c->ms_earlier_slices[0]; *ms_pose = t[1] + c->ms_earlier_slices[1]; *ms_cover = t[2] + c->ms_earlier_slices[2];
+    *ms_heuristic = t[3];
     return PPGPU_OK;
 }
 
@@ -708,8 +711,19 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     const bool dubinsH = p.heuristic == PPGPU_H_TSP_DUBINS_ALL || p.heuristic == PPGPU_H_TSP_DUBINS_K;
     const bool gaussianSweep = p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN;
     p.fuse_h = (PP_FUSE_HEUR && !dubinsH && !gaussianSweep) ? 1 : 0;
+    c->ms_earlier_slices[0] = c->ms_earlier_slices[1] = c->ms_earlier_slices[2] = 0;
     for (long long e0 = 0; e0 < total; e0 += slice) {
         p.e_base = e0; p.ws_base = 0; p.n_edges = (total - e0 < slice) ? (total - e0) : slice;
+        if (c->timing && e0 > 0) {
+            // a sliced launch re-uses the events: bank the previous slice's three durations first (timing is a measurement aid: the
+            // wait costs the overlap between slices, nothing else)
+            HIP_TRY(hipEventSynchronize(c->ev[3]));
+            for (int i = 0; i < 3; i++) {
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+                c->ms_earlier_slices[i] += ms;
+            }
+        }
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(pp_k_solve_edges, dim3((unsigned)((p.n_edges + 255) / 256)), dim3(256), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -1041,17 +1055,22 @@ extern "C" int ppgpu_allreduce_best(ppgpu_ctx* c, void* comm, uint64_t* d_key2) 
     HIP_TRY(hipSetDevice(c->device));
     typedef int (*allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
     typedef int (*count_t)(void*, int*);
-    static void* lib = nullptr;
-    static allgather_t allgather = nullptr;
-    static count_t count = nullptr;
-    if (!lib) {
-        lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // resolved once, published only when complete (contexts may live on several threads)
+    struct Rccl { allgather_t allgather = nullptr; count_t count = nullptr; std::string error; };
+    static Rccl rccl;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!lib) return fail(PPGPU_ERCCL, std::string("cannot load librccl.so: ") + dlerror());
-        allgather = (allgather_t)dlsym(lib, "ncclAllGather");
-        count = (count_t)dlsym(lib, "ncclCommCount");
-        if (!allgather || !count) return fail(PPGPU_ERCCL, "librccl.so lacks ncclAllGather/ncclCommCount");
-    }
+        if (!lib) { rccl.error = std::string("cannot load librccl.so: ") + dlerror(); return; }
+        allgather_t ag = (allgather_t)dlsym(lib, "ncclAllGather");
+        count_t cn = (count_t)dlsym(lib, "ncclCommCount");
+        if (!ag || !cn) { rccl.error = "librccl.so lacks ncclAllGather/ncclCommCount"; return; }
+        rccl.allgather = ag; rccl.count = cn;
+    });
+    if (!rccl.allgather || !rccl.count) return fail(PPGPU_ERCCL, rccl.error);
+    const allgather_t allgather = rccl.allgather;
+    const count_t count = rccl.count;
     int world = 0;
     if (count(comm, &world) != 0 || world <= 0) return fail(PPGPU_ERCCL, "ncclCommCount failed");
     int rc = c->gather.reserve((size_t)world * 2, false, c->stream);

@@ -28,7 +28,7 @@ def _build():
 
 
 _build()
-O = C.CDLL(ORACLE_SO)
+O = C.CDLL(os.environ.get("PP_ORACLE_SO", ORACLE_SO))     # PP_ORACLE_SO: another build of the same sources (bench.py times an -O0 one)
 
 
 class PlanStats(C.Structure):

@@ -573,6 +573,60 @@ def test_long_child_ribbon_list_gets_its_heuristic_on_the_host(torch_cuda):
     assert abs(h_host - cpu["h"][0]) <= 1e-9 * max(1.0, cpu["h"][0]), (h_host, cpu["h"][0])
 
 
+def test_config4_eight_shards_walked_on_one_device(torch_cuda):
+    """SURVEY config 4 as far as one GPU allows: ONE iteration batch of 262 144 sample attempts, costed (a) in one piece and (b) as
+    the eight shards an 8-GPU node would take — every rank skips the attempts of the lower ranks (ppgpu_sampler_skip), draws and
+    costs its own 32 768, reduces its best key with its own edge-index base — walked one after the other on this device.  The
+    union of the shards' records must be the unsharded launch bit for bit, and the lexicographic min of the eight keys
+    (ppgpu_key_min: what follows the 16-byte all-gather) must name the same edge with the same f as the unsharded reduction."""
+    from path_planner_amd import api, workloads, sharding
+    from path_planner_amd.types import RESULT_DTYPE
+    torch = torch_cuda
+    w = workloads.config3()
+    total, world = 262144, 8
+    ctx = api.Context(0)
+    ctx.set_config(w.cfg)
+    ctx.set_grid(w.grid, w.res)
+    ctx.set_obstacles(w.obst)
+    ctx.set_vertices(w.root(), w.ribbons4)
+
+    def cost(lo, hi, base):
+        ctx.sampler_init(w.bounds6, w.seed, w.ribbons4)
+        if lo:
+            ctx.sampler_skip(lo)
+        n = ctx.sampler_add(hi - lo)
+        d_res = torch.zeros(4 * n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
+        d_key = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+        torch.cuda.synchronize()
+        ctx.cost_edges_dense(0, 1, 0, n, 0xF, d_res.data_ptr())
+        ctx.best_edge(4 * n, d_res.data_ptr(), d_key.data_ptr(), goal_only=False, base=base)
+        ctx.synchronize()
+        return n, d_res.cpu().numpy(), d_key.cpu().numpy().view(np.uint64).copy(), ctx.get_samples()
+
+    n_all, rec_all, key_all, samples_all = cost(0, total, 0)
+    max_edges = 4 * (total // world)
+    shard_recs, keys, kept, shard_samples = [], [], [], []
+    for r in range(world):
+        lo, hi = sharding.shard_attempts(total, r, world)
+        assert hi - lo == total // world
+        n, rec, key, smp = cost(lo, hi, sharding.edge_index_base(r, max_edges))
+        shard_recs.append(rec); keys.append(key); kept.append(n); shard_samples.append(smp)
+    assert sum(kept) == n_all
+    assert np.array_equal(np.concatenate(shard_samples), samples_all)              # the union of the shards IS the unsharded stream
+    assert np.array_equal(np.concatenate(shard_recs), rec_all)                     # ... and so are the costed edges, byte for byte
+    d_keys = torch.from_numpy(np.concatenate(keys).view(np.int64)).to("cuda:0")
+    d_out = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    ctx.key_min(world, d_keys.data_ptr(), d_out.data_ptr())
+    ctx.synchronize()
+    best = d_out.cpu().numpy().view(np.uint64)
+    assert best.tolist() == sharding.combine_keys(np.array(keys)).tolist()
+    rank, local = int(best[1]) // max_edges, int(best[1]) % max_edges
+    assert best[0] == key_all[0] and 4 * sum(kept[:rank]) + local == int(key_all[1])
+    f_all = rec_all.view(RESULT_DTYPE)["f"]
+    assert f_all[int(key_all[1])].view(np.uint64) == key_all[0]
+
+
 def test_allreduce_best_on_a_one_rank_communicator(torch_cuda):
     """ppgpu_allreduce_best loads librccl at run time and does ONE collective (all-gather of 16 bytes per rank) followed by
     the lexicographic min.  A 1-GPU box can only form a 1-rank communicator: that still exercises the dlopen, the NCCL-ABI
