@@ -373,7 +373,12 @@ struct PPGrid {
     const uint32_t* bits;  // rows x words_per_row, bit (c & 31) of word c >> 5; NULL with rows == 0: base Map
     int rows, cols, wpr;
     double res, inv_res;
+    // clearance[r * cols + c] = min(PP_CLEAR_CAP, chessboard distance in cells from cell (r, c) to the nearest cell that is blocked
+    // or outside the grid); 0 for a blocked cell.  Built on the device when the grid is set (pp_k_grid_row_clear / pp_k_grid_clear);
+    // lets the pose sweep skip whole chunks of steps that cannot touch a blocked cell.  NULL: no skipping.
+    const unsigned char* clearance;
 };
+#define PP_CLEAR_CAP 64
 // GridWorldMap::isBlocked (path_planner/src/common/map/GridWorldMap.cpp:84-93); Map::isBlocked (Map.cpp:4-6).
 // The cell index is size_t(x / res): the quotient is first taken as x * (1/res) and the exact division is done only
 // where that product is within 1e-9 of an integer (relative), i.e. where the division's rounding could matter.

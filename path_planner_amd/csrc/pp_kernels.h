@@ -37,6 +37,8 @@ struct PPParams {
     double* track_pen;                   // Gaussian model only: [edge][ngp] collisionExists(step k) ...
     double* track_chunk_pen;             // ... and [edge][nch] its sum times the penalty factor over the chunk's executable steps
     struct PPTrackSummary* track_summary;
+    unsigned char* track_skip;           // [edge][nch]  1: the pose sweep skips this 64-step chunk (pp_k_plan_skips); NULL: no skipping
+    double* track_carry;                 // [edge][nch]  heading of the step before the chunk, for edges that may not cover while turning
     int2* track_far;                     // [edge] {first event the cover sweep's wave has to visit, last event before it} (pp_k_approach_events)
     unsigned long long* work;            // work-queue heads of the per-edge kernels (PP_Q_*), zeroed by pp_k_solve_edges
     unsigned* need_big;                  // set by the cover sweep when some child has 9..12 ribbons (pp_k_heuristic_big then has work)
@@ -59,6 +61,40 @@ struct __attribute__((aligned(128))) PPEdgeSetup {
     unsigned vi, cbits, sflags;
 };
 static_assert(sizeof(PPEdgeSetup) == 384, "PPEdgeSetup is sized for three 128-byte lines");
+
+// ------------------------------------------------------------------------------------------
+// Clearance map of the occupancy grid (PPGrid::clearance), built whenever a grid is set: chessboard (L-infinity) distance in cells
+// to the nearest cell that is blocked or outside the grid, capped at PP_CLEAR_CAP.  The L-infinity distance separates: with
+// r(x, y') = distance along row y' from column x to the nearest blocked-or-outside cell, d(x, y) = min over dy of max(|dy|, r(x, y + dy)).
+__global__ __launch_bounds__(256) void pp_k_grid_row_clear(const uint32_t* bits, int rows, int cols, int wpr, unsigned char* rowclear) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+    const uint32_t* row = bits + (size_t)r * wpr;
+    int d = 0;
+    for (; d < PP_CLEAR_CAP; d++) {
+        const int a = c - d, b = c + d;
+        if (a < 0 || b >= cols) break;                                      // the grid's edge is as good as a blocked cell
+        if (((row[a >> 5] >> (a & 31)) | (row[b >> 5] >> (b & 31))) & 1u) break;
+    }
+    rowclear[i] = (unsigned char)d;
+}
+__global__ __launch_bounds__(256) void pp_k_grid_clear(const unsigned char* rowclear, int rows, int cols, unsigned char* clearance) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+    int best = rowclear[i];
+    for (int dy = 1; dy < best; dy++) {                                     // a row |dy| away cannot give less than |dy|
+        const int up = r + dy, dn = r - dy;
+        int m = dy;                                                         // rows outside the grid: blocked at distance |dy|
+        if (up < rows && dn >= 0) {
+            const int ru = rowclear[(size_t)up * cols + c], rd = rowclear[(size_t)dn * cols + c];
+            m = max(dy, min(ru, rd));
+        }
+        best = min(best, m);
+    }
+    clearance[i] = (unsigned char)best;
+}
 
 // ------------------------------------------------------------------------------------------
 // Collision-check time grid, one row per open vertex (Edge.cpp:114-120,173): the reference
@@ -475,6 +511,107 @@ __device__ __forceinline__ void pp_window_pose(const PPEdgeSetup* S, const PPCur
         double _u; bool _e = false;                                                                        \
         pp_window_pose(_S, _hot, _cur, _cs, t, t0, valid, x, y, _u, _e);                                   \
     } while (0)
+// Which 64-step chunks of an edge's sweep can be skipped?  One THREAD per (edge, chunk), in a kernel of its own ahead of the pose
+// sweep (inside the sweep the test's registers pushed the per-step loop into spills).  A chunk is skipped when it provably changes
+// nothing the sweep records:
+//   * all 64 steps exist and lie before the edge's end time, on the curve proper (no retry at the ends);
+//   * every pose of the chunk lies within `hs` (arc length from the chunk's middle step, so also Euclidean distance) of the middle
+//     pose, and the clearance map says every cell within that distance of the middle pose's cell is free and inside the grid
+//     (+2 cells for the pose's place inside its cell and the rounding of the cell index): no step can be blocked;
+//   * no obstacle can hold any pose of the chunk: seen from the middle step, the pose stays outside the obstacle's box grown by
+//     the distance pose and obstacle can drift apart within the chunk (Gaussian model: outside the 1e-13 radius grown likewise);
+//   * on edges that may not cover while turning (Edge.cpp:159) the heading-unchanged bits are known without sampling: the step
+//     before the chunk and its last step lie on the same segment of the curve — a straight (the heading is the same expression
+//     at every step: all bits set) or an arc whose steps are more than 1e-9 rad apart (no two headings equal: all bits clear).
+// A skipped chunk's outputs are stored here (no hits; the heading bits); for a chunk that is NOT skipped on such an edge the
+// heading of the step before it is stored (`lastHeading`, Edge.cpp:96,174: the sweep needs it when the chunk before was skipped).
+// Everything is the arithmetic the sweep itself would do (pp_window_pose's expressions, one lane's worth).
+#ifndef PP_NO_CHUNK_SKIP
+#define PP_CHUNK_SKIP 1
+#else
+#define PP_CHUNK_SKIP 0
+#endif
+template <bool GAUSSIAN>
+__device__ __forceinline__ void pp_plan_skips_thread(const PPParams& p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n_edges * p.nch) return;
+    const long long e = p.ws_base + i / p.nch;
+    const int chunk = (int)(i % p.nch), k0 = chunk * PP_WAVE;
+    unsigned char* skipb = p.track_skip + (size_t)e * p.nch + chunk;
+    const PPEdgeSetup* S = p.setup + e;
+    bool ok = !(S->sflags & (PP_SETUP_MALFORMED | PP_SETUP_COLOCATED)) && S->type >= 0 && (k0 + PP_WAVE - 1 < p.ng);
+    const bool cov = (S->cbits & PPGPU_EDGE_COVERAGE) != 0;
+    const unsigned vi = S->vi;
+    const double* tg = p.tgrid + (size_t)(ok ? vi : 0) * p.ng;
+    const double wStart = S->wStart, speed = S->speed, length = S->length, rho = S->rho, rho_inv = S->rho_inv;
+    const double endTime = fmin(p.horizon + 1e-12 + p.sst, S->wEnd);
+    const double tF = ok ? tg[k0] : 0.0, tM = ok ? tg[k0 + PP_WAVE / 2] : 0.0, tL = ok ? tg[k0 + PP_WAVE - 1] : INFINITY;
+    const double tP = (ok && k0 > 0) ? tg[k0 - 1] : 0.0;
+    const bool exists = ok && (tF < endTime);                  // the sweep reaches this chunk at all (unless it is blocked earlier)
+    if (!exists) { *skipb = 0; return; }                       // most threads of a short edge: nothing to decide
+    ok = ok && (tL < endTime);
+    const double dP = (tP - wStart) * speed, dF = (tF - wStart) * speed, dM = (tM - wStart) * speed, dL = (tL - wStart) * speed;
+    ok = ok && (dF >= 0.0) && (dL <= length);
+    const double hs = fmax(dL - dM, dM - dF) * (1.0 + 1e-12) + 1e-9;      // how far (arc length) a step of the chunk is from the middle step
+    const double ht = fmax(tL - tM, tM - tF);
+    const double hi0 = S->seg[0].hi, hi1 = S->seg[1].hi;
+    unsigned long long eqWord = ~0ull;
+    if (!cov) {
+        // the step before the chunk: its heading is what the first step of the chunk is compared with
+        const double tpP = (rho_inv != 0.0) ? dP * rho_inv : dP / rho, tpL = (rho_inv != 0.0) ? dL * rho_inv : dL / rho;
+        const int segP = pp_seg_of(tpP, hi0, hi1), segL = pp_seg_of(tpL, hi0, hi1);
+        const bool straight = S->seg[segL].type == 1;
+        eqWord = straight ? ~0ull : 0ull;
+        ok = ok && (k0 > 0) && (dP >= 0.0) && (segP == segL) && (straight || (tpL - tpP) > 65.0 * 1e-9);
+        if (exists && k0 > 0 && dP >= 0.0 && dP <= length) {
+            const PPSeg* g = &S->seg[segP];
+            double ux, uy, uth;
+            pp_curve_seg(g->type, (tpP - g->o1) - g->o2, g->bx, g->by, g->bth, g->sb, g->cb, ux, uy, uth);
+            p.track_carry[(size_t)e * p.nch + chunk] = pp_heading_from_yaw(pp_mod2pi(uth));
+        }
+    }
+    if (__ballot(ok) != 0ull) {
+        const double tpM = (rho_inv != 0.0) ? dM * rho_inv : dM / rho;
+        const PPSeg* g = &S->seg[pp_seg_of(tpM, hi0, hi1)];
+        double ux, uy, uth;
+        pp_curve_seg(g->type, (tpM - g->o1) - g->o2, g->bx, g->by, g->bth, g->sb, g->cb, ux, uy, uth);
+        const double x = ux * rho + S->qx, y = uy * rho + S->qy;
+        if (p.grid.rows != 0) {
+            const double cx = x * p.grid.inv_res, cy = y * p.grid.inv_res;
+            const bool inside = (x >= 0.0) & (y >= 0.0) & (cx < (double)p.grid.cols) & (cy < (double)p.grid.rows);
+            const int need = (int)(hs * p.grid.inv_res) + 2;
+            int clear = 0;
+            if (ok && inside) clear = (int)p.grid.clearance[(size_t)(unsigned)cy * p.grid.cols + (unsigned)cx];
+            ok = ok && inside && (need < PP_CLEAR_CAP) && (clear > need);
+        }
+        if (p.n_obst > 0 && __ballot(ok) != 0ull) {
+            for (int j = 0; j < p.n_obst; j++) {
+                const PPObst& o = p.obst[j];                               // wave-uniform address: scalar loads
+                const double dt = tM - o.Time;
+                const double X = o.X + o.Speed * dt * o.cosYaw, Y = o.Y + o.Speed * dt * o.sinYaw;
+                const double slack = hs + fabs(o.Speed) * ht + 1e-3;         // how far pose and obstacle can drift apart within the chunk
+                const double dx = x - X, dy = y - Y;
+                if (GAUSSIAN) {
+                    const double R = o.reach + slack;
+                    ok = ok && (dx * dx + dy * dy > R * R);
+                } else {
+                    // the box test of pp_obstacle_hit with both half-extents grown by the drift: outside it, no step of the chunk is inside the box
+                    const double rx = dx * o.cosYaw - dy * o.sinYaw, ry = dx * o.sinYaw + dy * o.cosYaw;
+                    ok = ok && ((fabs(rx) > o.halfL + slack) | (fabs(ry) > o.halfW + slack));
+                }
+            }
+        }
+    }
+    *skipb = ok ? 1 : 0;
+    if (ok) {
+        p.track_chunk_hits[(size_t)e * p.nch + chunk] = 0u;
+        if (!cov) p.track_eq[(size_t)e * p.nch + chunk] = eqWord;
+        if (GAUSSIAN) p.track_chunk_pen[(size_t)e * p.nch + chunk] = 0.0;
+    }
+}
+__global__ __launch_bounds__(256) void pp_k_plan_skips(PPParams p) { pp_plan_skips_thread<false>(p); }
+__global__ __launch_bounds__(256) void pp_k_plan_skips_gaussian(PPParams p) { pp_plan_skips_thread<true>(p); }
+
 // e = the edge's slot in the workspace.  GAUSSIAN: the dynamic obstacles are GaussianDynamicObstaclesManager's (its own
 // instantiation: exp() and the density bookkeeping would otherwise cost the common kernel registers).
 template <bool GAUSSIAN>
@@ -554,84 +691,95 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
     }
 #endif
 
-    double tNext = (lane < p.ng) ? tg[lane] : INFINITY;
-    for (int base = 0;; base += PP_WAVE) {
-        const int k = base + lane;
-        const double t = tNext;
-        const double tFirst = pp_readlane(t, 0);
-        if (!(tFirst < endTime)) { limit = base; break; }             // `while (intermediate.time() < endTime)`
-        tNext = (k + PP_WAVE < p.ng) ? tg[k + PP_WAVE] : INFINITY;    // the next chunk's times travel while this one computes
-        const bool valid = t < endTime;
-        double x, y, heading;
-        bool blk = false;
-        int hits = 0;
-        {
-            double uth;
-            pp_window_pose(S, hot, cur, cs, t, tFirst, valid, x, y, uth, dubErr);
-            // the heading itself (:47) only matters for "unchanged since the last step" (Edge.cpp:159), which only matters
-            // on edges that may not cover while turning
-            heading = cov ? 0.0 : pp_heading_from_yaw(pp_mod2pi(uth));
-#ifndef PP_ABL_NO_GRID
-            blk = valid & pp_is_blocked(p.grid, x, y);                // Edge.cpp:144
-#endif
-        }
-        double dens = 0;
-#ifndef PP_ABL_NO_OBST
-        if (anyObstacle && laneCull) {                                // :150-151
-            // which obstacles can come near this chunk: lane i answers for obstacle i from its registers
-            const double dtc = tFirst - cullT0;
-            const double ddx = pp_readlane(x, 0) - (oX0 + oVx * dtc), ddy = pp_readlane(y, 0) - (oY0 + oVy * dtc);
-            unsigned long long m = __ballot(!(ddx * ddx + ddy * ddy > oR2));      // oR2 = -1 in lanes without an obstacle
-            while (m) {
-                const int j = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                if (!gaussian) { if (valid) hits += pp_obstacle_hit(p.obst[j], x, y, t); }
-                else dens += pp_obstacle_pdf(reinterpret_cast<const PPGauss*>(p.obst)[j], x, y, t);
+    // Chunks of 64 steps that provably touch neither a blocked cell nor an obstacle are not sampled at all (pp_k_plan_skips decided
+    // which, one thread per chunk); the others go through the per-step code below, one step per lane.
+    const unsigned char* skipb = p.track_skip ? p.track_skip + (size_t)e * p.nch : nullptr;
+    const double* carry = p.track_carry + (size_t)e * p.nch;
+    bool afterSkip = false, stop = false;
+    for (int g0 = 0; !stop; g0 += PP_WAVE) {
+        const unsigned long long skips = skipb ? __ballot((g0 + lane < p.nch) && skipb[g0 + lane] != 0) : 0ull;
+        for (int ci = 0; ci < PP_WAVE; ci++) {
+            const int base = (g0 + ci) * PP_WAVE;
+            if ((skips >> ci) & 1ull) { limit = base + PP_WAVE; afterSkip = true; continue; }
+            const int k = base + lane;
+            const double t = (k < p.ng) ? tg[k] : INFINITY;
+            const double tFirst = pp_readlane(t, 0);
+            if (!(tFirst < endTime)) { limit = base; stop = true; break; }   // `while (intermediate.time() < endTime)`
+            // `lastHeading` (Edge.cpp:96,174) of the step before this chunk: the chunks in between were skipped, pp_k_plan_skips left it
+            if (!cov && afterSkip) carryHeading = pp_const_f64(carry + (base >> 6))[0];
+            afterSkip = false;
+            const bool valid = t < endTime;
+            double x, y, heading;
+            bool blk = false;
+            int hits = 0;
+            {
+                double uth;
+                pp_window_pose(S, hot, cur, cs, t, tFirst, valid, x, y, uth, dubErr);
+                // the heading itself (:47) only matters for "unchanged since the last step" (Edge.cpp:159), which only matters
+                // on edges that may not cover while turning
+                heading = cov ? 0.0 : pp_heading_from_yaw(pp_mod2pi(uth));
+    #ifndef PP_ABL_NO_GRID
+                blk = valid & pp_is_blocked(p.grid, x, y);                // Edge.cpp:144
+    #endif
             }
-            if (gaussian) { if (dens < 1e-5) dens = 0; if (!valid) dens = 0; }   // GaussianDynamicObstaclesManager.cpp:11
-        } else if (anyObstacle) {
-            if (!gaussian)
-                hits = pp_obstacle_hits_chunk(p.obst, p.n_obst, x, y, t, valid, pp_readlane(x, 0), pp_readlane(y, 0), tFirst, chunkSpan, chunkTime);
-            else
-                dens = pp_obstacle_density_chunk(reinterpret_cast<const PPGauss*>(p.obst), p.n_obst, x, y, t, valid, pp_readlane(x, 0),
-                                                 pp_readlane(y, 0), tFirst, chunkSpan, chunkTime);
-        }
-#endif
-        unsigned long long eqMask = ~0ull;
-        if (!cov) {
-            double prevHeading = __shfl_up(heading, 1, PP_WAVE);
-            if (lane == 0) prevHeading = carryHeading;
-            eqMask = __ballot(prevHeading == heading);
-            carryHeading = pp_readlane(heading, 63);
-        }
-
-        const unsigned long long bm = __ballot(blk);
-        const int fb = bm ? (__ffsll((long long)bm) - 1) : PP_WAVE;
-        const int nvalid = __popcll(__ballot(valid));
-        const int nlim = fb < nvalid ? fb : nvalid;
-
-        int chunkHits = 0;
-        if (__ballot(hits != 0) != 0ull) {
-            // per-step counts are only ever read for a chunk whose sum is not zero
-            chunkHits = pp_wave_sum_i(lane < nlim ? hits : 0);
-            thits[k] = (unsigned short)(hits > 65535 ? 65535 : hits);
-        }
-        if (gaussian) {
-            double chunkPen = 0;
-            if (__ballot(dens != 0.0) != 0ull) {
-                chunkPen = pp_wave_sum_d(lane < nlim ? dens * p.cpf : 0.0);
-                p.track_pen[(size_t)e * p.ngp + k] = dens;
+            double dens = 0;
+    #ifndef PP_ABL_NO_OBST
+            if (anyObstacle && laneCull) {                                // :150-151
+                // which obstacles can come near this chunk: lane i answers for obstacle i from its registers
+                const double dtc = tFirst - cullT0;
+                const double ddx = pp_readlane(x, 0) - (oX0 + oVx * dtc), ddy = pp_readlane(y, 0) - (oY0 + oVy * dtc);
+                unsigned long long m = __ballot(!(ddx * ddx + ddy * ddy > oR2));      // oR2 = -1 in lanes without an obstacle
+                while (m) {
+                    const int j = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    if (!gaussian) { if (valid) hits += pp_obstacle_hit(p.obst[j], x, y, t); }
+                    else dens += pp_obstacle_pdf(reinterpret_cast<const PPGauss*>(p.obst)[j], x, y, t);
+                }
+                if (gaussian) { if (dens < 1e-5) dens = 0; if (!valid) dens = 0; }   // GaussianDynamicObstaclesManager.cpp:11
+            } else if (anyObstacle) {
+                if (!gaussian)
+                    hits = pp_obstacle_hits_chunk(p.obst, p.n_obst, x, y, t, valid, pp_readlane(x, 0), pp_readlane(y, 0), tFirst, chunkSpan, chunkTime);
+                else
+                    dens = pp_obstacle_density_chunk(reinterpret_cast<const PPGauss*>(p.obst), p.n_obst, x, y, t, valid, pp_readlane(x, 0),
+                                                     pp_readlane(y, 0), tFirst, chunkSpan, chunkTime);
             }
-            if (lane == 0) p.track_chunk_pen[(size_t)e * p.nch + (base >> 6)] = chunkPen;
-        }
-        if (lane == 0) {
-            tch[base >> 6] = (unsigned)chunkHits;
-            if (!cov) teq[base >> 6] = eqMask;                        // only read for edges that may not cover while turning
-        }
+    #endif
+            unsigned long long eqMask = ~0ull;
+            if (!cov) {
+                double prevHeading = __shfl_up(heading, 1, PP_WAVE);
+                if (lane == 0) prevHeading = carryHeading;
+                eqMask = __ballot(prevHeading == heading);
+                carryHeading = pp_readlane(heading, 63);
+            }
 
-        if (fb < nvalid) { limit = base + fb; blocked = 1; break; }
-        if (nvalid < PP_WAVE) { limit = base + nvalid; break; }
-        limit = base + PP_WAVE;
+            const unsigned long long bm = __ballot(blk);
+            const int fb = bm ? (__ffsll((long long)bm) - 1) : PP_WAVE;
+            const int nvalid = __popcll(__ballot(valid));
+            const int nlim = fb < nvalid ? fb : nvalid;
+
+            int chunkHits = 0;
+            if (__ballot(hits != 0) != 0ull) {
+                // per-step counts are only ever read for a chunk whose sum is not zero
+                chunkHits = pp_wave_sum_i(lane < nlim ? hits : 0);
+                thits[k] = (unsigned short)(hits > 65535 ? 65535 : hits);
+            }
+            if (gaussian) {
+                double chunkPen = 0;
+                if (__ballot(dens != 0.0) != 0ull) {
+                    chunkPen = pp_wave_sum_d(lane < nlim ? dens * p.cpf : 0.0);
+                    p.track_pen[(size_t)e * p.ngp + k] = dens;
+                }
+                if (lane == 0) p.track_chunk_pen[(size_t)e * p.nch + (base >> 6)] = chunkPen;
+            }
+            if (lane == 0) {
+                tch[base >> 6] = (unsigned)chunkHits;
+                if (!cov) teq[base >> 6] = eqMask;                        // only read for edges that may not cover while turning
+            }
+
+            if (fb < nvalid) { limit = base + fb; blocked = 1; stop = true; break; }
+            if (nvalid < PP_WAVE) { limit = base + nvalid; stop = true; break; }
+            limit = base + PP_WAVE;
+        }
     }
     const int anyErr = (__ballot(dubErr) != 0ull) ? 1 : 0;
     if (lane == 0) { sum->limit = limit; sum->blocked = blocked; sum->dub_err = anyErr; sum->pad = 0; }

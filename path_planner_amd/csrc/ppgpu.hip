@@ -64,6 +64,7 @@ struct ppgpu_ctx {
     ppgpu_config cfg{};
     // Map
     DevBuf<uint32_t> grid;
+    DevBuf<unsigned char> grid_clear, grid_rowclear;   // clearance map of the grid (PPGrid::clearance) and its row pass
     int rows = 0, cols = 0, wpr = 0;
     double res = 0;
     // dynamic obstacles
@@ -97,6 +98,8 @@ struct ppgpu_ctx {
     DevBuf<unsigned> track_chunk_hits;
     DevBuf<PPTrackSummary> track_summary;
     DevBuf<int2> track_far;
+    DevBuf<unsigned char> track_skip;
+    DevBuf<double> track_carry;
     DevBuf<unsigned> need_big;
     DevBuf<unsigned long long> work;    // queue heads of the resident per-edge grids (PP_Q_*)
     int n_cu = 0;
@@ -157,14 +160,14 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     if (!c) return PPGPU_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->grid.release(); c->obst.release(); c->verts.release(); c->ribbons.release(); c->tgrid.release();
+    c->grid.release(); c->grid_clear.release(); c->grid_rowclear.release(); c->obst.release(); c->verts.release(); c->ribbons.release(); c->tgrid.release();
     c->sx.release(); c->sy.release(); c->sh.release(); c->samp_ribbons.release();
     c->s_bytes.release(); c->s_u64.release(); c->s_u32a.release(); c->s_u32b.release(); c->s_cand.release();
     c->tmp_edges.release(); c->tmp_wedges.release(); c->partial.release(); c->tmp_results.release(); c->tmp_child.release();
     c->ord_key.release(); c->ord_val.release(); c->ord_idx.release(); c->ord_fallbacks.release();
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     c->setup.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
-    c->track_summary.release(); c->track_far.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->work.release(); c->dstage_in.release(); c->dstage_out.release();
+    c->track_summary.release(); c->track_far.release(); c->track_skip.release(); c->track_carry.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->work.release(); c->dstage_in.release(); c->dstage_out.release();
     if (c->stage_in) (void)hipHostFree(c->stage_in);
     if (c->stage_out) (void)hipHostFree(c->stage_out);
     for (int i = 0; i < 5; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -242,6 +245,15 @@ int ppgpu_set_grid(ppgpu_ctx* c, const uint8_t* cells, int32_t rows, int32_t col
     int rc = c->grid.reserve(bits.size(), false, c->stream);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(c->grid.p, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    // clearance map: chessboard distance to the nearest blocked-or-outside cell, capped (two separable passes on the device)
+    if ((rc = c->grid_clear.reserve((size_t)rows * cols, false, c->stream)) || (rc = c->grid_rowclear.reserve((size_t)rows * cols, false, c->stream)))
+        return rc;
+    {
+        const long long ncell = (long long)rows * cols;
+        hipLaunchKernelGGL(pp_k_grid_row_clear, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, c->grid.p, rows, cols, wpr, c->grid_rowclear.p);
+        hipLaunchKernelGGL(pp_k_grid_clear, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, c->grid_rowclear.p, rows, cols, c->grid_clear.p);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->rows = rows; c->cols = cols; c->wpr = wpr; c->res = res;
     return PPGPU_OK;
@@ -517,7 +529,7 @@ int ppgpu_sampler_add(ppgpu_ctx* c, int64_t n_attempts, int64_t* n_total_out) {
     hipLaunchKernelGGL(pp_k_generate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, s.on_ribbons ? qpos : nullptr,
                        s.on_ribbons ? proj : nullptr, c->samp_ribbons.p, n, c->s_cand.p);
     // 5. SamplingBasedPlanner::addSamples' map filter, order-preserving compaction into the store
-    PPGrid g{c->grid.p, c->rows, c->cols, c->wpr, c->res, c->res > 0 ? 1.0 / c->res : 0.0};
+    PPGrid g{c->grid.p, c->rows, c->cols, c->wpr, c->res, c->res > 0 ? 1.0 / c->res : 0.0, nullptr};
     unsigned char* keep = proj;  // the projection bits are no longer needed once the candidates exist
     hipLaunchKernelGGL(pp_k_keep_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, c->s_cand.p, n, keep);
     hipLaunchKernelGGL(pp_k_count_reduce, dim3(nblk_n), dim3(256), 0, st, keep, n, 1u, blk32);
@@ -550,7 +562,7 @@ static void fill_params(ppgpu_ctx* c, PPParams& p) {
     p.cpf = g.collision_penalty_factor; p.tpf = g.time_penalty_factor;
     p.heuristic = g.heuristic; p.tsp_k = g.tsp_k; p.h_rho = g.heuristic_turning_radius;
     p.fuse_h = 0;
-    p.grid = PPGrid{c->grid.p, c->rows, c->cols, c->wpr, c->res, c->res > 0 ? 1.0 / c->res : 0.0};
+    p.grid = PPGrid{c->grid.p, c->rows, c->cols, c->wpr, c->res, c->res > 0 ? 1.0 / c->res : 0.0, c->rows > 0 ? c->grid_clear.p : nullptr};
     p.obst = c->obst.p; p.n_obst = c->n_obst; p.obst_model = c->obst_model;
     p.verts = c->verts.p; p.ribbons = c->ribbons.p; p.tgrid = c->tgrid.p; p.ng = c->ng; p.nverts = c->nverts;
     p.sx = c->sx.p; p.sy = c->sy.p; p.sh = c->sh.p; p.n_samples = c->n_samples + c->n_extra;
@@ -692,7 +704,8 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
             (rc = c->track_hits.reserve(ws * p.ngp, false, c->stream)) ||
             (rc = c->track_eq.reserve(ws * p.nch, false, c->stream)) ||
             (rc = c->track_chunk_hits.reserve(ws * p.nch, false, c->stream)) ||
-            (rc = c->track_summary.reserve(ws, false, c->stream)) || (rc = c->track_far.reserve(ws, false, c->stream)))
+            (rc = c->track_summary.reserve(ws, false, c->stream)) || (rc = c->track_far.reserve(ws, false, c->stream)) ||
+            (rc = c->track_skip.reserve(ws * p.nch, false, c->stream)) || (rc = c->track_carry.reserve(ws * p.nch, false, c->stream)))
             return rc;
         if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN &&
             ((rc = c->track_pen.reserve(ws * p.ngp, false, c->stream)) || (rc = c->track_chunk_pen.reserve(ws * p.nch, false, c->stream))))
@@ -700,6 +713,9 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     }
     p.setup = c->setup.p; p.track_hits = c->track_hits.p; p.track_eq = c->track_eq.p;
     p.track_chunk_hits = c->track_chunk_hits.p; p.track_summary = c->track_summary.p; p.track_far = c->track_far.p;
+    // chunk skipping needs the clearance map (or no grid at all) and solved curves (a given curve may start late or end early)
+    p.track_skip = (PP_CHUNK_SKIP && !p.wedges && (c->rows == 0 || c->grid_clear.p) && p.ng >= PP_WAVE) ? c->track_skip.p : nullptr;
+    p.track_carry = c->track_carry.p;
     p.track_pen = c->track_pen.p; p.track_chunk_pen = c->track_chunk_pen.p;
     {
         int rc = c->need_big.reserve(1, false, c->stream);
@@ -727,6 +743,11 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(pp_k_solve_edges, dim3((unsigned)((p.n_edges + 255) / 256)), dim3(256), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        if (p.track_skip) {                                          // timed with the pose sweep
+            const unsigned blocks = (unsigned)((p.n_edges * p.nch + 255) / 256);
+            if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN) hipLaunchKernelGGL(pp_k_plan_skips_gaussian, dim3(blocks), dim3(256), 0, c->stream, p);
+            else hipLaunchKernelGGL(pp_k_plan_skips, dim3(blocks), dim3(256), 0, c->stream, p);
+        }
         if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN)
             hipLaunchKernelGGL(pp_k_pose_sweep_gaussian, dim3(resident_grid(c, 0, pp_k_pose_sweep_gaussian, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
         else
@@ -739,6 +760,25 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
             hipLaunchKernelGGL(pp_k_cover_sweep, dim3(resident_grid(c, 3, pp_k_cover_sweep, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     }
+#ifdef PP_DBG_SKIPS
+    if (p.track_skip) {   // developer aid: how many of the chunks the sweeps reached were skipped (last slice)
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::vector<unsigned char> sk((size_t)p.n_edges * p.nch);
+        std::vector<PPTrackSummary> sm((size_t)p.n_edges);
+        HIP_TRY(hipMemcpy(sk.data(), c->track_skip.p, sk.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(sm.data(), c->track_summary.p, sm.size() * sizeof(PPTrackSummary), hipMemcpyDeviceToHost));
+        unsigned long long reached = 0, skipped = 0, marked = 0;
+        for (long long e = 0; e < p.n_edges; e++) {
+            const int nreach = (sm[(size_t)e].limit + 63) / 64;
+            for (int ch = 0; ch < p.nch; ch++) {
+                marked += sk[(size_t)e * p.nch + ch];
+                if (ch < nreach) { reached++; skipped += sk[(size_t)e * p.nch + ch]; }
+            }
+        }
+        std::fprintf(stderr, "[skips] edges %lld, chunks reached %llu, skipped %llu (%.1f %%), marked in all %llu\n", p.n_edges, reached, skipped,
+                     reached ? 100.0 * skipped / reached : 0.0, marked);
+    }
+#endif
     p.e_base = 0;
     p.n_edges = total;
     if (p.heuristic == PPGPU_H_TSP_DUBINS_ALL || p.heuristic == PPGPU_H_TSP_DUBINS_K)
