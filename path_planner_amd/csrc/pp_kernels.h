@@ -1643,16 +1643,16 @@ __global__ __launch_bounds__(256) void pp_k_select_nearest(const double* lengths
 // std::pop_heap once the heap holds k + 1), stops once the heap is full and its worst LENGTH is not above the next distance, and
 // then walks the heap ARRAY front to back.  Which vertex std::pop_heap later surfaces among children of exactly equal f depends
 // on that order, so it is replayed here: one 256-thread workgroup per (vertex, radius).
-//   1. candidates = valid samples (farther than the increment) with distance <= the k-th smallest length (pp_k_select_nearest):
-//      everything the scan can visit before it stops (a winner's distance is at most its length), compacted into LDS;
-//   2. bitonic sort by (distance, sample index);
+//   1. candidates = valid samples (farther than the increment) with distance <= an upper bound of the k-th smallest length:
+//      everything the scan can visit before it stops (a winner's distance is at most its length);
+//   2. bitonic sort by (distance, sample index) in LDS;
 //   3. wave 0 replays the scan with the heap held one slot per lane (parent/child moves are v_readlane and a lane-select, no memory),
 //      following libstdc++'s __push_heap / __adjust_heap step for step.  A candidate whose cost is strictly above the heap's
 //      root, pushed onto a full heap of pairwise distinct costs and popped again, leaves the array exactly as it was (the hole
 //      sinks along the path the push shifted down and every element returns to its slot), so only the candidates at or below
 //      the current root — a few dozen of the hundreds to thousands — are taken through the exact steps.
-// More than PP_ORD_CAP candidates are sorted in a global scratch instead of LDS (same code, slower); more than the scratch holds,
-// k above 64, or equal costs inside a heap fall back to ascending length and raise *fallbacks (the caller reports it).
+// More than PP_ORD_CAP candidates (4 096: a sample set of about a million), k above 63, or equal costs inside a heap fall back to
+// ascending length and raise *fallbacks (the caller reports it).
 #define PP_ORD_CAP 4096
 struct PPOrdHeap { double cost, len; int idx; };
 __device__ __forceinline__ void pp_ord_set(PPOrdHeap& h, int slot, double cost, double len, int idx) {   // slot and values are wave-uniform
@@ -1692,91 +1692,244 @@ __device__ __forceinline__ void pp_ord_pop(PPOrdHeap& h, int n) {
     }
     pp_ord_sift_up(h, hole, vc, vl, vi);
 }
-template <typename KP, typename IP>
-__device__ __forceinline__ void pp_ord_bitonic(KP key, IP val, int n2) {   // ascending by (key, val); n2 a power of two; whole workgroup
-    for (int size = 2; size <= n2; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int t = (int)threadIdx.x; t < (n2 >> 1); t += (int)blockDim.x) {
-                const int i = ((t / stride) * stride << 1) + (t % stride), j = i + stride;
-                const double ki = key[i], kj = key[j];
-                const int vi = val[i], vj = val[j];
-                const bool up = (i & size) == 0;
-                const bool gt = ki > kj || (ki == kj && vi > vj);
-                if (gt == up) { key[i] = kj; key[j] = ki; val[i] = vj; val[j] = vi; }
-            }
+// The four steps of the replay, each as parallel as its data allows (the first version did everything in the one workgroup of a
+// (vertex, radius): two serial passes over all samples and a gather per 64 candidates made it the slowest kernel of the planner's
+// round trip):
+//   pp_k_lengths_minima     thread per (vertex, sample): both Dubins lengths (as pp_k_dubins_lengths) and, per 256-sample block, the
+//                           smallest valid length of each radius and the number of valid samples;
+//   pp_k_expand_bound       workgroup per (vertex, radius): U = the k-th smallest of the block minima (of groups of blocks when there
+//                           are more than 512).  At least k samples are not longer than U, so U bounds the k-th smallest length from
+//                           above, and it is nearly always equal to it (the k best samples seldom share a block).  Fewer than k valid
+//                           samples, or fewer than k blocks with one: U = +inf (the scan visits everything);
+//   pp_k_expand_candidates  thread per (vertex, sample): the samples the scan can visit — valid, distance <= U — appended to the
+//                           (vertex, radius) list {distance, index, length} with one atomic per wavefront;
+//   pp_k_expand_order       workgroup per (vertex, radius): sort the list by (distance, index), replay (above).
+__global__ __launch_bounds__(256) void pp_k_lengths_minima(const ppgpu_vertex* verts, const double* sx, const double* sy, const double* sh, long long ns,
+                                                           double rho, double rho_cov, double inc_d, double* out, double* blockmin, int* blockcnt) {
+    __shared__ double m0[4], m1[4];
+    __shared__ int nv[4];
+    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y;
+    double l0 = -1, l1 = -1;
+    if (s < ns) {
+        const ppgpu_vertex* V = verts + v;
+        const double ax = V->x, ay = V->y, ayaw = pp_yaw(V->heading);
+        const double bx = sx[s], by = sy[s], byaw = pp_yaw(sh[s]);
+        if (sqrt((ax - bx) * (ax - bx) + (ay - by) * (ay - by)) > inc_d) {   // State::distanceTo, SamplingBasedPlanner.cpp:111
+            PPDubins d;
+            pp_dubins_shortest(ax, ay, ayaw, bx, by, byaw, rho, d);
+            l0 = pp_dubins_length(d, rho);
+            pp_dubins_shortest(ax, ay, ayaw, bx, by, byaw, rho_cov, d);
+            l1 = pp_dubins_length(d, rho_cov);
         }
+        double2 o; o.x = l0; o.y = l1;
+        reinterpret_cast<double2*>(out)[(size_t)v * ns + s] = o;
+    }
+    const double a0 = pp_wave_min(l0 >= 0 ? l0 : INFINITY), a1 = pp_wave_min(l1 >= 0 ? l1 : INFINITY);
+    const int cnt = __popcll(__ballot(l0 >= 0));
+    const int w = (int)(threadIdx.x >> 6);
+    if (pp_lane() == 0) { m0[w] = a0; m1[w] = a1; nv[w] = cnt; }
     __syncthreads();
+    if (threadIdx.x == 0) {
+        const size_t b = (size_t)v * gridDim.x + blockIdx.x;
+        blockmin[2 * b] = fmin(fmin(m0[0], m0[1]), fmin(m0[2], m0[3]));
+        blockmin[2 * b + 1] = fmin(fmin(m1[0], m1[1]), fmin(m1[2], m1[3]));
+        blockcnt[b] = nv[0] + nv[1] + nv[2] + nv[3];
+    }
 }
-__global__ __launch_bounds__(256) void pp_k_expand_order(const double* lengths, const ppgpu_vertex* verts, const double* sx, const double* sy,
-                                                         long long ns, int k, double max_speed, double tpf, int two_radii,
-                                                         const int* sel_idx, const double* sel_len, double* g_key, int* g_val,
-                                                         long long g_cap, int* out_idx, unsigned* fallbacks) {
-    __shared__ double cd[PP_ORD_CAP];
-    __shared__ int ci[PP_ORD_CAP];
-    __shared__ int count;
+#define PP_BOUND_CAP 512             // values the bound kernel ranks: block minima, merged into groups of consecutive blocks when there are more
+__global__ __launch_bounds__(256) void pp_k_expand_bound(const double* blockmin, const int* blockcnt, int nblk, int k, double* bound, int* cand_count) {
+    __shared__ double vals[PP_BOUND_CAP];
+    __shared__ int valid;
+    __shared__ double U;
     const int vr = blockIdx.x, v = vr >> 1, r = vr & 1;
     const int tid = (int)threadIdx.x;
-    int* out = out_idx + (size_t)vr * k;
-    const int* wi = sel_idx + (size_t)vr * k;
-    const double* wl = sel_len + (size_t)vr * k;
-    if ((r == 1 && !two_radii) || wi[0] < 0) {               // radius not in use (:60-63,97-100), or no sample farther than the increment
-        for (int j = tid; j < k; j += 256) out[j] = (r == 1 && !two_radii) ? -1 : wi[j];
-        return;
-    }
-    const double* L = lengths + ((size_t)v * ns) * 2 + r;
-    const bool fullSet = wi[k - 1] >= 0;
-    const double bound = fullSet ? wl[k - 1] * (1.0 + 1e-9) : INFINITY;   // fewer than k valid samples: the scan visits them all
-    const double vx = verts[v].x, vy = verts[v].y;
-    if (tid == 0) count = 0;
+    if (tid == 0) { valid = 0; U = INFINITY; cand_count[vr] = 0; }
     __syncthreads();
-    // 1. candidates, distance = State::distanceTo (State.h:177-179) of the sample to the source
-    double* gk = g_key + (size_t)vr * g_cap;
-    int* gv = g_val + (size_t)vr * g_cap;
-    for (long long s = tid; s < ns; s += 256) {
-        if (!(L[s * 2] >= 0)) continue;
-        const double d = sqrt((sx[s] - vx) * (sx[s] - vx) + (sy[s] - vy) * (sy[s] - vy));
-        if (d > bound) continue;
-        const int slot = atomicAdd(&count, 1);
-        if (slot < PP_ORD_CAP) { cd[slot] = d; ci[slot] = (int)s; }
-        if (slot < g_cap) { gk[slot] = d; gv[slot] = (int)s; }      // kept too, in case LDS overflows
+    const int per = (nblk + PP_BOUND_CAP - 1) / PP_BOUND_CAP;            // blocks per ranked value
+    const int nval = (nblk + per - 1) / per;
+    int c = 0;
+    for (int j = tid; j < nval; j += 256) {
+        double m = INFINITY;
+        for (int b = j * per; b < (j + 1) * per && b < nblk; b++) {
+            m = fmin(m, blockmin[2 * ((size_t)v * nblk + b) + r]);
+            c += blockcnt[(size_t)v * nblk + b];
+        }
+        vals[j] = m;
     }
+    atomicAdd(&valid, c);
     __syncthreads();
-    const int M = count;
-    bool fallback = k >= PP_WAVE;                              // the heap holds k + 1 entries for a moment, one per lane
-    const bool inLds = M <= PP_ORD_CAP;
-    int n2 = 64;
-    while (n2 < M) n2 <<= 1;
-    if (!fallback) {
-        // 2. sort
-        if (inLds) {
-            for (int i = M + tid; i < n2; i += 256) { cd[i] = INFINITY; ci[i] = 0x7fffffff; }
-            pp_ord_bitonic(cd, ci, n2);
-        } else if ((long long)n2 <= g_cap) {
-            for (int i = M + tid; i < n2; i += 256) { gk[i] = INFINITY; gv[i] = 0x7fffffff; }
-            pp_ord_bitonic(gk, gv, n2);
-        } else {
-            fallback = true;
+    // the k-th smallest of the minima by rank counting (ties ranked by position): k groups hold a sample not longer than it
+    if (valid >= k) {
+        for (int j = tid; j < nval; j += 256) {
+            const double x = vals[j];
+            if (!(x < INFINITY)) continue;
+            int rank = 0;
+            for (int i = 0; i < nval; i++) rank += ((vals[i] < x) | ((vals[i] == x) & (i < j))) ? 1 : 0;
+            if (rank == k - 1) U = x;
         }
     }
+    __syncthreads();
+    if (tid == 0) bound[vr] = U;
+}
+__global__ __launch_bounds__(256) void pp_k_expand_candidates(const double* lengths, const ppgpu_vertex* verts, const double* sx, const double* sy,
+                                                              long long ns, int two_radii, const double* bound, double* g_key, int* g_val, double* g_len,
+                                                              long long g_cap, int* cand_count) {
+    __shared__ int wcount[2][4], wbase[2][4];
+    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y, w = (int)(threadIdx.x >> 6), lane = pp_lane();
+    double l0 = -1, l1 = -1, d = 0;
+    if (s < ns) {
+        const double2 L = reinterpret_cast<const double2*>(lengths)[(size_t)v * ns + s];
+        l0 = L.x; l1 = L.y;
+        const double vx = verts[v].x, vy = verts[v].y;
+        d = sqrt((sx[s] - vx) * (sx[s] - vx) + (sy[s] - vy) * (sy[s] - vy));       // State::distanceTo of the sample to the source
+    }
+    const int nr = two_radii ? 2 : 1;
+    bool take[2] = {false, false};
+    unsigned long long m[2] = {0ull, 0ull};
+    for (int r = 0; r < nr; r++) {
+        const double len = r ? l1 : l0;
+        take[r] = (len >= 0) && !(d > bound[2 * v + r] * (1.0 + 1e-9));
+        m[r] = __ballot(take[r]);
+        if (lane == 0) wcount[r][w] = __popcll(m[r]);
+    }
+    __syncthreads();
+    // one atomic per workgroup and radius (a device-scope atomic on one address completes every ~12 ns: per wavefront they took
+    // longer than everything else in this kernel)
+    if (threadIdx.x < (unsigned)nr) {
+        const int r = (int)threadIdx.x;
+        const int tot = wcount[r][0] + wcount[r][1] + wcount[r][2] + wcount[r][3];
+        int base = tot ? atomicAdd(&cand_count[2 * v + r], tot) : 0;
+        for (int i = 0; i < 4; i++) { wbase[r][i] = base; base += wcount[r][i]; }
+    }
+    __syncthreads();
+    for (int r = 0; r < nr; r++) {
+        if (!take[r]) continue;
+        const long long slot = wbase[r][w] + __popcll(m[r] & ((1ull << lane) - 1ull));
+        if (slot < g_cap) {
+            const size_t at = (size_t)(2 * v + r) * g_cap + slot;
+            g_key[at] = d; g_val[at] = (int)s; g_len[at] = r ? l1 : l0;
+        }
+    }
+}
+#define PP_ORD_INNER 1024            // candidates of the inner ring whose costs set the filter threshold
+__global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, double max_speed, double tpf, int two_radii, const double* bound,
+                                                         const double* g_key, const int* g_val, const double* g_len, long long g_cap,
+                                                         const int* cand_count, int* out_idx, unsigned* fallbacks) {
+    __shared__ double cd[PP_ORD_CAP];        // 80 KB of the CU's 160 KB LDS: distance, length, list position / sample index
+    __shared__ double cl[PP_ORD_CAP];
+    __shared__ int ci[PP_ORD_CAP];
+    __shared__ double inner[PP_ORD_INNER];
+    __shared__ int nInner, nKept;
+    __shared__ double threshold;
+    const int vr = blockIdx.x, r = vr & 1;
+    const int tid = (int)threadIdx.x;
+    int* out = out_idx + (size_t)vr * k;
+    const int M = cand_count[vr];
+#ifdef PP_DBG_ORD
+    long long tk0 = wall_clock64(), tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0; int nexact = 0;
+#endif
+    if ((r == 1 && !two_radii) || M <= 0) {                  // radius not in use (:60-63,97-100), or no sample farther than the increment
+        for (int j = tid; j < k; j += 256) out[j] = -1;
+        return;
+    }
+    const double* gk = g_key + (size_t)vr * g_cap;
+    const int* gv = g_val + (size_t)vr * g_cap;
+    const double* gl = g_len + (size_t)vr * g_cap;
+    bool fallback = k >= PP_WAVE || (long long)M > g_cap;     // the heap holds k + 1 entries for a moment, one per lane
+    // Most candidates cannot change the heap: a candidate beyond the inner ring (distance > U/4, a sixteenth of the disc) whose cost
+    // is above the k-th smallest cost INSIDE that ring finds the heap full of k cheaper entries when its turn comes, whatever the
+    // order inside the ring.  Only the ring and the cheaper ones outside it are sorted and replayed (a few hundred of thousands).
+    const double U = bound[vr];
+    if (tid == 0) { nInner = 0; nKept = 0; threshold = INFINITY; }
+    __syncthreads();
+    const bool filter = !fallback && (U < INFINITY) && M > 512;
+    const double dq = 0.25 * U;
+    if (filter) {
+        for (int i = tid; i < M; i += 256)
+            if (gk[i] <= dq) {
+                const int slot = atomicAdd(&nInner, 1);
+                if (slot < PP_ORD_INNER) inner[slot] = gl[i] / max_speed * tpf;
+            }
+        __syncthreads();
+        const int n = nInner;
+        if (n >= k && n <= PP_ORD_INNER)
+            for (int i = tid; i < n; i += 256) {
+                const double x = inner[i];
+                int rank = 0;
+                for (int j = 0; j < n; j++) rank += ((inner[j] < x) | ((inner[j] == x) & (j < i))) ? 1 : 0;
+                if (rank == k - 1) threshold = x;
+            }
+        __syncthreads();
+    }
+#ifdef PP_DBG_ORD
+    tk1 = wall_clock64();
+#endif
+    const double T = threshold;                               // +inf: keep everything
+    for (int i = tid; i < M && !fallback; i += 256) {
+        const double d = gk[i], len = gl[i];
+        if (d <= dq || !(len / max_speed * tpf > T)) {
+            const int slot = atomicAdd(&nKept, 1);
+            if (slot < PP_ORD_CAP) { cd[slot] = d; cl[slot] = len; ci[slot] = i; }
+        }
+    }
+    __syncthreads();
+    const int Mk = nKept;
+#ifdef PP_DBG_ORD
+    tk2 = wall_clock64();
+#endif
+    fallback = fallback || Mk > PP_ORD_CAP;
+    if (!fallback) {
+        int n2 = 64;
+        while (n2 < Mk) n2 <<= 1;
+        for (int i = Mk + tid; i < n2; i += 256) { cd[i] = INFINITY; cl[i] = INFINITY; ci[i] = 0x7fffffff; }
+        // by (distance, sample index): list positions are not in sample order, so equal distances compare their samples
+        for (int size = 2; size <= n2; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                __syncthreads();
+                for (int t = tid; t < (n2 >> 1); t += 256) {
+                    const int i = ((t / stride) * stride << 1) + (t % stride), j = i + stride;
+                    const double ki = cd[i], kj = cd[j];
+                    const int vi = ci[i], vj = ci[j];
+                    bool gt = ki > kj;
+                    if (ki == kj) gt = (vi == 0x7fffffff) ? (vj != 0x7fffffff) : (vj != 0x7fffffff && gv[vi] > gv[vj]);
+                    if (gt == ((i & size) == 0)) {
+                        const double li = cl[i], lj = cl[j];
+                        cd[i] = kj; cd[j] = ki; ci[i] = vj; ci[j] = vi; cl[i] = lj; cl[j] = li;
+                    }
+                }
+            }
+        __syncthreads();
+        for (int i = tid; i < Mk; i += 256) ci[i] = gv[ci[i]];                // list position -> sample index
+        __syncthreads();
+    }
+#ifdef PP_DBG_ORD
+    tk3 = wall_clock64();
+#endif
     if (tid >= PP_WAVE) return;
-    // 3. replay (wave 0)
+    // the replay (wave 0)
     const int lane = tid;
     PPOrdHeap h;
     h.cost = INFINITY; h.len = INFINITY; h.idx = -1;
     int hsize = 0;
     bool dup = false, stopped = false;
     if (!fallback) {
-        for (int base = 0; base < M && !stopped && !dup; base += PP_WAVE) {
+        for (int base = 0; base < Mk && !stopped && !dup; base += PP_WAVE) {
             const int c = base + lane;
-            const bool have = c < M;
-            const double d = have ? (inLds ? cd[c] : gk[c]) : INFINITY;
-            const int idx = have ? (inLds ? ci[c] : gv[c]) : -1;
-            const double len = have ? L[(size_t)idx * 2] : INFINITY;
+            const bool have = c < Mk;
+            const double d = have ? cd[c] : INFINITY;
+            const double len = have ? cl[c] : INFINITY;
+            const int idx = have ? ci[c] : -1;
             const double cost = len / max_speed * tpf;                 // Edge::computeApproxCost (Edge.cpp:17)
             // the candidates of this chunk that can change the heap: every one while it is not full, afterwards those at or below the
             // root's cost as it stands at the start of the chunk (the root only ever gets cheaper)
             unsigned long long todo = (hsize < k) ? __ballot(have) : __ballot(have & (cost <= pp_readlane(h.cost, 0)));
+            if (hsize >= k && todo == 0ull) {
+                // nobody enters the heap; the scan still ends at the first distance the worst kept length does not exceed
+                if (__ballot(have & !(pp_readlane(h.len, 0) > d)) != 0ull) stopped = true;
+                continue;
+            }
             while (todo) {
                 const int j = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
@@ -1787,15 +1940,40 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(const double* lengths, 
                     if (cj > pp_readlane(h.cost, 0)) continue;                            // the root moved since the chunk began: a no-op
                 }
                 if (__ballot((lane < hsize) & (h.cost == cj)) != 0ull) { dup = true; break; }
+#ifdef PP_DBG_ORD
+                nexact++;
+#endif
                 pp_ord_sift_up(h, hsize, cj, lj, ij);                                     // push_back + std::push_heap
                 hsize++;
                 if (hsize > k) { hsize--; pp_ord_pop(h, hsize); }                         // std::pop_heap + pop_back
             }
         }
     }
+#ifdef PP_DBG_ORD
+    tk4 = wall_clock64();
+    if (lane == 0 && vr < 4) printf("[ord] vr %d M %d inner %d kept %d exact %d | filter %lld keep %lld sort %lld replay %lld (x10ns)\n", vr, M, nInner, Mk, nexact, tk1 - tk0, tk2 - tk1, tk3 - tk2, tk4 - tk3);
+#endif
     if (fallback || dup) {
+        // keep what a plain selection gives: the k cheapest of the list, ascending by (length, sample); only the push order is lost
         if (lane == 0) atomicAdd(fallbacks, 1u);
-        for (int j = lane; j < k; j += PP_WAVE) out[j] = wi[j];
+        const int Mc = (long long)M < g_cap ? M : (int)g_cap;
+        double prevL = -INFINITY; int prevI = -1;
+        for (int j = 0; j < k; j++) {
+            double bl = INFINITY; int bi = 0x7fffffff;
+            for (int c = lane; c < Mc; c += PP_WAVE) {
+                const double l = gl[c];
+                const int i = gv[c];
+                const bool after = (l > prevL) || (l == prevL && i > prevI);
+                if (after && (l < bl || (l == bl && i < bi))) { bl = l; bi = i; }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const double l2 = __shfl_xor(bl, o, PP_WAVE); const int i2 = __shfl_xor(bi, o, PP_WAVE);
+                if (l2 < bl || (l2 == bl && i2 < bi)) { bl = l2; bi = i2; }
+            }
+            if (lane == 0) out[j] = (bi == 0x7fffffff) ? -1 : bi;
+            prevL = bl; prevI = bi;
+            if (bi == 0x7fffffff) { for (int jj = j + 1 + lane; jj < k; jj += PP_WAVE) out[jj] = -1; break; }
+        }
         return;
     }
     if (lane < k) out[lane] = (lane < hsize) ? h.idx : -1;      // the heap array, front to back

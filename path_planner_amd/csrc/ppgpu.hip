@@ -33,6 +33,9 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 // obstacle model adds 8 bytes per step).  A launch whose workspace
 // would exceed PP_SLICE_BYTES runs as consecutive slices.  (Running slice i's cover sweep next to slice i+1's pose sweep
 // on a second stream was measured and gains nothing: both sweeps are bound by fp64 VALU issue.)
+#ifndef PP_PREPASS_MIN_EDGES
+#define PP_PREPASS_MIN_EDGES 8192   // launches below this skip pp_k_plan_skips / pp_k_approach_events (their results are optional)
+#endif
 #ifndef PP_SLICE_BYTES
 #define PP_SLICE_BYTES (32ull << 30)
 #endif
@@ -91,6 +94,7 @@ struct ppgpu_ctx {
     DevBuf<ppgpu_wrapper_edge> tmp_wedges;
     DevBuf<ppgpu_edge_result> tmp_results;
     DevBuf<double> tmp_child, tmp_lengths, tmp_len_out, int_child;
+    long long prepass_min_edges = PP_PREPASS_MIN_EDGES;   // env PPGPU_PREPASS_MIN_EDGES overrides (tests run the prepasses on small launches too)
     size_t slice_bytes = PP_SLICE_BYTES; // workspace budget of one costing slice (env PPGPU_SLICE_BYTES overrides: tests)
     DevBuf<PPEdgeSetup> setup;          // workspace of the current costing slice: phase-0 records ...
     DevBuf<unsigned short> track_hits;  // ... and the pose sweep's track (see PPParams)
@@ -113,7 +117,8 @@ struct ppgpu_ctx {
     int max_vertex_ribbons = 0;
     DevBuf<int> tmp_idx;
     DevBuf<double> ord_key;             // pp_k_expand_order: candidate scratch beyond what LDS holds, push-order output, fallback counter
-    DevBuf<int> ord_val, ord_idx;
+    DevBuf<int> ord_val, ord_idx, ord_blockcnt, ord_count;
+    DevBuf<double> ord_len, ord_blockmin, ord_bound;
     DevBuf<unsigned> ord_fallbacks;
     unsigned long long order_fallbacks = 0;   // (vertex, radius) lists of ppgpu_expand_host / ppgpu_expand_order that fell back to ascending length
     DevBuf<unsigned char> dstage_in, dstage_out;            // device ends of ppgpu_expand_host's single upload / download
@@ -148,6 +153,7 @@ int ppgpu_create(int device, ppgpu_ctx** out) {
     c->n_cu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    if (const char* pm = std::getenv("PPGPU_PREPASS_MIN_EDGES")) c->prepass_min_edges = std::atoll(pm);
     if (const char* sb = std::getenv("PPGPU_SLICE_BYTES")) {
         const long long v = std::atoll(sb);
         if (v > 0) c->slice_bytes = (size_t)v;
@@ -164,7 +170,8 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->sx.release(); c->sy.release(); c->sh.release(); c->samp_ribbons.release();
     c->s_bytes.release(); c->s_u64.release(); c->s_u32a.release(); c->s_u32b.release(); c->s_cand.release();
     c->tmp_edges.release(); c->tmp_wedges.release(); c->partial.release(); c->tmp_results.release(); c->tmp_child.release();
-    c->ord_key.release(); c->ord_val.release(); c->ord_idx.release(); c->ord_fallbacks.release();
+    c->ord_key.release(); c->ord_val.release(); c->ord_idx.release(); c->ord_fallbacks.release(); c->ord_len.release();
+    c->ord_blockmin.release(); c->ord_blockcnt.release(); c->ord_bound.release(); c->ord_count.release();
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     c->setup.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
     c->track_summary.release(); c->track_far.release(); c->track_skip.release(); c->track_carry.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->work.release(); c->dstage_in.release(); c->dstage_out.release();
@@ -610,22 +617,33 @@ int ppgpu_select_nearest(ppgpu_ctx* c, int32_t v0, int32_t nv, int32_t k, int32_
     return PPGPU_OK;
 }
 
-// After pp_k_dubins_lengths + pp_k_select_nearest for vertices [0, nv) (results in c->tmp_lengths / tmp_idx / tmp_len_out): the
-// winners of every (vertex, radius) in the reference's push order -> c->ord_idx.  Asynchronous; *c->ord_fallbacks.p counts lists
-// that kept ascending length.
+// The k winners of every (vertex, radius) of vertices [0, nv) in the reference's push order -> c->ord_idx, and both Dubins lengths
+// of every (vertex, sample) -> c->tmp_lengths: lengths + block minima, bound, candidate lists, sort + replay (pp_kernels.h).
+// Asynchronous; *c->ord_fallbacks.p counts lists that kept ascending length.
 static int launch_expand_order(ppgpu_ctx* c, int nv, int k) {
     const long long ns = c->n_samples;
     long long cap = 64;
-    while (cap < ns && cap < 65536) cap <<= 1;
+    while (cap < ns && cap < 65536) cap <<= 1;         // candidates per list; pp_k_expand_order filters them down to at most PP_ORD_CAP
+    const int nblk = (int)((ns + 255) / 256);
     int rc;
-    if ((rc = c->ord_key.reserve((size_t)nv * 2 * cap, false, c->stream)) || (rc = c->ord_val.reserve((size_t)nv * 2 * cap, false, c->stream)) ||
-        (rc = c->ord_idx.reserve((size_t)nv * 2 * k, false, c->stream)) || (rc = c->ord_fallbacks.reserve(1, false, c->stream)))
+    if ((rc = c->tmp_lengths.reserve((size_t)nv * ns * 2, false, c->stream)) ||
+        (rc = c->ord_key.reserve((size_t)nv * 2 * cap, false, c->stream)) || (rc = c->ord_val.reserve((size_t)nv * 2 * cap, false, c->stream)) ||
+        (rc = c->ord_len.reserve((size_t)nv * 2 * cap, false, c->stream)) || (rc = c->ord_idx.reserve((size_t)nv * 2 * k, false, c->stream)) ||
+        (rc = c->ord_fallbacks.reserve(1, false, c->stream)) || (rc = c->ord_blockmin.reserve((size_t)nv * nblk * 2, false, c->stream)) ||
+        (rc = c->ord_blockcnt.reserve((size_t)nv * nblk, false, c->stream)) || (rc = c->ord_bound.reserve((size_t)nv * 2, false, c->stream)) ||
+        (rc = c->ord_count.reserve((size_t)nv * 2, false, c->stream)))
         return rc;
     HIP_TRY(hipMemsetAsync(c->ord_fallbacks.p, 0, sizeof(unsigned), c->stream));
     const int two_radii = (c->cfg.coverage_turning_radius != c->cfg.turning_radius) ? 1 : 0;
-    hipLaunchKernelGGL(pp_k_expand_order, dim3((unsigned)(nv * 2)), dim3(256), 0, c->stream, c->tmp_lengths.p, c->verts.p, c->sx.p, c->sy.p, ns, k,
-                       c->cfg.max_speed, c->cfg.time_penalty_factor, two_radii, c->tmp_idx.p, c->tmp_len_out.p, c->ord_key.p, c->ord_val.p, cap,
-                       c->ord_idx.p, c->ord_fallbacks.p);
+    hipLaunchKernelGGL(pp_k_lengths_minima, dim3((unsigned)nblk, (unsigned)nv), dim3(256), 0, c->stream, c->verts.p, c->sx.p, c->sy.p, c->sh.p, ns,
+                       c->cfg.turning_radius, c->cfg.coverage_turning_radius, c->cfg.collision_checking_increment, c->tmp_lengths.p,
+                       c->ord_blockmin.p, c->ord_blockcnt.p);
+    hipLaunchKernelGGL(pp_k_expand_bound, dim3((unsigned)(nv * 2)), dim3(256), 0, c->stream, c->ord_blockmin.p, c->ord_blockcnt.p, nblk, k,
+                       c->ord_bound.p, c->ord_count.p);
+    hipLaunchKernelGGL(pp_k_expand_candidates, dim3((unsigned)nblk, (unsigned)nv), dim3(256), 0, c->stream, c->tmp_lengths.p, c->verts.p, c->sx.p,
+                       c->sy.p, ns, two_radii, c->ord_bound.p, c->ord_key.p, c->ord_val.p, c->ord_len.p, cap, c->ord_count.p);
+    hipLaunchKernelGGL(pp_k_expand_order, dim3((unsigned)(nv * 2)), dim3(256), 0, c->stream, ns, k, c->cfg.max_speed, c->cfg.time_penalty_factor,
+                       two_radii, c->ord_bound.p, c->ord_key.p, c->ord_val.p, c->ord_len.p, cap, c->ord_count.p, c->ord_idx.p, c->ord_fallbacks.p);
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;
 }
@@ -635,13 +653,9 @@ int ppgpu_expand_order(ppgpu_ctx* c, int32_t v0, int32_t nv, int32_t k, int32_t*
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     if (k <= 0 || !h_idx || v0 != 0 || nv <= 0 || nv > c->nverts) return fail(PPGPU_EINVAL, "expand_order: bad arguments (v0 must be 0)");
-    const long long ns = c->n_samples;
+    if (nv > 65535) return fail(PPGPU_ECAPACITY, "expand_order: at most 65535 vertices per call");
+    if (c->n_samples <= 0) return fail(PPGPU_ESTATE, "expand_order: the sample store is empty");
     const size_t nout = (size_t)nv * 2 * k;
-    if ((rc = c->tmp_lengths.reserve((size_t)nv * ns * 2, false, c->stream)) || (rc = c->tmp_idx.reserve(nout, false, c->stream)) ||
-        (rc = c->tmp_len_out.reserve(nout, false, c->stream)))
-        return rc;
-    if ((rc = ppgpu_dubins_lengths(c, 0, nv, c->tmp_lengths.p))) return rc;
-    hipLaunchKernelGGL(pp_k_select_nearest, dim3((unsigned)(nv * 2)), dim3(256), 0, c->stream, c->tmp_lengths.p, ns, k, c->tmp_idx.p, c->tmp_len_out.p);
     if ((rc = launch_expand_order(c, nv, k))) return rc;
     unsigned fb = 0;
     HIP_TRY(hipMemcpyAsync(h_idx, c->ord_idx.p, nout * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -712,10 +726,13 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
             return rc;
     }
     p.setup = c->setup.p; p.track_hits = c->track_hits.p; p.track_eq = c->track_eq.p;
-    p.track_chunk_hits = c->track_chunk_hits.p; p.track_summary = c->track_summary.p; p.track_far = c->track_far.p;
+    p.track_chunk_hits = c->track_chunk_hits.p; p.track_summary = c->track_summary.p; p.track_far = c->track_far.p;   // (cleared below for small launches)
     // chunk skipping needs the clearance map (or no grid at all) and solved curves (a given curve may start late or end early)
-    p.track_skip = (PP_CHUNK_SKIP && !p.wedges && (c->rows == 0 || c->grid_clear.p) && p.ng >= PP_WAVE) ? c->track_skip.p : nullptr;
+    // both prepasses pay for themselves on large launches only: a planner round trip of a few hundred edges is latency-bound
+    const bool big = total >= c->prepass_min_edges;
+    p.track_skip = (PP_CHUNK_SKIP && big && !p.wedges && (c->rows == 0 || c->grid_clear.p) && p.ng >= PP_WAVE) ? c->track_skip.p : nullptr;
     p.track_carry = c->track_carry.p;
+    if (!big) p.track_far = nullptr;
     p.track_pen = c->track_pen.p; p.track_chunk_pen = c->track_chunk_pen.p;
     {
         int rc = c->need_big.reserve(1, false, c->stream);
@@ -753,7 +770,7 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         else
             hipLaunchKernelGGL(pp_k_pose_sweep, dim3(resident_grid(c, 1, pp_k_pose_sweep, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-        hipLaunchKernelGGL(pp_k_approach_events, dim3((unsigned)((p.n_edges + 255) / 256)), dim3(256), 0, c->stream, p);   // timed with the cover sweep
+        if (p.track_far) hipLaunchKernelGGL(pp_k_approach_events, dim3((unsigned)((p.n_edges + 255) / 256)), dim3(256), 0, c->stream, p);   // timed with the cover sweep
         if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN)
             hipLaunchKernelGGL(pp_k_cover_sweep_gaussian, dim3(resident_grid(c, 2, pp_k_cover_sweep_gaussian, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
         else
@@ -1010,16 +1027,7 @@ int ppgpu_expand_host(ppgpu_ctx* c, int32_t nv, const ppgpu_vertex* hv, int32_t 
     hipLaunchKernelGGL(pp_k_time_grid, dim3((unsigned)nv), dim3(64), 0, st, c->verts.p, nv, c->cfg.start_state_time,
                        c->cfg.collision_checking_increment, c->cfg.max_speed, c->ng, c->tgrid.p);
     // ---- k nearest per (vertex, radius), on the device
-    if (select) {
-        const size_t nout = (size_t)nv * 2 * k;
-        if ((rc = c->tmp_lengths.reserve((size_t)nv * ns * 2, false, st)) || (rc = c->tmp_idx.reserve(nout, false, st)) ||
-            (rc = c->tmp_len_out.reserve(nout, false, st)))
-            return rc;
-        hipLaunchKernelGGL(pp_k_dubins_lengths, dim3((unsigned)((ns + 255) / 256), (unsigned)nv), dim3(256), 0, st, c->verts.p, 0, c->sx.p, c->sy.p,
-                           c->sh.p, ns, c->cfg.turning_radius, c->cfg.coverage_turning_radius, c->cfg.collision_checking_increment, c->tmp_lengths.p);
-        hipLaunchKernelGGL(pp_k_select_nearest, dim3((unsigned)(nv * 2)), dim3(256), 0, st, c->tmp_lengths.p, ns, k, c->tmp_idx.p, c->tmp_len_out.p);
-        if ((rc = launch_expand_order(c, nv, k))) return rc;   // the winners in the order expand() pushes them
-    }
+    if (select && (rc = launch_expand_order(c, nv, k))) return rc;   // the k winners per (vertex, radius) in the order expand() pushes them
     const double slow = c->cfg.slow_speed <= 0 ? c->cfg.max_speed : c->cfg.slow_speed;     // PlannerConfig::slowSpeed()
     const int two_speeds = (slow != c->cfg.max_speed) ? 1 : 0;                              // SamplingBasedPlanner.cpp:57-59
     const int two_radii = (c->cfg.coverage_turning_radius != c->cfg.turning_radius) ? 1 : 0;  // :60-63

@@ -21,3 +21,13 @@ def _build_oracle():
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     yield
+
+
+@pytest.fixture(autouse=True)
+def _prepasses_on_small_launches(monkeypatch):
+    """The two optional prepasses of a costing launch (pp_k_plan_skips, pp_k_approach_events) normally run only on launches of
+    8 192 edges or more; the parity tests mostly cost a few thousand edges, so they lower the threshold to 0 and every record they
+    compare with the oracle went through both.  tests/test_gpu_parity.py::test_small_launches_without_prepasses checks the other
+    setting gives the same bytes.  (Read by ppgpu_create, also in the plan_cli subprocesses.)"""
+    monkeypatch.setenv("PPGPU_PREPASS_MIN_EDGES", "0")
+    yield

@@ -430,11 +430,12 @@ def test_children_with_long_ribbon_lists_do_not_abort_the_plan():
     assert host["host_heuristics"] > 0 and host["plan_depth"] >= 1 and len(host["plan"]) >= 1
 
 
-def test_ten_hertz_replan_loop_with_32_moving_obstacles():
+def test_ten_hertz_replan_loop_with_32_moving_obstacles(monkeypatch):
     """SURVEY config 5 on one GPU: 40 consecutive plan() calls with a 100 ms real-time budget each, the start advanced 0.1 s along
     the returned plan, the plan handed back as previousPlan, 32 moving obstacles on the config-3 grid.  Every cycle must
     return a plan, close to its deadline; the first (allocating) cycle is reported separately by plan_cli."""
     from path_planner_amd import workloads
+    monkeypatch.delenv("PPGPU_PREPASS_MIN_EDGES", raising=False)      # the production setting
     w = workloads.config3()
     w.obst = workloads.obstacles(32, 3, 204.8, time=float(w.start5[4]), keep_free=(float(w.start5[0]), float(w.start5[1]), 25))
     with tempfile.TemporaryDirectory() as d:

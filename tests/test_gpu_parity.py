@@ -573,6 +573,20 @@ def test_long_child_ribbon_list_gets_its_heuristic_on_the_host(torch_cuda):
     assert abs(h_host - cpu["h"][0]) <= 1e-9 * max(1.0, cpu["h"][0]), (h_host, cpu["h"][0])
 
 
+def test_small_launches_without_prepasses(torch_cuda, monkeypatch):
+    """Launches below 8 192 edges skip the chunk-skip planner and the approach prepass (both only move work around): the records must
+    be the same bytes with and without them."""
+    from path_planner_amd import workloads
+    w = workloads.config3(n_samples=1500)
+    outs = []
+    for threshold in ("0", "1000000000"):
+        monkeypatch.setenv("PPGPU_PREPASS_MIN_EDGES", threshold)
+        ctx, world, n, cs = _setup(w, 1500)
+        gpu, gchild = _dense(torch_cuda, ctx, 1, n, 0xF)
+        outs.append((gpu.tobytes(), gchild.tobytes()))
+    assert outs[0] == outs[1]
+
+
 def test_config4_eight_shards_walked_on_one_device(torch_cuda):
     """SURVEY config 4 as far as one GPU allows: ONE iteration batch of 262 144 sample attempts, costed (a) in one piece and (b) as
     the eight shards an 8-GPU node would take — every rank skips the attempts of the lower ranks (ppgpu_sampler_skip), draws and

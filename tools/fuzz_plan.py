@@ -69,18 +69,24 @@ def classify_tie(H, O, same_length=True):
     word_tie = retry = False
     for i in range(min(len(H), len(O))):
         h, o = H[i], O[i]
+        if np.max(rel(h[:5], o[:5])) > 1e-4:
+            break       # from here on the two searches expand different (equal-f) vertices: only what came before can explain it
+        if h[8] != o[8]:
+            # same source, two words for (nearly) the same length: a zero-length arc makes two words the same curve; otherwise the
+            # lengths must agree to the last digits (a tie `cost < best` settles by rounding), or to 1e-5 once an upstream end
+            # pose has moved
+            lh, lo = (h[5] + h[6] + h[7]) * h[9], (o[5] + o[6] + o[7]) * o[9]
+            same_curve = min(h[5], h[7]) <= 1e-9 and min(o[5], o[7]) <= 1e-9
+            if h[9] != o[9] or (not same_curve and abs(lh - lo) > (1e-5 if retry else 1e-11) * max(1.0, abs(lo))):
+                return False, f"edge {i}: different Dubins words, lengths {lh!r} and {lo!r}"
+            word_tie = True
+            continue
         r = rel(h, o)
-        r[8] = 0.0                                          # the word is compared below
         if np.max(r) > 1e-4:
-            # from here on the two searches expand different (equal-f) vertices: only what came before can explain it
-            break
+            break       # same source, another target: the order of equal-f siblings already differs
         if h[11] != o[11]:
             return False, f"edge {i}: infeasible flag differs"
-        if h[8] != o[8]:
-            if min(h[5], h[7]) > 1e-9 or min(o[5], o[7]) > 1e-9:
-                return False, f"edge {i}: different Dubins words on a curve without a zero-length arc"
-            word_tie = True
-        elif np.max(r) > 1e-12:
+        if np.max(r) > 1e-12:
             retry = True                                    # same edge, last digits differ: a parent's end pose moved by <= 1e-5 m
     if not (word_tie or retry):
         return False, "no upstream difference explains the other plan: the push / pop order itself differs"
