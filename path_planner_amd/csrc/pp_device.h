@@ -847,6 +847,25 @@ __device__ __forceinline__ bool pp_tsp_big_ok(int heuristic, int K, int n) {
     return pp_tsp_prefixes(n, K, Ls) < (1ull << 21);
 }
 
+// pp_k_heuristic_lanes (pp_kernels.h): the TSP heuristics with one lane per edge, for edges that leave their ribbons untouched
+#define PP_H_DEFERRED (-1.0)        // what the cover sweep writes into h for such an edge (a heuristic is never negative)
+#define PP_HL_MAX_LEAVES 4096
+// how many leaves the enumeration of n ribbons has (branching 2 * min(K, remaining) per level)
+__device__ __forceinline__ unsigned pp_lane_tsp_leaves(int n, int K) {
+    unsigned long long L = 1;
+    for (int rem = n; rem >= 1 && L <= (1ull << 20); rem--) L *= (unsigned long long)(2 * (rem < K ? rem : K));
+    return L > (1ull << 20) ? (1u << 20) : (unsigned)L;
+}
+// may the cover sweep leave a child list of n ribbons to pp_k_heuristic_lanes?
+#define PP_HL_MAX_N 6
+static_assert(PP_HL_MAX_N == 6, "pp_k_heuristic_lanes dispatches on n = 1 .. 6");
+__device__ __forceinline__ bool pp_lane_tsp_ok(int heuristic, int tsp_k, int n) {
+    if (n < 1 || n > PP_HL_MAX_N) return false;
+    if (heuristic == PPGPU_H_TSP_POINT_ALL) return pp_lane_tsp_leaves(n, PP_TSP_MAX) <= PP_HL_MAX_LEAVES;
+    if (heuristic == PPGPU_H_TSP_POINT_K) return tsp_k > 0 && pp_lane_tsp_leaves(n, tsp_k) <= PP_HL_MAX_LEAVES;
+    return false;
+}
+
 // RibbonManager::maxDistance (RibbonManager.cpp:234-248); pts = x,y of the query point then of every ribbon's start, end
 __device__ inline double pp_h_max_distance(const double* pts, int n, double w) {
     const double x = pts[0], y = pts[1];

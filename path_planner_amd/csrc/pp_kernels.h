@@ -10,6 +10,7 @@ struct PPParams {
     double inv_inc_d;                    // 1 / inc_d (host division): first guess of a quotient that is then verified
     int heuristic, tsp_k;
     int fuse_h;                          // the cover sweep's wave goes straight on to the edge's heuristic (see PP_FUSE_HEUR)
+    int defer_h;                         // ... unless the edge left its ribbons untouched: then pp_k_heuristic_lanes does it (large launches)
     double h_rho;                        // RibbonManager::m_TurningRadius of the Dubins-TSP heuristics
     // world
     PPGrid grid;
@@ -41,6 +42,7 @@ struct PPParams {
     double* track_carry;                 // [edge][nch]  heading of the step before the chunk, for edges that may not cover while turning
     int2* track_far;                     // [edge] {first event the cover sweep's wave has to visit, last event before it} (pp_k_approach_events)
     unsigned long long* work;            // work-queue heads of the per-edge kernels (PP_Q_*), zeroed by pp_k_solve_edges
+    unsigned* defer_list; unsigned* defer_count;   // edges whose heuristic the cover sweep left to pp_k_heuristic_lanes
     unsigned* need_big;                  // set by the cover sweep when some child has 9..12 ribbons (pp_k_heuristic_big then has work)
     int ngp, nch;                        // steps per edge rounded up to whole 64-step chunks, and that many chunks
 };
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256) void pp_k_solve_edges(PPParams p) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     // the queue heads of the kernels that follow (all of them start after this kernel has ended, in stream order)
     if (e < 4 * PP_NQ) p.work[(size_t)e * PP_QSTRIDE] = 0ull;
-    if (e == 0 && p.e_base == 0) *p.need_big = 0u;            // raised by the cover sweeps of this launch, read by pp_k_heuristic_big
+    if (e == 0 && p.e_base == 0) { *p.need_big = 0u; if (p.defer_count) for (int i = 0; i <= PP_HL_MAX_N; i++) p.defer_count[i] = 0u; }            // raised by the cover sweeps of this launch, read by pp_k_heuristic_big
     if (e >= p.n_edges) return;
     unsigned vi, target, cbits;
     const long long eg = pp_edge_position(p, p.e_base + e);   // position in the caller's edge list; e = position in this slice
@@ -911,6 +913,9 @@ __global__ __launch_bounds__(256) void pp_k_approach_events(PPParams p) {
 }
 
 // e = the edge's slot in the workspace, eg = its position in the caller's edge list, lds = 256 doubles private to the wave
+#ifndef PP_LANE_HEUR
+#define PP_LANE_HEUR 1   // untouched ribbon lists: heuristic by pp_k_heuristic_lanes
+#endif
 #ifndef PP_FUSE_HEUR
 #define PP_FUSE_HEUR 1
 #endif
@@ -1288,7 +1293,10 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
 #if PP_FUSE_HEUR
     // The edge's heuristic, by this wave, from the ribbons it still holds in registers (point heuristics; the record and the child
     // ribbons are stored, so nothing of the sweep is live any more): what pp_heuristic_edge<false, PP_TSP_MAX> would do.
-    if (!GAUSSIAN && p.fuse_h && !throwsRef && nrib > 0 && nrib <= p.stride) {          // = pp_heuristic_edge<false, PP_TSP_MAX>
+    // large launches: the TSP enumeration of a short list is pp_k_heuristic_lanes' (a few lanes instead of this wave)
+    const bool deferred = !GAUSSIAN && p.defer_h && !throwsRef && nrib <= p.stride && pp_lane_tsp_ok(p.heuristic, p.tsp_k, nrib);
+    if (deferred && lane == 0) rec->h = PP_H_DEFERRED;
+    if (!GAUSSIAN && p.fuse_h && !deferred && !throwsRef && nrib > 0 && nrib <= p.stride) {          // = pp_heuristic_edge<false, PP_TSP_MAX>
         const bool tsp = p.heuristic != PPGPU_H_MAX_DISTANCE;
         bool leaveToBigPass = false;
         const unsigned flags0 = flags;
@@ -1507,6 +1515,209 @@ __global__ __launch_bounds__(PP_H_WPB * 64) void pp_k_heuristic_big(PPParams p) 
     for (PP_EACH_EDGE(e, 4, PP_Q_BIG, p.n_edges, PP_Q_CHUNK_HEUR))
         pp_heuristic_edge<false, PP_TSP_MAX_BIG>(p, e, lds_all[wave]);
 }
+
+// ------------------------------------------------------------------------------------------
+// The point-robot TSP heuristics with a few LANES per edge instead of a wave (large launches: the cover sweep marks the edge by
+// h = PP_H_DEFERRED and goes on to its next edge).  The enumeration of RibbonManager.cpp:53-94 is a tree walk of lookups, adds and
+// compares; run by a whole wave for one edge (pp_h_tsp_point) most of its instructions are the bookkeeping of spreading prefixes
+// over lanes, and the table is rebuilt per edge by 64 lanes that mostly idle.  Here PP_HL_SPLIT adjacent lanes share an edge and
+// take the root's branches in turn, each walking its subtree depth-first with control flow that is uniform across the wave for
+// equal n (the data differ, the trip counts do not).  Distances between ribbon endpoints live in the edge's own triangle of LDS
+// (pp_dist(a, b) == pp_dist(b, a) bit for bit: one entry per pair), the distances from the child's end position in registers.
+// Same expressions as pp_h_tsp_point, fmin / fmax taken in another (exact) order: the same bits.
+#ifndef PP_HL_SPLIT
+#define PP_HL_SPLIT 4
+#endif
+#define PP_HL_TRI (PP_HL_MAX_N * (2 * PP_HL_MAX_N - 1) + 1)     // doubles per edge: pairs of 2n endpoints (+1: odd stride)
+#define PP_HL_PTS (4 * PP_HL_MAX_N + 1)
+struct PPLaneTsp { const double* T; double twoW; int K; bool sortK; };
+__device__ __forceinline__ int pp_tri(int a, int b) {            // endpoints 0 .. 2n-1 (start / end of ribbon i = 2i / 2i + 1), a != b
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    return ((hi * (hi - 1)) >> 1) + lo;
+}
+template <int REM>
+__device__ __forceinline__ unsigned pp_lane_tsp_order(const double (&key)[REM > 0 ? REM : 1], unsigned ord) {
+    unsigned o = 0;                                              // pp_tsp_sort_n's ranks (stable, descending)
+#pragma unroll
+    for (int i = 0; i < REM; i++) {
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < REM; j++)
+            if (j != i) rank += ((key[j] > key[i]) | ((key[j] == key[i]) & (j < i))) ? 1 : 0;
+        o |= ((ord >> (4 * i)) & 0xfu) << (4 * rank);
+    }
+    return o;
+}
+__device__ __forceinline__ unsigned pp_lane_tsp_drop(unsigned srt, int c) {        // remove position c of the 4-bit list
+    const unsigned lowmask = (c == 0) ? 0u : ((1u << (4 * c)) - 1u);
+    return (srt & lowmask) | ((srt >> 4) & ~lowmask);
+}
+template <int REM>
+__device__ __forceinline__ double pp_lane_tsp(const PPLaneTsp& c, double sf, unsigned ord, int pt) {
+    if constexpr (REM == 0) {
+        return sf;
+    } else {
+        unsigned srt = ord;
+        if (REM > 1 && c.sortK) {
+            double key[REM];
+#pragma unroll
+            for (int i = 0; i < REM; i++) {
+                const int r = (int)((ord >> (4 * i)) & 0xfu);
+                key[i] = fmin(c.T[pp_tri(pt, 2 * r)], c.T[pp_tri(pt, 2 * r + 1)]);
+            }
+            srt = pp_lane_tsp_order<REM>(key, ord);
+        }
+        const int nb = REM < c.K ? REM : c.K;                 // ribbons branched on, each entered from both ends
+        double best = PP_DBL_MAX;
+        for (int cc = 0; cc < nb; cc++) {
+            const int rid = (int)((srt >> (4 * cc)) & 0xfu);
+            const double len = c.T[rid * (2 * rid + 1) + 2 * rid];         // = pp_tri(2 rid, 2 rid + 1)
+            const double base = sf + len - c.twoW;
+            const double fromStart = fmax(base + c.T[pp_tri(pt, 2 * rid)], 0);       // enter at the start, leave from the end
+            const double fromEnd = fmax(base + c.T[pp_tri(pt, 2 * rid + 1)], 0);
+            if constexpr (REM == 1) {
+                best = fmin(best, fmin(fromStart, fromEnd));
+            } else {
+                const unsigned nord = pp_lane_tsp_drop(srt, cc);
+#pragma unroll 1
+                for (int dir = 0; dir < 2; dir++)
+                    best = fmin(best, pp_lane_tsp<REM - 1>(c, dir == 0 ? fromStart : fromEnd, nord, 2 * rid + 1 - dir));
+            }
+        }
+        return best;
+    }
+}
+// The root: the current point is the child's end position.
+template <int N>
+__device__ __forceinline__ double pp_lane_tsp_root(const PPLaneTsp& c, const double* P, double qx, double qy, int sub) {
+    double d0[2 * N];
+#pragma unroll
+    for (int q = 0; q < 2 * N; q++) d0[q] = pp_dist(qx, qy, P[2 * q], P[2 * q + 1]);
+    unsigned srt = 0x76543210u;
+    if (N > 1 && c.sortK) {
+        double key[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) key[i] = fmin(d0[2 * i], d0[2 * i + 1]);
+        srt = pp_lane_tsp_order<N>(key, srt);
+    }
+    const int b = 2 * (N < c.K ? N : c.K);
+    double best = PP_DBL_MAX;
+    for (int u0 = 0; u0 < b; u0 += PP_HL_SPLIT) {
+        const bool act = u0 + sub < b;
+        const int u = act ? u0 + sub : 0;
+        const int cc = u >> 1, dir = u & 1;
+        const int rid = (int)((srt >> (4 * cc)) & 0xfu);
+        const double len = c.T[rid * (2 * rid + 1) + 2 * rid];
+        const int qi = 2 * rid + dir;                           // the endpoint entered: start (dir 0) or end
+        double dd = d0[0];
+#pragma unroll
+        for (int j = 1; j < 2 * N; j++) dd = (qi == j) ? d0[j] : dd;
+        const double nsf = fmax(0.0 + len - c.twoW + dd, 0);
+        double v = nsf;
+        if constexpr (N > 1) v = pp_lane_tsp<N - 1>(c, nsf, pp_lane_tsp_drop(srt, cc), 2 * rid + 1 - dir);
+        if (act) best = fmin(best, v);
+    }
+#pragma unroll
+    for (int m = 1; m < PP_HL_SPLIT; m <<= 1) best = fmin(best, __shfl_xor(best, m));
+    return best;
+}
+
+// The edges the cover sweeps deferred, packed into one list per ribbon count (a wave of pp_k_heuristic_lanes then holds lists of
+// one length: uniform control flow); one atomic per workgroup and list reserves its run.  defer_count[n], defer_list[(n-1) * total ..].
+#define PP_DL_PER 4          // edges per thread of pp_k_deferred_list
+__global__ __launch_bounds__(256) void pp_k_deferred_list(PPParams p) {
+    __shared__ unsigned s_cnt[PP_HL_MAX_N][4 * PP_DL_PER];
+    __shared__ unsigned s_base[PP_HL_MAX_N];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int nn[PP_DL_PER];                                   // ribbon count of a deferred edge, 0: not deferred
+#pragma unroll
+    for (int j = 0; j < PP_DL_PER; j++) {
+        const long long e = ((long long)blockIdx.x * PP_DL_PER + j) * 256 + tid;
+        nn[j] = 0;
+        if (e < p.total_edges) {
+            const ppgpu_edge_result* rec = p.out + e;
+            if (rec->h == PP_H_DEFERRED && !(rec->flags & PPGPU_F_THROWS)) nn[j] = (int)((rec->info >> 8) & 0xffu);
+        }
+        for (int n = 1; n <= PP_HL_MAX_N; n++) {
+            const unsigned long long m = __ballot(nn[j] == n);
+            if (lane == 0) s_cnt[n - 1][j * 4 + wave] = (unsigned)__popcll(m);
+        }
+    }
+    __syncthreads();
+    if (tid < PP_HL_MAX_N) {
+        unsigned tot = 0;
+        for (int i = 0; i < 4 * PP_DL_PER; i++) { const unsigned c = s_cnt[tid][i]; s_cnt[tid][i] = tot; tot += c; }   // -> offsets
+        s_base[tid] = tot ? atomicAdd(p.defer_count + 1 + tid, tot) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PP_DL_PER; j++) {
+        const int n = nn[j];
+        // every lane votes (n = 0: in no list), so the ballots below are taken by whole waves
+        for (int q = 1; q <= PP_HL_MAX_N; q++) {
+            const unsigned long long m = __ballot(n == q);
+            if (n == q)
+                p.defer_list[(size_t)(q - 1) * (size_t)p.total_edges + s_base[q - 1] + s_cnt[q - 1][j * 4 + wave] +
+                             (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned)(((long long)blockIdx.x * PP_DL_PER + j) * 256 + tid);
+        }
+    }
+}
+#ifndef PP_HL_THREADS
+#define PP_HL_THREADS 64
+#endif
+// (occupancy is set by LDS: 11.8 KB per 16 edges, 13 waves per CU)
+__global__ __launch_bounds__(PP_HL_THREADS) void pp_k_heuristic_lanes(PPParams p) {
+    constexpr int PER = PP_HL_THREADS / PP_HL_SPLIT;              // edges per workgroup
+    __shared__ double Tall[PER * PP_HL_TRI];
+    __shared__ double Pall[PER * PP_HL_PTS];
+    const int tid = threadIdx.x;
+    // which list this workgroup serves: the lists follow one another in whole workgroups
+    unsigned blk = blockIdx.x, count = 0;
+    int n = 1;
+    for (; n <= PP_HL_MAX_N; n++) {
+        count = (unsigned)pp_const_i32(p.defer_count + n)[0];
+        const unsigned nblk = (count + (unsigned)PER - 1u) / (unsigned)PER;
+        if (blk < nblk) break;
+        blk -= nblk;
+    }
+    if (n > PP_HL_MAX_N) return;                                  // the grid is sized for "every edge deferred"
+    const unsigned slot = blk * (unsigned)PER + (unsigned)tid / PP_HL_SPLIT;
+    const int sub = tid & (PP_HL_SPLIT - 1);
+    const bool have = slot < count;
+    const long long e = have ? (long long)p.defer_list[(size_t)(n - 1) * (size_t)p.total_edges + slot] : 0;
+    ppgpu_edge_result* rec = p.out + e;
+    double* T = Tall + (tid / PP_HL_SPLIT) * PP_HL_TRI;
+    double* P = Pall + (tid / PP_HL_SPLIT) * PP_HL_PTS;
+    double qx = 0, qy = 0, g = 0;
+    if (have) {
+        qx = rec->end_x; qy = rec->end_y; g = rec->g;
+        const double* cr = p.child + (size_t)e * p.stride * 4;    // ribbon i = 4 doubles = endpoints 2i, 2i + 1
+        for (int j = sub; j < 4 * n; j += PP_HL_SPLIT) P[j] = cr[j];
+    }
+    __syncthreads();
+    if (have)
+        for (int hi = 1 + sub; hi < 2 * n; hi += PP_HL_SPLIT)
+            for (int lo = 0; lo < hi; lo++)
+                T[((hi * (hi - 1)) >> 1) + lo] = pp_dist(P[2 * lo], P[2 * lo + 1], P[2 * hi], P[2 * hi + 1]);
+    __syncthreads();
+    if (!have) return;
+    PPLaneTsp c;
+    c.T = T; c.twoW = 2 * p.ribw;
+    c.sortK = p.heuristic != PPGPU_H_TSP_POINT_ALL;
+    c.K = c.sortK ? p.tsp_k : PP_TSP_MAX;
+    double hdist = 0;
+    switch (n) {
+        case 1: hdist = pp_lane_tsp_root<1>(c, P, qx, qy, sub); break;
+        case 2: hdist = pp_lane_tsp_root<2>(c, P, qx, qy, sub); break;
+        case 3: hdist = pp_lane_tsp_root<3>(c, P, qx, qy, sub); break;
+        case 4: hdist = pp_lane_tsp_root<4>(c, P, qx, qy, sub); break;
+        case 5: hdist = pp_lane_tsp_root<5>(c, P, qx, qy, sub); break;
+        default: hdist = pp_lane_tsp_root<PP_HL_MAX_N>(c, P, qx, qy, sub); break;
+    }
+    const double hh = hdist / p.max_speed * p.tpf;
+    if (sub == 0) { rec->h = hh; rec->f = g + hh; }
+}
+
 
 // ------------------------------------------------------------------------------------------
 // Dubins lengths from open vertices to every sample, both radii (Edge::computeApproxCost for the
