@@ -10,6 +10,7 @@ struct PPParams {
     double inv_inc_d;                    // 1 / inc_d (host division): first guess of a quotient that is then verified
     int heuristic, tsp_k;
     int fuse_h;                          // the cover sweep's wave goes straight on to the edge's heuristic (see PP_FUSE_HEUR)
+    int quiet_finish;                    // pp_k_approach_events finishes the edges whose cover sweep has nothing to do
     int defer_h;                         // ... unless the edge left its ribbons untouched: then pp_k_heuristic_lanes does it (large launches)
     double h_rho;                        // RibbonManager::m_TurningRadius of the Dubins-TSP heuristics
     // world
@@ -42,6 +43,7 @@ struct PPParams {
     double* track_carry;                 // [edge][nch]  heading of the step before the chunk, for edges that may not cover while turning
     int2* track_far;                     // [edge] {first event the cover sweep's wave has to visit, last event before it} (pp_k_approach_events)
     unsigned long long* work;            // work-queue heads of the per-edge kernels (PP_Q_*), zeroed by pp_k_solve_edges
+    unsigned* live_list; unsigned* live_count;     // edges of the slice the cover sweep still has to visit (pp_k_approach_events)
     unsigned* defer_list; unsigned* defer_count;   // edges whose heuristic the cover sweep left to pp_k_heuristic_lanes
     unsigned* need_big;                  // set by the cover sweep when some child has 9..12 ribbons (pp_k_heuristic_big then has work)
     int ngp, nch;                        // steps per edge rounded up to whole 64-step chunks, and that many chunks
@@ -361,6 +363,7 @@ __global__ __launch_bounds__(256) void pp_k_solve_edges(PPParams p) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     // the queue heads of the kernels that follow (all of them start after this kernel has ended, in stream order)
     if (e < 4 * PP_NQ) p.work[(size_t)e * PP_QSTRIDE] = 0ull;
+    if (e == 0 && p.live_count) *p.live_count = 0u;
     if (e == 0 && p.e_base == 0) { *p.need_big = 0u; if (p.defer_count) for (int i = 0; i <= PP_HL_MAX_N; i++) p.defer_count[i] = 0u; }            // raised by the cover sweeps of this launch, read by pp_k_heuristic_big
     if (e >= p.n_edges) return;
     unsigned vi, target, cbits;
@@ -857,14 +860,133 @@ __device__ __forceinline__ int pp_event_stride(double D, double inc_d, double in
 // wavefront would have computed — and each hands over {next event, last event visited} where its chain meets a ribbon, runs
 // past the sweep's limit or end time, or passes the point from which the curve stays clear of all ribbons (PPEdgeSetup::tfar).
 // The cover sweep starts its state machine there instead of at step 0.
+//
+// Quiet edges.  When the chain ends without meeting a ribbon (past the sweep's limit, or past PPEdgeSetup::tfar) the cover sweep's
+// event loop has nothing to do for this edge, and unless the last cover (Edge.cpp:182-191) happens within reach of a ribbon
+// the rest of computeTrueCost is scalar work: where the loop stopped, two poses, the hit sums, the cost, the record, a copy of the
+// vertex's ribbons.  The lane does that too (pp_finish_quiet_edge: phase C of pp_cover_sweep_edge, the same expressions, for the
+// case "no event changed anything") and marks the edge PP_FAR_DONE; the cover sweep's wave then drops it at once.  Nearly half
+// the edges of config 3.
+#define PP_FAR_DONE (-2)
+__device__ __forceinline__ void pp_lane_pose(const PPEdgeSetup* S, double t, double wStart, double speed, double length, double rho, double rho_inv,
+                                             double qx, double qy, double hi0, double hi1, double& x, double& y, double& uth, bool& err) {
+    double dist = (t - wStart) * speed;                                     // DubinsWrapper.cpp:36
+    if (dist < 0 || dist > length) dist = dist - 1e-5;                      // EDUBPARAM retry, :39-42
+    if (dist < 0 || dist > length) { err = true; dist = fmin(fmax(dist, 0.0), length); }
+    const double tprime = (rho_inv != 0.0) ? dist * rho_inv : dist / rho;
+    const PPSeg* g = &S->seg[pp_seg_of(tprime, hi0, hi1)];
+    double ux, uy;
+    pp_curve_seg(g->type, (tprime - g->o1) - g->o2, g->bx, g->by, g->bth, g->sb, g->cb, ux, uy, uth);
+    x = ux * rho + qx;
+    y = uy * rho + qy;
+}
+// -> true: the edge's record and child ribbons are written.  false: nothing was written, the wave does the edge.
+__device__ __forceinline__ bool pp_finish_quiet_edge(const PPParams& p, const PPEdgeSetup* S, const ppgpu_vertex* V, long long e, long long eg,
+                                                     int limit, int lastEv, const double* rp, const double* tg) {
+    const int nrib = V->ribbon_count;                                       // > 0, no piece short enough to be erased
+    const PPTrackSummary* sum = p.track_summary + e;
+    if (sum->dub_err) return false;
+    if (nrib > p.stride || nrib > PP_TSP_MAX) return false;
+    if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN) return false;
+    // the heuristic must not need this edge's wave either
+    const bool deferH = p.defer_h && pp_lane_tsp_ok(p.heuristic, p.tsp_k, nrib);
+    if (p.fuse_h && !deferH && p.heuristic != PPGPU_H_MAX_DISTANCE) return false;
+    const double wStart = S->wStart, wEnd = S->wEnd, speed = S->speed, length = S->length, rho = S->rho, rho_inv = S->rho_inv, qx = S->qx, qy = S->qy;
+    const double hi0 = S->seg[0].hi, hi1 = S->seg[1].hi;
+    const double srcT = V->time;
+    const bool cov = (S->cbits & PPGPU_EDGE_COVERAGE) != 0;
+    const double endTime = fmin(p.horizon + 1e-12 + p.sst, wEnd);           // Edge.cpp:90; no event shortened it
+    bool infeasible = (srcT >= endTime);                                    // :102-110
+    const int stopKind = sum->blocked;
+    // where the loop of Edge.cpp:143-175 stopped (no event: every step below `limit` ran)
+    int steps, hexec, lastIdx;
+    double tfinal;
+    bool coverFinal = true;
+    const int nexec = limit;                                                // max(cnt, lastEv + 1), cnt = limit
+    (void)lastEv;
+    if (stopKind == 1 && tg[limit] < endTime) {                             // `break` at :146
+        infeasible = true;
+        lastIdx = limit;
+        coverFinal = cov || (((p.track_eq[(size_t)e * p.nch + (limit >> 6)] >> (limit & 63)) & 1ull) != 0ull);
+        tfinal = tg[limit];
+        steps = limit + 1;
+        hexec = limit;
+    } else {
+        if (stopKind == 2 && tg[0] < endTime) infeasible = true;
+        lastIdx = nexec - 1;
+        tfinal = (nexec < p.ng) ? tg[nexec] : INFINITY;
+        steps = nexec;
+        hexec = nexec;
+    }
+    (void)tfinal;                                                           // only used when the ribbons run out: they do not here
+    if (!(wStart <= endTime && wEnd >= endTime)) return false;              // DubinsWrapper::containsTime: the reference throws
+    double ix = V->x, iy = V->y, uth;
+    bool perr = false, ignored = false;
+    if (lastIdx >= 0) pp_lane_pose(S, tg[lastIdx], wStart, speed, length, rho, rho_inv, qx, qy, hi0, hi1, ix, iy, uth, ignored);
+    double endX, endY;
+    pp_lane_pose(S, endTime, wStart, speed, length, rho, rho_inv, qx, qy, hi0, hi1, endX, endY, uth, perr);
+    if (perr) return false;
+    const double endHeading = pp_heading_from_yaw(pp_mod2pi(uth));
+    if (cov || coverFinal) {                                                // the last cover (:182-191): only if it cannot touch a ribbon
+        const double grow = p.ribw + 1e-3;
+        bool inBox = false;
+        for (int i = 0; i < nrib; i++) {
+            const double sx = rp[4 * i], sy = rp[4 * i + 1], ex = rp[4 * i + 2], ey = rp[4 * i + 3];
+            inBox |= (ix >= fmin(sx, ex) - grow) & (ix <= fmax(sx, ex) + grow) & (iy >= fmin(sy, ey) - grow) & (iy <= fmax(sy, ey) + grow);
+        }
+        if (inBox) return false;
+    }
+    int hitsTotal = 0;
+    if (p.n_obst > 0) {
+        const unsigned* tch = p.track_chunk_hits + (size_t)e * p.nch;
+        const int cfull = hexec >> 6;
+        for (int c = 0; c < cfull; c++) hitsTotal += (int)tch[c];
+        if ((hexec & 63) != 0 && tch[cfull] != 0u) {
+            const unsigned short* thits = p.track_hits + (size_t)e * p.ngp;
+            for (int i = cfull << 6; i < hexec; i++) hitsTotal += (int)thits[i];
+        }
+    }
+    const double penalty = (double)hitsTotal * p.cpf;
+    const double netTime = endTime - srcT;
+    const double tc = fmax(netTime - 0, 0);                                 // :197 with ribbons left
+    const double trueCost = tc * p.tpf + penalty;
+    const double g = V->g + trueCost;
+    unsigned flags = infeasible ? PPGPU_F_INFEASIBLE : 0u;
+    if (endTime >= p.sst + p.horizon) flags |= PPGPU_F_GOAL;
+    double h = 0;
+    if (deferH) h = PP_H_DEFERRED;
+    else if (p.fuse_h) {                                                    // MaxDistance (RibbonManager.cpp:234-248), as pp_h_max_distance
+        double sumLength = 0, mn = PP_DBL_MAX, mx = 0;
+        for (int i = 0; i < nrib; i++) {
+            const double sx = rp[4 * i], sy = rp[4 * i + 1], ex = rp[4 * i + 2], ey = rp[4 * i + 3];
+            sumLength += sqrt(pp_sq_len(sx, sy, ex, ey)) - 2 * p.ribw;
+            const double dStart = pp_dist(sx, sy, endX, endY);
+            const double dEnd = pp_dist(ex, ey, endX, endY);
+            mn = fmin(fmin(mn, dEnd), dStart);
+            mx = fmax(fmax(mx, dEnd), dStart);
+        }
+        h = fmax(sumLength + mn, mx) / p.max_speed * p.tpf;
+    }
+    ppgpu_edge_result* rec = p.out + eg;
+    double* r = reinterpret_cast<double*>(rec);
+    const unsigned info = (unsigned)(S->type & 0xff) | ((unsigned)(nrib & 0xff) << 8) | ((unsigned)(steps & 0xffff) << 16);
+    r[0] = __hiloint2double((int)info, (int)flags);
+    r[1] = trueCost; r[2] = penalty; r[3] = S->approx;
+    r[4] = endX; r[5] = endY; r[6] = endHeading; r[7] = speed; r[8] = endTime;
+    r[9] = g; r[10] = h; r[11] = (h == PP_H_DEFERRED) ? g : g + h;
+    r[12] = V->coverage_completed_time; r[13] = S->p0; r[14] = S->p1; r[15] = S->p2;
+    double* c = p.child + (size_t)eg * p.stride * 4;
+    for (int i = 0; i < 4 * nrib; i++) c[i] = rp[i];
+    return true;
+}
 __global__ __launch_bounds__(256) void pp_k_approach_events(PPParams p) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= p.n_edges) return;
-    const PPEdgeSetup* S = p.setup + p.ws_base + e;
+    const bool valid = e < p.n_edges;
+    const PPEdgeSetup* S = p.setup + p.ws_base + (valid ? e : 0);
     int2 out; out.x = 0; out.y = -1;
     const unsigned sflags = S->sflags;
     const int dubType = S->type;
-    if (!(sflags & (PP_SETUP_MALFORMED | PP_SETUP_COLOCATED)) && dubType >= 0) {
+    if (valid && !(sflags & (PP_SETUP_MALFORMED | PP_SETUP_COLOCATED)) && dubType >= 0) {
         const ppgpu_vertex* V = p.verts + S->vi;
         const int nrib = V->ribbon_count;
         const int limit = p.track_summary[p.ws_base + e].limit;
@@ -878,6 +1000,7 @@ __global__ __launch_bounds__(256) void pp_k_approach_events(PPParams p) {
             bool tiny = false;
             for (int i = 0; i < nrib; i++) tiny |= pp_sq_len(rp[4 * i], rp[4 * i + 1], rp[4 * i + 2], rp[4 * i + 3]) < minLength0 * minLength0 / (2.0 * 2.0);
             int k = 0, lastEv = -1;
+            bool handOver = tiny;               // the wave has events to visit (or an error to flag)
             // a piece short enough to be erased makes every event a real one (Ribbon::covered is checked wherever the vehicle is)
             while (!tiny) {
                 if (k >= limit) break;
@@ -886,7 +1009,7 @@ __global__ __launch_bounds__(256) void pp_k_approach_events(PPParams p) {
                 if ((t - wStart) * speed / rho > tfar) { k = 0x3fffffff; break; }       // the rest of the curve is clear: no event is visited
                 double dist = (t - wStart) * speed;                                     // DubinsWrapper.cpp:36
                 if (dist < 0 || dist > length) dist = dist - 1e-5;                      // EDUBPARAM retry, :39-42
-                if (dist < 0 || dist > length) break;                                   // the wavefront's code flags the error
+                if (dist < 0 || dist > length) { handOver = true; break; }              // the wavefront's code flags the error
                 const double tprime = (rho_inv != 0.0) ? dist * rho_inv : dist / rho;
                 const PPSeg* g = &S->seg[pp_seg_of(tprime, hi0, hi1)];
                 double ux, uy, uth;
@@ -901,15 +1024,44 @@ __global__ __launch_bounds__(256) void pp_k_approach_events(PPParams p) {
                     const double qE = (ex - x) * (ex - x) + (ey - y) * (ey - y);
                     q = fmin(q, fmin(qE, qS));
                 }
-                if (inBox) break;                                                       // within reach of a ribbon: the wavefront takes over here
+                if (inBox) { handOver = true; break; }                                  // within reach of a ribbon: the wavefront takes over here
                 const double D = fmin(PP_DBL_MAX, sqrt(q));
                 lastEv = k;
                 k = k + pp_event_stride(D, p.inc_d, p.inv_inc_d, p.ng) + 1;
             }
             out.x = k; out.y = lastEv;
+#ifndef PP_NO_QUIET_FINISH
+            if (!handOver && k >= limit && p.quiet_finish &&
+                pp_finish_quiet_edge(p, S, V, p.ws_base + e, pp_edge_position(p, p.e_base + e), limit, lastEv, rp, tg))
+                out.x = PP_FAR_DONE;
+#endif
+#ifdef PP_DBG_QUIET
+            atomicAdd(p.need_big + 8 + (out.x == PP_FAR_DONE ? 0 : (!handOver && k >= limit) ? 1 : 2), 1u);
+#endif
         }
     }
-    p.track_far[p.ws_base + e] = out;
+    if (valid) p.track_far[p.ws_base + e] = out;
+    // the edges the cover sweep's waves still have to visit, packed (one atomic per workgroup; the order of the launch — long
+    // edges first — survives up to the order in which workgroups get here)
+    if (p.live_list) {
+        __shared__ unsigned s_cnt[4];
+        __shared__ unsigned s_base;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const bool live = valid && out.x != PP_FAR_DONE;
+        const unsigned long long m = __ballot(live);
+        if (lane == 0) s_cnt[wave] = (unsigned)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            s_base = tot ? atomicAdd(p.live_count, tot) : 0u;
+        }
+        __syncthreads();
+        if (live) {
+            unsigned at = s_base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wave; w++) at += s_cnt[w];
+            p.live_list[at] = (unsigned)e;
+        }
+    }
 }
 
 // e = the edge's slot in the workspace, eg = its position in the caller's edge list, lds = 256 doubles private to the wave
@@ -926,6 +1078,9 @@ template <bool GAUSSIAN>
 __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const long long e, const long long eg, double* lds) {
     const int lane = pp_lane();
 
+#ifndef PP_NO_APPROACH
+    if (p.track_far && pp_const_i32(&p.track_far[e].x)[0] == PP_FAR_DONE) return;   // a quiet edge: pp_k_approach_events finished it
+#endif
     // ---- phase 0 was done by pp_k_solve_edges: everything here is wave-uniform and arrives through scalar loads
     const PPEdgeSetup* S = p.setup + e;
     unsigned flags = 0;
@@ -1363,7 +1518,9 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep(PP
     __shared__ double lds_all[PP_WPB][PP_COVER_LDS];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     PPQueue qs = pp_queue_init();
-    for (PP_EACH_EDGE(idx, 2, PP_Q_COVER, p.n_edges, PP_Q_CHUNK_COVER)) {
+    const long long n = p.live_list ? (long long)(unsigned)pp_const_i32(p.live_count)[0] : p.n_edges;
+    for (PP_EACH_EDGE(i, 2, PP_Q_COVER, n, PP_Q_CHUNK_COVER)) {
+        const long long idx = p.live_list ? (long long)(unsigned)pp_const_i32(p.live_list + i)[0] : i;
         const long long eg = pp_edge_position(p, p.e_base + idx);
         pp_cover_sweep_edge<false>(p, p.ws_base + idx, eg, lds_all[wave]);
     }
@@ -1372,8 +1529,11 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep_ga
     __shared__ double lds_all[PP_WPB][PP_WAVE * 4];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     PPQueue qs = pp_queue_init();
-    for (PP_EACH_EDGE(idx, 2, PP_Q_COVER, p.n_edges, PP_Q_CHUNK_COVER))
+    const long long n = p.live_list ? (long long)(unsigned)pp_const_i32(p.live_count)[0] : p.n_edges;
+    for (PP_EACH_EDGE(i, 2, PP_Q_COVER, n, PP_Q_CHUNK_COVER)) {
+        const long long idx = p.live_list ? (long long)(unsigned)pp_const_i32(p.live_list + i)[0] : i;
         pp_cover_sweep_edge<true>(p, p.ws_base + idx, pp_edge_position(p, p.e_base + idx), lds_all[wave]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -94,6 +94,7 @@ struct ppgpu_ctx {
     DevBuf<ppgpu_wrapper_edge> tmp_wedges;
     DevBuf<ppgpu_edge_result> tmp_results;
     DevBuf<double> tmp_child, tmp_lengths, tmp_len_out, int_child;
+    bool quiet_finish = true;           // env PPGPU_QUIET_FINISH=0: every edge's phase C stays with its wave
     bool lane_heuristic = true;         // env PPGPU_LANE_HEURISTIC=0: large launches keep the wave-per-edge enumeration too (tests compare the two)
     long long prepass_min_edges = PP_PREPASS_MIN_EDGES;   // env PPGPU_PREPASS_MIN_EDGES overrides (tests run the prepasses on small launches too)
     size_t slice_bytes = PP_SLICE_BYTES; // workspace budget of one costing slice (env PPGPU_SLICE_BYTES overrides: tests)
@@ -106,7 +107,7 @@ struct ppgpu_ctx {
     DevBuf<unsigned char> track_skip;
     DevBuf<double> track_carry;
     DevBuf<unsigned> need_big;          // [0] need_big, [1 + n] number of deferred edges with n ribbons (pp_k_deferred_list)
-    DevBuf<unsigned> defer_list;
+    DevBuf<unsigned> defer_list, live_list;
     DevBuf<unsigned long long> work;    // queue heads of the resident per-edge grids (PP_Q_*)
     int n_cu = 0;
     int resident[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // workgroups of each per-edge kernel the device holds at once (0 = not asked yet)
@@ -157,6 +158,7 @@ int ppgpu_create(int device, ppgpu_ctx** out) {
     c->stream = c->own_stream;
     if (const char* pm = std::getenv("PPGPU_PREPASS_MIN_EDGES")) c->prepass_min_edges = std::atoll(pm);
     if (const char* lh = std::getenv("PPGPU_LANE_HEURISTIC")) c->lane_heuristic = std::atoi(lh) != 0;
+    if (const char* qf = std::getenv("PPGPU_QUIET_FINISH")) c->quiet_finish = std::atoi(qf) != 0;
     if (const char* sb = std::getenv("PPGPU_SLICE_BYTES")) {
         const long long v = std::atoll(sb);
         if (v > 0) c->slice_bytes = (size_t)v;
@@ -177,7 +179,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->ord_blockmin.release(); c->ord_blockcnt.release(); c->ord_bound.release(); c->ord_count.release();
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     c->setup.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
-    c->track_summary.release(); c->track_far.release(); c->track_skip.release(); c->track_carry.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->defer_list.release(); c->work.release(); c->dstage_in.release(); c->dstage_out.release();
+    c->track_summary.release(); c->track_far.release(); c->track_skip.release(); c->track_carry.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->defer_list.release(); c->live_list.release(); c->work.release(); c->dstage_in.release(); c->dstage_out.release();
     if (c->stage_in) (void)hipHostFree(c->stage_in);
     if (c->stage_out) (void)hipHostFree(c->stage_out);
     for (int i = 0; i < 5; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -572,7 +574,7 @@ static void fill_params(ppgpu_ctx* c, PPParams& p) {
     p.cpf = g.collision_penalty_factor; p.tpf = g.time_penalty_factor;
     p.heuristic = g.heuristic; p.tsp_k = g.tsp_k; p.h_rho = g.heuristic_turning_radius;
     p.fuse_h = 0;
-    p.defer_h = 0; p.defer_list = nullptr; p.defer_count = nullptr;
+    p.defer_h = 0; p.defer_list = nullptr; p.defer_count = nullptr; p.quiet_finish = 0; p.live_list = nullptr; p.live_count = nullptr;
     p.grid = PPGrid{c->grid.p, c->rows, c->cols, c->wpr, c->res, c->res > 0 ? 1.0 / c->res : 0.0, c->rows > 0 ? c->grid_clear.p : nullptr};
     p.obst = c->obst.p; p.n_obst = c->n_obst; p.obst_model = c->obst_model;
     p.verts = c->verts.p; p.ribbons = c->ribbons.p; p.tgrid = c->tgrid.p; p.ng = c->ng; p.nverts = c->nverts;
@@ -739,7 +741,7 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     if (!big) p.track_far = nullptr;
     p.track_pen = c->track_pen.p; p.track_chunk_pen = c->track_chunk_pen.p;
     {
-        int rc = c->need_big.reserve(2 + PP_HL_MAX_N, false, c->stream);
+        int rc = c->need_big.reserve(16, false, c->stream);
         if (rc) return rc;
         p.need_big = c->need_big.p;   // cleared by the first slice's pp_k_solve_edges
         if ((rc = c->work.reserve(PP_WORK_WORDS, false, c->stream))) return rc;
@@ -750,6 +752,12 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     p.fuse_h = (PP_FUSE_HEUR && !dubinsH && !gaussianSweep) ? 1 : 0;
     p.defer_h = (p.fuse_h && big && PP_LANE_HEUR && c->lane_heuristic && total < (1ll << 32) &&
                  (p.heuristic == PPGPU_H_TSP_POINT_ALL || p.heuristic == PPGPU_H_TSP_POINT_K)) ? 1 : 0;
+    p.quiet_finish = (p.track_far && c->quiet_finish) ? 1 : 0;
+    if (p.track_far && slice < (1ll << 32)) {
+        int rc = c->live_list.reserve((size_t)slice, false, c->stream);
+        if (rc) return rc;
+        p.live_list = c->live_list.p; p.live_count = c->need_big.p + 12;
+    }
     if (p.defer_h) {
         int rc = c->defer_list.reserve((size_t)total * PP_HL_MAX_N, false, c->stream);
         if (rc) return rc;
@@ -788,6 +796,15 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
             hipLaunchKernelGGL(pp_k_cover_sweep, dim3(resident_grid(c, 3, pp_k_cover_sweep, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     }
+#ifdef PP_DBG_QUIET
+    {   // developer aid: how the approach chains of the last slice ended
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        unsigned cnt[16];
+        HIP_TRY(hipMemcpy(cnt, c->need_big.p, sizeof(cnt), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[quiet] edges %lld: finished by the lane %u, no events but left to the wave %u, handed over %u\n", p.n_edges, cnt[8], cnt[9], cnt[10]);
+        HIP_TRY(hipMemset(c->need_big.p + 8, 0, 8 * sizeof(unsigned)));
+    }
+#endif
 #ifdef PP_DBG_SKIPS
     if (p.track_skip) {   // developer aid: how many of the chunks the sweeps reached were skipped (last slice)
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -941,7 +958,7 @@ int ppgpu_heuristic_host(ppgpu_ctx* c, int32_t n, const double* poses3, const in
         off += (size_t)counts[i];
     }
     if ((rc = c->tmp_results.reserve((size_t)n, false, c->stream)) || (rc = c->tmp_child.reserve(child.size(), false, c->stream)) ||
-        (rc = c->need_big.reserve(2 + PP_HL_MAX_N, false, c->stream)) || (rc = c->work.reserve(PP_WORK_WORDS, false, c->stream)))
+        (rc = c->need_big.reserve(16, false, c->stream)) || (rc = c->work.reserve(PP_WORK_WORDS, false, c->stream)))
         return rc;
     HIP_TRY(hipMemsetAsync(c->work.p, 0, (size_t)PP_WORK_WORDS * sizeof(unsigned long long), c->stream));   // queue heads (no solve kernel runs here)
     HIP_TRY(hipMemcpyAsync(c->tmp_results.p, rec.data(), rec.size() * sizeof(ppgpu_edge_result), hipMemcpyHostToDevice, c->stream));
