@@ -90,8 +90,6 @@ def main():
         if world > 1:
             dist.all_gather_into_tensor(d_gather, d_key2)          # one collective: 16 B per rank over xGMI
             ctx.key_min(world, d_gather.data_ptr(), d_key2.data_ptr())
-        if timed:
-            kernel_events.append(ctx.last_timing())     # (solve, pose, cover, heuristic) ms of this step's launch, from HIP events
         return ne
 
     def fence():
@@ -108,6 +106,10 @@ def main():
         edges += step(True)
     fence()
     elapsed = time.perf_counter() - t0
+    # (solve, pose, cover, heuristic) ms of the last timed steps' launches, from the HIP events the library recorded between its
+    # kernels on this stream inside the timed region (a ring of 8 sets: read back here, so no step waited for its own events)
+    for back in range(min(args.steps, 8)):
+        kernel_events.append(ctx.past_timing(back))
 
     tot = torch.tensor([float(edges), elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -134,7 +136,10 @@ def main():
         # kernel that reads the ribbons and writes the record and the child ribbons.
         bytes_per_edge = 88 + 32 + 32 * R + 56 * M / 4.0 + 150 + steps_mean / 8.0
         flops_per_edge = 1000 + steps_mean * (70 + 21 * M) + 4e4        # solve + sweeps + heuristic
-        ach_gbs = bytes_per_edge * n_edges_launch / (kern_ms * 1e-3) / 1e9
+        # the cover sweep visits the edges the approach prepass could not finish itself (a packed list); the record, the ribbons
+        # in and out and the track words of those edges are its algorithmic bytes
+        cover_edges = ctx.last_cover_edges()
+        ach_gbs = bytes_per_edge * cover_edges / (kern_ms * 1e-3) / 1e9
         # over the whole costing launch: the cover sweep's wave also runs the edge's heuristic (PP_FUSE_HEUR), so the kernels
         # are not priced separately
         ach_tf = flops_per_edge * n_edges_launch / (launch_ms * 1e-3) / 1e12
@@ -154,9 +159,11 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
                 # "achieved HBM GB/s on the collision sweep against the chip's peak" (BASELINE north_star): counter bytes of the
                 # pose sweep (collision checks) over its live kernel time.  Low is good here: the sweep is ALU-bound.
-                ps = tj["kernels"]["pp_k_pose_sweep"]
-                nbytes = ps.get("fetch_size_bytes", 0.0) + ps.get("write_size_bytes", 0.0)
-                sweep_hbm = {"kernel": "pp_k_pose_sweep", "pmc_bytes_per_launch": nbytes, "GBps": nbytes / (pose_ms * 1e-3) / 1e9,
+                nbytes = 0.0
+                for kname in ("pp_k_plan_skips", "pp_k_pose_sweep"):        # the interval the events bracket: planner + sweep
+                    ps = tj["kernels"].get(kname, {})
+                    nbytes += ps.get("fetch_size_bytes", 0.0) + ps.get("write_size_bytes", 0.0)
+                sweep_hbm = {"kernel": "pp_k_plan_skips+pp_k_pose_sweep", "pmc_bytes_per_launch": nbytes, "GBps": nbytes / (pose_ms * 1e-3) / 1e9,
                              "frac_of_peak": nbytes / (pose_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             except Exception:
                 traffic = None
@@ -180,14 +187,16 @@ def main():
                        "ribbons": R, "heuristic": "TspPointRobotNoSplitKRibbons K=2",
                        "edges_per_iter_per_gpu": n_edges_launch, "sharding": "sample batch split by rank, 1 all-gather/iter"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                         "achieved_is": "algorithmic bytes per edge (model, SURVEY 8d) x edges / the kernel's time measured live with HIP events",
+                         "achieved_is": "algorithmic bytes per edge (model, SURVEY 8d) x edges the kernel processed / its time measured live with HIP events",
                          "traffic": traffic, "traffic_is": ("PMC bytes per launch from profiles/traffic.json, measured on these kernel sources"
                                                             if traffic is not None else "null: no PMC pass on these kernel sources (tools/traffic.sh)"),
-                         "kernel": "pp_k_cover_sweep", "kernel_ms": kern_ms,
-                         "kernels_ms": {"pp_k_solve_edges": solve_ms, "pp_k_pose_sweep": pose_ms, "pp_k_cover_sweep": cover_ms,
-                                        "pp_k_heuristic": heur_ms},
-                         "kernels_note": "pp_k_cover_sweep includes the edges' heuristic (same wavefront, PP_FUSE_HEUR); "
-                                         "pp_k_heuristic is what is left in separate heuristic kernels (the 12-ribbon pass)",
+                         "kernel": "pp_k_cover_sweep", "kernel_ms": kern_ms, "edges_in_kernel": cover_edges,
+                         "kernels_ms": {"pp_k_solve_edges": solve_ms, "pp_k_plan_skips+pp_k_pose_sweep": pose_ms, "pp_k_cover_sweep": cover_ms,
+                                        "others": heur_ms},
+                         "kernels_note": "HIP events between the kernels of each costing launch of the timed region (last 8 steps); "
+                                         "'others' = pp_k_approach_events (finishes the edges whose coverage state machine has nothing to do: "
+                                         "edges_in_kernel is what is left for the cover sweep) + pp_k_deferred_list + pp_k_heuristic_lanes + "
+                                         "pp_k_heuristic_big; the four add up to the launch",
                          "algorithmic_bytes_per_edge": bytes_per_edge, "workspace_bytes_per_edge": workspace_bytes_per_edge,
                          "collision_sweep_hbm": sweep_hbm,
                          "note": "all four kernels are fp64-VALU bound, not HBM bound (SURVEY 8d): see valu_fp64"},

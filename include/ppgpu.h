@@ -163,14 +163,22 @@ const char* ppgpu_last_error(void);
 /* Launch on a caller-owned hipStream_t (NULL = the handle's own stream). */
 int ppgpu_set_stream(ppgpu_ctx* ctx, void* hip_stream);
 int ppgpu_synchronize(ppgpu_ctx* ctx);
-/* Measurement aid: with timing on, every costing launch records HIP events on the handle's stream between its four
- * kernels (curve solve, pose sweep, cover sweep, heuristic); ppgpu_last_timing waits for the last launch and returns their
- * durations in milliseconds.  For a launch that ran as several workspace slices the first three are summed over the slices.
- * With the point heuristics and the binary obstacle model the cover sweep's wavefront computes the edge's heuristic itself:
- * ms_cover then covers both and ms_heuristic only the separate pass over child lists of 9 to 12 ribbons.
- * The events cost a few microseconds per launch: leave timing off in production. */
+/* Measurement aid: with timing on, every costing launch records HIP events on the handle's stream between its kernels;
+ * ppgpu_last_timing waits for the last launch and returns, in milliseconds: ms_solve = pp_k_solve_edges; ms_pose = the pose
+ * sweep with its chunk-skip planner (pp_k_plan_skips + pp_k_pose_sweep); ms_cover = pp_k_cover_sweep alone; ms_heuristic =
+ * everything else of the launch (pp_k_approach_events, pp_k_deferred_list, the heuristic kernels).  The four add up to the
+ * launch.  For a launch that ran as several workspace slices each figure is summed over the slices.  On small launches, with
+ * the point heuristics and the binary obstacle model, the cover sweep's wavefront computes the edge's heuristic itself.
+ * The events cost a few microseconds per launch: leave timing off in production.
+ * ppgpu_past_timing reads an earlier launch: back = 0 is the last one, up to 7 launches back (a ring of event sets), so a
+ * caller can time several launches in a row without a host wait between them and collect the durations afterwards. */
 int ppgpu_enable_timing(ppgpu_ctx* ctx, int32_t on);
 int ppgpu_last_timing(ppgpu_ctx* ctx, double* ms_solve, double* ms_pose, double* ms_cover, double* ms_heuristic);
+int ppgpu_past_timing(ppgpu_ctx* ctx, int32_t back, double* ms_solve, double* ms_pose, double* ms_cover, double* ms_heuristic);
+/* Measurement aid: how many edges of the last costing launch pp_k_cover_sweep visited.  On large launches the approach prepass
+ * finishes the edges whose coverage state machine has nothing to do and hands the cover sweep a packed list of the others; on
+ * small launches it is every edge.  (Sliced launches: exact with timing on, the last slice's share otherwise.)  Waits for the launch. */
+int ppgpu_last_cover_edges(ppgpu_ctx* ctx, int64_t* n_edges);
 
 /* ---------------------------------------------------------------- world state */
 

@@ -35,6 +35,8 @@ def _load():
         "ppgpu_expand_host": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, C.POINTER(C.c_int64), vp, vp, vp, i32]),
         "ppgpu_enable_timing": (C.c_int, [vp, i32]),
         "ppgpu_last_timing": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]),
+        "ppgpu_past_timing": (C.c_int, [vp, i32, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]),
+        "ppgpu_last_cover_edges": (C.c_int, [vp, C.POINTER(i64)]),
         "ppgpu_set_config": (C.c_int, [vp, C.POINTER(PpgpuConfig)]),
         "ppgpu_set_grid": (C.c_int, [vp, vp, i32, i32, dbl]),
         "ppgpu_set_obstacles": (C.c_int, [vp, i32, i32, vp]),
@@ -115,6 +117,18 @@ class Context:
         t = [C.c_double() for _ in range(4)]
         self._ck(LIB.ppgpu_last_timing(self._h, *[C.byref(x) for x in t]), "ppgpu_last_timing")
         return tuple(x.value for x in t)
+
+    def past_timing(self, back):
+        """The same for the launch `back` launches ago (0 = the last one, at most 7)."""
+        t = [C.c_double() for _ in range(4)]
+        self._ck(LIB.ppgpu_past_timing(self._h, back, *[C.byref(x) for x in t]), "ppgpu_past_timing")
+        return tuple(x.value for x in t)
+
+    def last_cover_edges(self):
+        """Edges of the last costing launch that pp_k_cover_sweep visited (the others were finished by the approach prepass)."""
+        n = C.c_int64()
+        self._ck(LIB.ppgpu_last_cover_edges(self._h, C.byref(n)), "ppgpu_last_cover_edges")
+        return n.value
 
     def synchronize(self):
         self._ck(LIB.ppgpu_synchronize(self._h), "ppgpu_synchronize")

@@ -60,6 +60,7 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+#define PP_TIMING_RING 8
 struct ppgpu_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -114,9 +115,16 @@ struct ppgpu_ctx {
     DevBuf<double> track_pen, track_chunk_pen;   // Gaussian obstacle model only
     // optional per-kernel timing of costing launches (ppgpu_enable_timing)
     bool timing = false;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool ev_valid = false;
-    double ms_earlier_slices[3] = {0, 0, 0};   // solve / pose / cover time of the slices before the last one of a sliced launch
+    // a ring of event sets: the last PP_TIMING_RING launches can be read back without a host wait between them
+    hipEvent_t ev_ring[PP_TIMING_RING][6] = {};   // [0..4] as the launch goes; [5] between the approach prepass and the cover sweep
+    double ms_ring[PP_TIMING_RING][4] = {};    // solve / pose / cover / approach time of the slices before the last one of a sliced launch
+    hipEvent_t* ev = ev_ring[0];               // the set of the launch being recorded / recorded last
+    double* ms_earlier_slices = ms_ring[0];
+    int ev_slot = 0;
+    long long last_launch_edges = 0;           // edges of the last costing launch, and whether its cover sweep took a packed list
+    bool last_launch_packed = false;           // (then the list's length is at need_big[12]: last slice)
+    long long live_earlier_slices = 0;
+    long long ev_launches = 0;                 // timed launches so far
     int max_vertex_ribbons = 0;
     DevBuf<int> tmp_idx;
     DevBuf<double> ord_key;             // pp_k_expand_order: candidate scratch beyond what LDS holds, push-order output, fallback counter
@@ -182,7 +190,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->track_summary.release(); c->track_far.release(); c->track_skip.release(); c->track_carry.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->defer_list.release(); c->live_list.release(); c->work.release(); c->dstage_in.release(); c->dstage_out.release();
     if (c->stage_in) (void)hipHostFree(c->stage_in);
     if (c->stage_out) (void)hipHostFree(c->stage_out);
-    for (int i = 0; i < 5; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int r = 0; r < PP_TIMING_RING; r++) for (int i = 0; i < 6; i++) if (c->ev_ring[r][i]) (void)hipEventDestroy(c->ev_ring[r][i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PPGPU_OK;
@@ -197,22 +205,42 @@ int ppgpu_set_stream(ppgpu_ctx* c, void* s) {
 int ppgpu_enable_timing(ppgpu_ctx* c, int32_t on) {
     if (!c) return fail(PPGPU_EINVAL, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    if (on && !c->ev[0])
-        for (int i = 0; i < 5; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+    if (on && !c->ev_ring[0][0])
+        for (int r = 0; r < PP_TIMING_RING; r++) for (int i = 0; i < 6; i++) HIP_TRY(hipEventCreate(&c->ev_ring[r][i]));
     c->timing = on != 0;
-    c->ev_valid = false;
+    c->ev_launches = 0;
     return PPGPU_OK;
 }
 
-int ppgpu_last_timing(ppgpu_ctx* c, double* ms_solve, double* ms_pose, double* ms_cover, double* ms_heuristic) {
+int ppgpu_past_timing(ppgpu_ctx* c, int32_t back, double* ms_solve, double* ms_pose, double* ms_cover, double* ms_heuristic) {
     if (!c || !ms_solve || !ms_pose || !ms_cover || !ms_heuristic) return fail(PPGPU_EINVAL, "null argument");
-    if (!c->timing || !c->ev_valid) return fail(PPGPU_ESTATE, "no timed costing launch (ppgpu_enable_timing, then cost edges)");
+    if (!c->timing || c->ev_launches == 0) return fail(PPGPU_ESTATE, "no timed costing launch (ppgpu_enable_timing, then cost edges)");
+    if (back < 0 || back >= PP_TIMING_RING || back >= c->ev_launches) return fail(PPGPU_EINVAL, "past_timing: that launch is no longer (or not yet) in the ring");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipEventSynchronize(c->ev[4]));
-    float t[4] = {0, 0, 0, 0};
-    for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&t[i], c->ev[i], c->ev[i + 1]));
-    *ms_solve = t[0] + c->ms_earlier_slices[0]; *ms_pose = t[1] + c->ms_earlier_slices[1]; *ms_cover = t[2] + c->ms_earlier_slices[2];
-    *ms_heuristic = t[3];
+    const int slot = (c->ev_slot - back + PP_TIMING_RING) % PP_TIMING_RING;
+    hipEvent_t* ev = c->ev_ring[slot];
+    HIP_TRY(hipEventSynchronize(ev[4]));
+    float t[4] = {0, 0, 0, 0}, ta = 0;
+    for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&t[i], ev[i == 2 ? 5 : i], ev[i + 1]));   // the cover sweep alone: from event 5
+    HIP_TRY(hipEventElapsedTime(&ta, ev[2], ev[5]));                                                   // the approach prepass
+    *ms_solve = t[0] + c->ms_ring[slot][0]; *ms_pose = t[1] + c->ms_ring[slot][1]; *ms_cover = t[2] + c->ms_ring[slot][2];
+    *ms_heuristic = t[3] + ta + c->ms_ring[slot][3];
+    return PPGPU_OK;
+}
+int ppgpu_last_timing(ppgpu_ctx* c, double* ms_solve, double* ms_pose, double* ms_cover, double* ms_heuristic) {
+    return ppgpu_past_timing(c, 0, ms_solve, ms_pose, ms_cover, ms_heuristic);
+}
+
+int ppgpu_last_cover_edges(ppgpu_ctx* c, int64_t* n_edges) {
+    if (!c || !n_edges) return fail(PPGPU_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    *n_edges = c->last_launch_edges;
+    if (c->last_launch_packed) {
+        unsigned live = 0;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(&live, c->need_big.p + 12, sizeof(unsigned), hipMemcpyDeviceToHost));
+        *n_edges = (int64_t)live + c->live_earlier_slices;
+    }
     return PPGPU_OK;
 }
 
@@ -763,18 +791,28 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         if (rc) return rc;
         p.defer_list = c->defer_list.p; p.defer_count = c->need_big.p + 1;      // [n] = deferred edges with n ribbons
     }
-    c->ms_earlier_slices[0] = c->ms_earlier_slices[1] = c->ms_earlier_slices[2] = 0;
+    if (c->timing) {                                  // the next set of the ring
+        c->ev_slot = (int)(c->ev_launches % PP_TIMING_RING);
+        c->ev = c->ev_ring[c->ev_slot];
+        c->ms_earlier_slices = c->ms_ring[c->ev_slot];
+    }
+    c->ms_earlier_slices[0] = c->ms_earlier_slices[1] = c->ms_earlier_slices[2] = c->ms_earlier_slices[3] = 0;
     for (long long e0 = 0; e0 < total; e0 += slice) {
         p.e_base = e0; p.ws_base = 0; p.n_edges = (total - e0 < slice) ? (total - e0) : slice;
+        if (e0 == 0) c->live_earlier_slices = 0;
         if (c->timing && e0 > 0) {
             // a sliced launch re-uses the events: bank the previous slice's three durations first (timing is a measurement aid: the
             // wait costs the overlap between slices, nothing else)
             HIP_TRY(hipEventSynchronize(c->ev[3]));
             for (int i = 0; i < 3; i++) {
                 float ms = 0;
-                HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+                HIP_TRY(hipEventElapsedTime(&ms, c->ev[i == 2 ? 5 : i], c->ev[i + 1]));
                 c->ms_earlier_slices[i] += ms;
             }
+            float msa = 0;
+            HIP_TRY(hipEventElapsedTime(&msa, c->ev[2], c->ev[5]));
+            c->ms_earlier_slices[3] += msa;
+            if (p.live_list) { unsigned live = 0; HIP_TRY(hipMemcpy(&live, c->need_big.p + 12, sizeof(unsigned), hipMemcpyDeviceToHost)); c->live_earlier_slices += live; }
         }
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(pp_k_solve_edges, dim3((unsigned)((p.n_edges + 255) / 256)), dim3(256), 0, c->stream, p);
@@ -789,7 +827,8 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         else
             hipLaunchKernelGGL(pp_k_pose_sweep, dim3(resident_grid(c, 1, pp_k_pose_sweep, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-        if (p.track_far) hipLaunchKernelGGL(pp_k_approach_events, dim3((unsigned)((p.n_edges + 255) / 256)), dim3(256), 0, c->stream, p);   // timed with the cover sweep
+        if (p.track_far) hipLaunchKernelGGL(pp_k_approach_events, dim3((unsigned)((p.n_edges + 255) / 256)), dim3(256), 0, c->stream, p);
+        if (c->timing) HIP_TRY(hipEventRecord(c->ev[5], c->stream));
         if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN)
             hipLaunchKernelGGL(pp_k_cover_sweep_gaussian, dim3(resident_grid(c, 2, pp_k_cover_sweep_gaussian, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
         else
@@ -838,7 +877,8 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     // 8-byte read each)
     if (p.heuristic == PPGPU_H_TSP_POINT_K)
         hipLaunchKernelGGL(pp_k_heuristic_big, dim3(resident_grid(c, 6, pp_k_heuristic_big, total)), dim3(PP_H_WPB * 64), 0, c->stream, p);
-    if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], c->stream)); c->ev_valid = true; }
+    c->last_launch_edges = total; c->last_launch_packed = p.live_list != nullptr;
+    if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], c->stream)); c->ev_launches++; }
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;
 }

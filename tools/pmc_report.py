@@ -1,6 +1,6 @@
-import csv, collections, glob, sys
+import csv, collections, glob, os, sys
 for name in sys.argv[1:]:
-    f = glob.glob(f'gpurun_out/pmc_{name}/*/*counter_collection.csv')[0]
+    f = max(glob.glob(f"gpurun_out/pmc_{name}/*/*counter_collection.csv"), key=os.path.getmtime)
     d = collections.defaultdict(dict)
     for r in csv.DictReader(open(f)):
         if any(x in r['Kernel_Name'] for x in ('cost_edges', 'heuristic', 'pose_sweep', 'cover_sweep', 'k_sweeps')):

@@ -7,7 +7,7 @@ import collections, csv, glob, json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {"unit": "bytes per kernel launch", "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE x1; counter unit 1 KB = 1024 B", "kernels": {}}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(os.path.join(ROOT, "gpurun_out", f"traffic_{counter}", "*", "*counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(ROOT, "gpurun_out", f"traffic_{counter}", "*", "*counter_collection.csv")), key=os.path.getmtime)
     tot, calls = collections.Counter(), collections.Counter()
     seen = set()
     for r in csv.DictReader(open(f)):
