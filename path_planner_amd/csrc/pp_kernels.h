@@ -580,19 +580,24 @@ __device__ __forceinline__ void pp_plan_skips_thread(const PPParams& p) {
     // iterations on 3 700 wavefronts) this mapping takes 0.21 ms, most threads of a short edge leaving after two loads
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n_edges * p.nch) return;
-    const long long e = p.ws_base + i / p.nch;
-    const int chunk = (int)(i % p.nch), k0 = chunk * PP_WAVE;
+    long long el;
+    int chunk;
+    if (i < (1ll << 32)) { el = (long long)((unsigned)i / (unsigned)p.nch); chunk = (int)((unsigned)i - (unsigned)el * (unsigned)p.nch); }
+    else { el = i / p.nch; chunk = (int)(i - el * p.nch); }
+    const long long e = p.ws_base + el;
+    const int k0 = chunk * PP_WAVE;
     unsigned char* skipb = p.track_skip + (size_t)e * p.nch + chunk;
     const PPEdgeSetup* S = p.setup + e;
     bool ok = !(S->sflags & (PP_SETUP_MALFORMED | PP_SETUP_COLOCATED)) && S->type >= 0 && (k0 + PP_WAVE - 1 < p.ng);
     const double endTime = fmin(p.horizon + 1e-12 + p.sst, S->wEnd);
     const double* tg = p.tgrid + (size_t)(ok ? S->vi : 0) * p.ng;
+    // the four times of the chunk in one round trip (the kernel is a chain of dependent loads: every one taken out counts)
     const double tF = ok ? tg[k0] : INFINITY;
+    const double tM = ok ? tg[k0 + PP_WAVE / 2] : INFINITY, tL = ok ? tg[k0 + PP_WAVE - 1] : INFINITY;
+    const double tP = (ok && k0 > 0) ? tg[k0 - 1] : 0.0;
     if (!(tF < endTime)) { *skipb = 0; return; }               // the sweep never reaches this chunk: most threads of a short edge
     const bool cov = (S->cbits & PPGPU_EDGE_COVERAGE) != 0;
     const double wStart = S->wStart, speed = S->speed, length = S->length, rho = S->rho, rho_inv = S->rho_inv;
-    const double tM = tg[k0 + PP_WAVE / 2], tL = tg[k0 + PP_WAVE - 1];
-    const double tP = (k0 > 0) ? tg[k0 - 1] : 0.0;
     ok = tL < endTime;
     const double dP = (tP - wStart) * speed, dF = (tF - wStart) * speed, dM = (tM - wStart) * speed, dL = (tL - wStart) * speed;
     ok = ok && (dF >= 0.0) && (dL <= length);
@@ -1712,13 +1717,37 @@ __device__ __forceinline__ unsigned pp_lane_tsp_drop(unsigned srt, int c) {     
     const unsigned lowmask = (c == 0) ? 0u : ((1u << (4 * c)) - 1u);
     return (srt & lowmask) | ((srt >> 4) & ~lowmask);
 }
+// The last two levels in one piece when both remaining ribbons are branched on (K >= 2, or the All variant): eight leaves from
+// ten table entries that do not depend on one another, instead of two nested loops of dependent lookups.  The order in which
+// the two ribbons are tried does not matter for a minimum, so their sort is skipped.
+__device__ __forceinline__ double pp_lane_tsp_last2(const PPLaneTsp& c, double sf, unsigned ord, int pt) {
+    const int a = (int)(ord & 0xfu), b = (int)((ord >> 4) & 0xfu);
+    const double la = c.T[a * (2 * a + 1) + 2 * a], lb = c.T[b * (2 * b + 1) + 2 * b];
+    const double pas = c.T[pp_tri(pt, 2 * a)], pae = c.T[pp_tri(pt, 2 * a + 1)];
+    const double pbs = c.T[pp_tri(pt, 2 * b)], pbe = c.T[pp_tri(pt, 2 * b + 1)];
+    const double xss = c.T[pp_tri(2 * a, 2 * b)], xse = c.T[pp_tri(2 * a, 2 * b + 1)];
+    const double xes = c.T[pp_tri(2 * a + 1, 2 * b)], xee = c.T[pp_tri(2 * a + 1, 2 * b + 1)];
+    const double baseA = sf + la - c.twoW, baseB = sf + lb - c.twoW;
+    const double a0 = fmax(baseA + pas, 0) + lb - c.twoW;          // a from its start: now at a's end, b to go
+    const double a1 = fmax(baseA + pae, 0) + lb - c.twoW;          // a from its end: now at a's start
+    const double b0 = fmax(baseB + pbs, 0) + la - c.twoW;
+    const double b1 = fmax(baseB + pbe, 0) + la - c.twoW;
+    const double m0 = fmin(fmax(a0 + xes, 0), fmax(a0 + xee, 0));  // from a's end to b's start / end
+    const double m1 = fmin(fmax(a1 + xss, 0), fmax(a1 + xse, 0));  // from a's start
+    const double m2 = fmin(fmax(b0 + xse, 0), fmax(b0 + xee, 0));  // from b's end to a's start / end
+    const double m3 = fmin(fmax(b1 + xss, 0), fmax(b1 + xes, 0));  // from b's start
+    return fmin(fmin(m0, m1), fmin(m2, m3));
+}
 template <int REM>
 __device__ __forceinline__ double pp_lane_tsp(const PPLaneTsp& c, double sf, unsigned ord, int pt) {
     if constexpr (REM == 0) {
         return sf;
     } else {
+        if constexpr (REM == 2) {
+            if (c.K >= 2) return pp_lane_tsp_last2(c, sf, ord, pt);
+        }
         unsigned srt = ord;
-        if (REM > 1 && c.sortK) {
+        if (REM > 1 && c.sortK && REM > c.K) {               // with K >= REM every ribbon is branched on: their order is immaterial
             double key[REM];
 #pragma unroll
             for (int i = 0; i < REM; i++) {
@@ -1754,7 +1783,7 @@ __device__ __forceinline__ double pp_lane_tsp_root(const PPLaneTsp& c, const dou
 #pragma unroll
     for (int q = 0; q < 2 * N; q++) d0[q] = pp_dist(qx, qy, P[2 * q], P[2 * q + 1]);
     unsigned srt = 0x76543210u;
-    if (N > 1 && c.sortK) {
+    if (N > 1 && c.sortK && N > c.K) {
         double key[N];
 #pragma unroll
         for (int i = 0; i < N; i++) key[i] = fmin(d0[2 * i], d0[2 * i + 1]);
