@@ -7,6 +7,7 @@ lib = os.path.join(ROOT, "gpurun_out", "libppgpu_counts.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-DPP_DBG_COUNTS",
                        os.path.join(ROOT, "path_planner_amd", "csrc", "ppgpu.hip"), "-o", lib, "-ldl"])
 os.environ["PPGPU_LIB_OVERRIDE"] = lib
+os.environ["PPGPU_QUIET_FINISH"] = "0"      # the counters travel in record slots that only the wave writes
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from path_planner_amd import api, workloads
