@@ -588,17 +588,19 @@ __device__ __forceinline__ void pp_plan_skips_thread(const PPParams& p) {
     const int k0 = chunk * PP_WAVE;
     unsigned char* skipb = p.track_skip + (size_t)e * p.nch + chunk;
     const PPEdgeSetup* S = p.setup + e;
-    bool ok = !(S->sflags & (PP_SETUP_MALFORMED | PP_SETUP_COLOCATED)) && S->type >= 0 && (k0 + PP_WAVE - 1 < p.ng);
+    const bool sane = !(S->sflags & (PP_SETUP_MALFORMED | PP_SETUP_COLOCATED)) && S->type >= 0;
+    const bool whole = k0 + PP_WAVE - 1 < p.ng;                // only whole chunks can be skipped ...
     const double endTime = fmin(p.horizon + 1e-12 + p.sst, S->wEnd);
-    const double* tg = p.tgrid + (size_t)(ok ? S->vi : 0) * p.ng;
-    // the four times of the chunk in one round trip (the kernel is a chain of dependent loads: every one taken out counts)
-    const double tF = ok ? tg[k0] : INFINITY;
-    const double tM = ok ? tg[k0 + PP_WAVE / 2] : INFINITY, tL = ok ? tg[k0 + PP_WAVE - 1] : INFINITY;
-    const double tP = (ok && k0 > 0) ? tg[k0 - 1] : 0.0;
+    const double* tg = p.tgrid + (size_t)(sane ? S->vi : 0) * p.ng;
+    // ... but a chunk cut by the end of the time grid is still sampled, and if the chunk before it is skipped the sweep takes
+    // `lastHeading` from here like for any other chunk (tools/fuzz_parity.py seed 17 round 3: an edge of 291 steps on a 300-step grid)
+    const double tF = (sane && k0 < p.ng) ? tg[k0] : INFINITY;
     if (!(tF < endTime)) { *skipb = 0; return; }               // the sweep never reaches this chunk: most threads of a short edge
     const bool cov = (S->cbits & PPGPU_EDGE_COVERAGE) != 0;
     const double wStart = S->wStart, speed = S->speed, length = S->length, rho = S->rho, rho_inv = S->rho_inv;
-    ok = tL < endTime;
+    const double tM = whole ? tg[k0 + PP_WAVE / 2] : tF, tL = whole ? tg[k0 + PP_WAVE - 1] : tF;
+    const double tP = (k0 > 0) ? tg[k0 - 1] : 0.0;
+    bool ok = whole && tL < endTime;
     const double dP = (tP - wStart) * speed, dF = (tF - wStart) * speed, dM = (tM - wStart) * speed, dL = (tL - wStart) * speed;
     ok = ok && (dF >= 0.0) && (dL <= length);
     const double hs = fmax(dL - dM, dM - dF) * (1.0 + 1e-12) + 1e-9;      // how far (arc length) a step of the chunk is from the middle step
@@ -746,6 +748,10 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
         const unsigned long long skips = skipb ? __ballot((g0 + lane < p.nch) && skipb[g0 + lane] != 0) : 0ull;
         for (int ci = 0; ci < PP_WAVE; ci++) {
             const int base = (g0 + ci) * PP_WAVE;
+#ifdef PP_DBG_TRACE
+            if (pp_edge_position(p, p.e_base + (e - p.ws_base)) == (long long)(PP_DBG_TRACE) && lane == 0 && base < 400)
+                printf("[pose] chunk at %d: skip %d (eq word %llx)\n", base, (int)((skips >> ci) & 1ull), (unsigned long long)teq[base >> 6]);
+#endif
             if ((skips >> ci) & 1ull) { limit = base + PP_WAVE; afterSkip = true; continue; }
             const int k = base + lane;
             const double t = (k < p.ng) ? tg[k] : INFINITY;
@@ -795,6 +801,10 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
                 double prevHeading = __shfl_up(heading, 1, PP_WAVE);
                 if (lane == 0) prevHeading = carryHeading;
                 eqMask = __ballot(prevHeading == heading);
+#ifdef PP_DBG_TRACE
+                if (pp_edge_position(p, p.e_base + (e - p.ws_base)) == (long long)(PP_DBG_TRACE) && lane == 0 && base < 400)
+                    printf("[pose] chunk at %d sampled: carry %.17g heading0 %.17g heading1 %.17g eq %llx\n", base, prevHeading, heading, pp_readlane(heading, 1), (unsigned long long)eqMask);
+#endif
                 carryHeading = pp_readlane(heading, 63);
             }
 
@@ -1029,6 +1039,9 @@ __global__ __launch_bounds__(256) void pp_k_approach_events(PPParams p) {
                     const double qE = (ex - x) * (ex - x) + (ey - y) * (ey - y);
                     q = fmin(q, fmin(qE, qS));
                 }
+#ifdef PP_DBG_TRACE
+                if (pp_edge_position(p, p.e_base + e) == (long long)(PP_DBG_TRACE)) printf("[lane] event %d: inBox %d q %.17g x %.17g y %.17g\n", k, (int)inBox, q, x, y);
+#endif
                 if (inBox) { handOver = true; break; }                                  // within reach of a ribbon: the wavefront takes over here
                 const double D = fmin(PP_DBL_MAX, sqrt(q));
                 lastEv = k;
@@ -1138,6 +1151,11 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
 #else
 #define PP_CNT(x)
 #endif
+#ifdef PP_DBG_TRACE
+#define PP_TRACE(...) do { if (eg == (long long)(PP_DBG_TRACE) && lane == 0) printf(__VA_ARGS__); } while (0)
+#else
+#define PP_TRACE(...)
+#endif
     int rdt = -1;                       // `auto ribbonsDoneTime = -1;` is an int (Edge.cpp:92)
     int nextEvent = 0;                  // toCoverDistance starts at 0: step 0 is an event
     int lastEv = -1;
@@ -1169,13 +1187,14 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                 if (tpn > pp_const_f64(&S->tfar)[0]) {
                     const double minLength0 = 2 * w;
                     const bool tiny = (lane < nrib) & (pp_sq_len(rib.sx, rib.sy, rib.ex, rib.ey) < minLength0 * minLength0 / (2.0 * 2.0));
-                    if (__ballot(tiny) == 0ull) { PP_CNT(dbgRestFar++); break; }
+                    if (__ballot(tiny) == 0ull) { PP_TRACE("[wave] event %d: past tfar (tpn %.9g > %.9g): stop\n", nextEvent, tpn, pp_const_f64(&S->tfar)[0]); PP_CNT(dbgRestFar++); break; }
                 }
             }
 #endif
             // a window of 64 steps of the track starting AT the next event, one step per lane (stretches without events are
             // never loaded)
             const int base = nextEvent;
+            PP_TRACE("[wave] window at %d (limit %d, lastEv %d, nrib %d)\n", base, limit, lastEv, nrib);
             PP_CNT(dbgWindows++);
             const int k = base + lane;
             const double t = (k < p.ng) ? tg[k] : INFINITY;
@@ -1213,6 +1232,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
 #ifndef PP_NO_QUIET_RUN
                     else L = pp_quiet_run(rib, nrib, w, q.x, q.y, stepOk, coverMask, 0, runSpan);
 #endif
+                    PP_TRACE("[wave]   continued run (kind %d) from %d: L %d\n", cont, base, L);
                     if (L > 0) {
                         if (cont == 1 && lane == contPiece) {
                             if (contMoveEnd) { rib.ex = nsx; rib.ey = nsy; } else { rib.sx = nsx; rib.sy = nsy; }
@@ -1232,6 +1252,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                 PP_CNT(dbgGeneric++);
                 nrib = pp_ribbons_event(rib, nrib, w, xj, yj, ((coverMask >> j) & 1ull) != 0ull, lds, D, adv);
                 PP_CNT(if (adv == -3) dbgFar++; else if (adv == -2) dbgNoChange++; else if (adv >= 0) dbgInPlace++);
+                PP_TRACE("[wave]   event %d: adv %d D %.17g nrib %d cover %d x %.17g y %.17g\n", base + j, adv, D, nrib, (int)((coverMask >> j) & 1ull), xj, yj);
                 if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
 
 #ifndef PP_NO_CORRIDOR_RUN
@@ -1243,6 +1264,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                     const int L = pp_corridor_run(rib, nrib, w, piece, moveEnd, q.x, q.y, (lane < climit) & (t < endTime), coverMask, j + 1, runSpan, nsx, nsy);
                     PP_CNT(dbgCorr++; dbgCorrLen += L);
                     runFailed = (L == 0);                  // do not keep paying for attempts that do not start
+                    PP_TRACE("[wave]   corridor run from %d: L %d\n", base + j + 1, L);
                     if (L > 0) {
                         if (lane == piece) {
                             if (moveEnd) { rib.ex = nsx; rib.ey = nsy; } else { rib.sx = nsx; rib.sy = nsy; }
@@ -1258,6 +1280,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                     // inside a corridor, nothing changed: the following steps are very likely the same kind of event
                     const int L = pp_quiet_run(rib, nrib, w, q.x, q.y, (lane < climit) & (t < endTime), coverMask, j + 1, runSpan);
                     PP_CNT(dbgQuiet++; dbgQuietLen += L);
+                    PP_TRACE("[wave]   quiet run from %d: L %d\n", base + j + 1, L);
                     quietFailed = (L == 0);
                     if (L > 0) {
                         lastEv = base + j + L;

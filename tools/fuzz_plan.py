@@ -11,9 +11,11 @@ Verdict per plan() call:
             edge dumps (classify_tie): both searches consume the same number of edges in the same order, no infeasible flag
             differs, and somewhere upstream the two sides disagree in the last digits of a curve — the reference's own
             `distance - 1e-5` retry (DubinsWrapper.cpp:39-42) fired on one side only, or two Dubins words of exactly equal length
-            were told apart by the last bit of libm (DESIGN.md 4.2) — after which vertices of (near-)equal f pop in another order;
+            were told apart by the last bit of libm, or the Dubins problem itself is degenerate (collinear poses, a word on the
+            edge of existing: the glibc solver returns the host's curve when its input is moved by 1e-11) — after
+            which vertices of (near-)equal f pop in another order;
   MISMATCH  anything else (a failed check is named).
-usage: tools/fuzz_plan.py [rounds] [seed]     (tests/test_gpu_fuzz_plan.py runs the same rounds inside the suite)"""
+usage: tools/fuzz_plan.py [rounds] [seed] [round ...]     (tests/test_gpu_fuzz_plan.py runs the same rounds inside the suite)"""
 import math
 import os
 import subprocess
@@ -61,12 +63,68 @@ def edge_dumps(w, sc, mp, t0, dt, calls, init, world, prev=None, start=None):
     return H, O
 
 
+def degenerate_dubins(h, o):
+    """Two different curves from the same source: is the Dubins problem one whose answer hangs on the last bits of its input?
+    The target is read off the oracle's curve (its end pose); the problem is solved again (oracle's solver, glibc) with source
+    and target moved by 1e-13 .. 1e-11 in heading and position.  If some such perturbation returns the HOST's curve (same word,
+    length within 1e-6) the choice between the two is decided below the accuracy of any libm: two words on the edge of
+    existing, or angles of +-1e-16 that `mod2pi` turns into 0 or a full turn (kinds i and ii)."""
+    rho = float(o[9])
+    if float(h[9]) != rho:
+        return False
+    q0 = [float(o[0]), float(o[1]), orc.yaw(float(o[2]))]
+    lo_len = float(o[5] + o[6] + o[7]) * rho
+    e, q1 = orc.dubins_sample([q0[0], q0[1], q0[2], float(o[5]), float(o[6]), float(o[7]), rho, float(o[8])], lo_len)
+    if e != 0:
+        e, q1 = orc.dubins_sample([q0[0], q0[1], q0[2], float(o[5]), float(o[6]), float(o[7]), rho, float(o[8])], lo_len - 1e-9)
+        if e != 0:
+            return False
+    want_word, want_len = float(h[8]), float(h[5] + h[6] + h[7]) * rho
+    for eps in (1e-13, 1e-12, 1e-11):
+        for d0 in (-eps, 0.0, eps):
+            for d1 in (-eps, 0.0, eps):
+                for dx, dy in ((0, 0), (eps, 0), (-eps, 0), (0, eps), (0, -eps)):
+                    e, p8 = orc.dubins_shortest_path([q0[0], q0[1], q0[2] + d0], [q1[0] + dx, q1[1] + dy, q1[2] + d1], rho)
+                    if e == 0 and p8[7] == want_word and abs(float(p8[3] + p8[4] + p8[5]) * rho - want_len) <= 1e-6 * max(1.0, want_len):
+                        return True
+    return False
+
+
+def full_turns_apart(h, o):
+    """The same word with the same parameters up to whole turns of an arc: an angle of +-1e-16 that `mod2pi` made 0 on one side
+    and 2 pi on the other (collinear poses; DESIGN.md 4.2 kind ii)."""
+    if h[8] != o[8] or h[9] != o[9]:
+        return False
+    for i in range(3):
+        d = abs(float(h[5 + i]) - float(o[5 + i]))
+        straight = i == 1 and h[8] < 4
+        if not (d < 1e-9 or (not straight and abs(d - 2 * math.pi) < 1e-9)):
+            return False
+    return True
+
+
+def end_pose(row):
+    q0 = [float(row[0]), float(row[1]), orc.yaw(float(row[2]))]
+    ln = float(row[5] + row[6] + row[7]) * float(row[9])
+    p8 = [q0[0], q0[1], q0[2], float(row[5]), float(row[6]), float(row[7]), float(row[9]), float(row[8])]
+    e, q = orc.dubins_sample(p8, ln)
+    if e != 0:
+        e, q = orc.dubins_sample(p8, max(ln - 1e-9, 0.0))
+    return q
+
+
+def same_target(h, o):
+    a, b = end_pose(h), end_pose(o)
+    dth = abs(a[2] - b[2]) % (2 * math.pi)
+    return math.hypot(a[0] - b[0], a[1] - b[1]) < 1e-4 and min(dth, 2 * math.pi - dth) < 1e-4
+
+
 def classify_tie(H, O, same_length=True):
     """Is a 'tie' verdict one of the two explained kinds?  Returns (True, what) or (False, why not)."""
     if same_length and len(H) != len(O):
         return False, f"the searches consume {len(H)} and {len(O)} edges"
     rel = lambda a, b: np.abs(a - b) / np.maximum(1.0, np.abs(b))
-    word_tie = retry = False
+    word_tie = retry = degenerate = False
     for i in range(min(len(H), len(O))):
         h, o = H[i], O[i]
         if np.max(rel(h[:5], o[:5])) > 1e-4:
@@ -78,19 +136,28 @@ def classify_tie(H, O, same_length=True):
             lh, lo = (h[5] + h[6] + h[7]) * h[9], (o[5] + o[6] + o[7]) * o[9]
             same_curve = min(h[5], h[7]) <= 1e-9 and min(o[5], o[7]) <= 1e-9
             if h[9] != o[9] or (not same_curve and abs(lh - lo) > (1e-5 if retry else 1e-11) * max(1.0, abs(lo))):
+                if not same_target(h, o):
+                    break                                   # same source, another target: the order of equal-f siblings already differs
+                if degenerate_dubins(h, o):
+                    degenerate = True
+                    continue
                 return False, f"edge {i}: different Dubins words, lengths {lh!r} and {lo!r}"
             word_tie = True
             continue
         r = rel(h, o)
         if np.max(r) > 1e-4:
+            if np.max(rel(h[5:8], o[5:8])) > 1e-4 and (full_turns_apart(h, o) or (same_target(h, o) and degenerate_dubins(h, o))):
+                degenerate = True                           # the same word with an arc of 0 on one side and a full turn on the other
+                continue
             break       # same source, another target: the order of equal-f siblings already differs
         if h[11] != o[11]:
             return False, f"edge {i}: infeasible flag differs"
         if np.max(r) > 1e-12:
             retry = True                                    # same edge, last digits differ: a parent's end pose moved by <= 1e-5 m
-    if not (word_tie or retry):
+    if not (word_tie or retry or degenerate):
         return False, "no upstream difference explains the other plan: the push / pop order itself differs"
-    return True, ("equal-length Dubins words" if word_tie else "") + (" + " if word_tie and retry else "") + ("one-sided 1e-5 retry upstream" if retry else "")
+    return True, " + ".join(x for x, on in (("equal-length Dubins words", word_tie), ("one-sided 1e-5 retry upstream", retry),
+                                            ("a Dubins problem whose shortest word flips under a 1e-11 perturbation", degenerate)) if on)
 
 
 def make_round(rng, rid):
@@ -174,9 +241,13 @@ def one_round(rng, rid, d, verbose=True):
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    only = {int(x) for x in sys.argv[3:]}          # optional: replay just these rounds of the sequence
     bad = ties = calls = 0
     with tempfile.TemporaryDirectory() as d:
         for r in range(rounds):
+            if only and r not in only:
+                make_round(rng, r)                 # advance the generator as the round would have
+                continue
             for which, v, why in one_round(rng, r, d):
                 calls += 1
                 bad += v == "MISMATCH"

@@ -30,3 +30,15 @@ print(os.environ.get("PPGPU_LIB_OVERRIDE", "default"), "mismatching edges:", bad
 for b in [int(a) for a in sys.argv[1:]]:
     print(" edge", b, "gpu", hex(int(gpu["flags"][b])), (int(gpu["info"][b]) & 255, (int(gpu["info"][b]) >> 8) & 255, int(gpu["info"][b]) >> 16), "param", gpu["param"][b],
           "cpu", hex(int(cpu["flags"][b])), (int(cpu["info"][b]) & 255, (int(cpu["info"][b]) >> 8) & 255, int(cpu["info"][b]) >> 16))
+gchild = d_child.cpu().numpy().reshape(ne, 20, 4)
+cd = np.abs(gchild - cchild).max(axis=(1, 2))
+worst = np.argsort(-cd)[:4]
+print(" child ribbons: edges off by more than 1e-7 m:", np.nonzero(cd > 1e-7)[0].tolist()[:20])
+for b in worst:
+    if cd[b] <= 1e-7:
+        break
+    nr = (int(gpu["info"][b]) >> 8) & 255
+    print(" edge", int(b), "cfg", int(b) % 4, "nrib", nr, "steps", int(gpu["info"][b]) >> 16, "flags", hex(int(gpu["flags"][b])), "max diff", cd[b])
+    for i in range(nr):
+        if np.abs(gchild[b, i] - cchild[b, i]).max() > 1e-7:
+            print("    ribbon", i, "gpu", gchild[b, i].tolist(), "\n             cpu", cchild[b, i].tolist())
