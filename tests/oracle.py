@@ -239,6 +239,29 @@ def dubins_shortest_path(q0, q1, rho):
     return e, out
 
 
+def dubins_answer_hangs_on_last_bits(q0, q1, rho, want_word, want_len, draws=4000):
+    """Is (q0 -> q1, rho) a Dubins problem whose SHORTEST WORD depends on the last bits of its input?  True when this solver
+    (the reference's algorithm on glibc) returns the word `want_word` with length `want_len` (1e-6 relative) once source heading,
+    target heading or target position are moved by at most 1e-11: a fixed grid of +-1e-13 .. 1e-11 steps, then random moves with
+    magnitudes log-uniform in [1e-16, 1e-11].  That is how the differential tools tell "another libm rounds an angle of +-1e-16
+    the other way" (collinear poses: `mod2pi` returns 0 or a full turn, per word; a word on the edge of existing) from a defect."""
+    q0, q1 = [float(x) for x in q0], [float(x) for x in q1]
+
+    def hit(d0, d1, dx, dy):
+        e, p8 = dubins_shortest_path([q0[0], q0[1], q0[2] + d0], [q1[0] + dx, q1[1] + dy, q1[2] + d1], rho)
+        return e == 0 and int(p8[7]) == int(want_word) and abs(float(p8[3] + p8[4] + p8[5]) * rho - want_len) <= 1e-6 * max(1.0, want_len)
+
+    for eps in (1e-13, 1e-12, 1e-11):
+        for d0 in (-eps, 0.0, eps):
+            for d1 in (-eps, 0.0, eps):
+                for dx, dy in ((0, 0), (eps, 0), (-eps, 0), (0, eps), (0, -eps)):
+                    if hit(d0, d1, dx, dy):
+                        return True
+    rng = np.random.default_rng(12345)
+    mag = 10.0 ** rng.uniform(-16, -11, (draws, 4)) * rng.choice([-1.0, 0.0, 1.0], (draws, 4), p=[0.4, 0.2, 0.4])
+    return any(hit(*m) for m in mag)
+
+
 def dubins_sample(path8, t):
     p = f64(path8)
     q = np.zeros(3)

@@ -14,6 +14,19 @@ from parity import compare_results
 import oracle as orc
 
 
+def degenerate_dubins(cfg, vert, ti, cbits, sx, sy, sh, grec):
+    """Does the oracle's solver return the device's curve (same word, same length) when source or target are moved by <= 1e-11?"""
+    rho = cfg.coverage_turning_radius if (cbits & 1) else cfg.turning_radius
+    q0 = [float(vert["x"]), float(vert["y"]), orc.O.ppo_state_yaw(float(vert["heading"]))]
+    q1 = [float(sx[ti]), float(sy[ti]), orc.O.ppo_state_yaw(float(sh[ti]))]
+    want_word, want_len = int(grec["info"]) & 0xFF, float(grec["approx_cost"]) * cfg.max_speed
+    ok = orc.dubins_answer_hangs_on_last_bits(q0, q1, rho, want_word, want_len)
+    if not ok and os.environ.get("FUZZ_VERBOSE"):
+        print("   not degenerate: q0", [x.hex() for x in q0], "q1", [x.hex() for x in q1], "rho", rho, "device word", want_word, "length", want_len,
+              "params", [float(x) for x in grec["param"]], flush=True)
+    return ok
+
+
 def wrapper_leg(rng, ctx, world, cfg, v, pool, sx, sy, sh, dub_h, per_vertex=10):
     """Edges whose curve is given (ppgpu_cost_wrapper_edges_host, the previous plan's segments): the oracle's shortest path from
     each vertex to a few targets, at the planner's or a foreign speed, some entered part-way along (curve start time before
@@ -176,8 +189,21 @@ def one_round(rng, rid):
         cpu2, cchild2 = world.cost_edges(v, pool, sx, sy, sh, e2, stride=20)
         rep2 = compare_results(gpu2, cpu2, gchild2, cchild2, allow_word_ties=True, skip_heuristic=dub_h)
         ok2 = rep2["ok"]
+        ndeg = 0
+        if not ok2:
+            # a Dubins problem whose answer hangs on the last bits of its input (kinds i and ii: a word on the edge of
+            # existing, collinear poses): the device's word differs from the oracle's, and the oracle's own solver returns the
+            # device's curve once source or target are moved by <= 1e-11.  Such edges are counted and left out; anything else fails.
+            relap = np.abs(gpu2["approx_cost"] - cpu2["approx_cost"]) / np.maximum(1.0, np.abs(cpu2["approx_cost"]))
+            differs = np.nonzero(((gpu2["info"] & 0xFF) != (cpu2["info"] & 0xFF)) & ((cpu2["flags"] & 2) == 0) & (relap > 1e-12))[0]
+            deg = [int(b) for b in differs if degenerate_dubins(cfg, v[int(e2[b] >> np.uint64(32)) & 0xFFFFFF], int(e2[b] & np.uint64(0xFFFFFFFF)),
+                                                                int(e2[b] >> np.uint64(56)), sx, sy, sh, gpu2[b])]
+            if len(deg) == len(differs) and len(deg) > 0:
+                keep2 = np.ones(len(e2), dtype=bool); keep2[deg] = False
+                rep2 = compare_results(gpu2[keep2], cpu2[keep2], gchild2[keep2], cchild2[keep2], allow_word_ties=True, skip_heuristic=dub_h)
+                ok2, ndeg = rep2["ok"], len(deg)
         print("    second generation:", len(e2), "edges from", len(pick), "children ->", "ok" if ok2 else "MISMATCH", "worst_rel %.2e" % rep2["worst_rel"],
-              "word ties", rep2["n_word_ties"], flush=True)
+              "word ties", rep2["n_word_ties"], ("degenerate Dubins problems %d" % ndeg) if ndeg else "", flush=True)
         if not ok2:
             print(rep2, flush=True)
             badh = np.nonzero(np.abs(gpu2["h"] - cpu2["h"]) > 1e-5 * np.maximum(1.0, np.abs(cpu2["h"])))[0]

@@ -80,14 +80,7 @@ def degenerate_dubins(h, o):
         if e != 0:
             return False
     want_word, want_len = float(h[8]), float(h[5] + h[6] + h[7]) * rho
-    for eps in (1e-13, 1e-12, 1e-11):
-        for d0 in (-eps, 0.0, eps):
-            for d1 in (-eps, 0.0, eps):
-                for dx, dy in ((0, 0), (eps, 0), (-eps, 0), (0, eps), (0, -eps)):
-                    e, p8 = orc.dubins_shortest_path([q0[0], q0[1], q0[2] + d0], [q1[0] + dx, q1[1] + dy, q1[2] + d1], rho)
-                    if e == 0 and p8[7] == want_word and abs(float(p8[3] + p8[4] + p8[5]) * rho - want_len) <= 1e-6 * max(1.0, want_len):
-                        return True
-    return False
+    return orc.dubins_answer_hangs_on_last_bits(q0, q1, rho, want_word, want_len)
 
 
 def full_turns_apart(h, o):
