@@ -221,7 +221,7 @@ def kernel_sources_sha256():
     """Identity of the kernel sources a PMC measurement belongs to (profiles/traffic.json carries the same stamp)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("ppgpu.hip", "pp_kernels.h", "pp_device.h", "pp_sampler.h"):
+    for f in ("ppgpu.hip", "pp_kernels.h", "pp_device.h", "pp_sampler.h", "pp_cr.h", "pp_cr_tables.h"):
         h.update(open(os.path.join(ROOT, "path_planner_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 

@@ -163,6 +163,12 @@ const char* ppgpu_last_error(void);
 /* Launch on a caller-owned hipStream_t (NULL = the handle's own stream). */
 int ppgpu_set_stream(ppgpu_ctx* ctx, void* hip_stream);
 int ppgpu_synchronize(ppgpu_ctx* ctx);
+/* Size the buffers that grow with the sample set — the sample store, the sampler's scratch, the length table and candidate lists
+ * of ppgpu_expand_host for batches of up to max_vertices open vertices — for max_samples samples now, so that an anytime planner
+ * that doubles its sample set every iteration (AStarPlanner.cpp:101-102) never meets a device allocation inside its time budget.
+ * Optional: without it the buffers grow on demand (powers of two) and stay for the life of the handle.  8 million samples and
+ * 16 vertices take 2.3 GB of the 288 GB. */
+int ppgpu_reserve_samples(ppgpu_ctx* ctx, int64_t max_samples, int32_t max_vertices);
 /* Measurement aid: with timing on, every costing launch records HIP events on the handle's stream between its kernels;
  * ppgpu_last_timing waits for the last launch and returns, in milliseconds: ms_solve = pp_k_solve_edges; ms_pose = the pose
  * sweep with its chunk-skip planner (pp_k_plan_skips + pp_k_pose_sweep); ms_cover = pp_k_cover_sweep alone; ms_heuristic =

@@ -30,6 +30,7 @@ def _load():
         "ppgpu_last_error": (C.c_char_p, []),
         "ppgpu_set_stream": (C.c_int, [vp, vp]),
         "ppgpu_synchronize": (C.c_int, [vp]),
+        "ppgpu_reserve_samples": (C.c_int, [vp, i64, i32]),
         "ppgpu_heuristic_host": (C.c_int, [vp, i32, vp, vp, vp, vp, vp]),
         "ppgpu_expand_capacity": (C.c_int64, [i32, i32]),
         "ppgpu_expand_host": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, C.POINTER(C.c_int64), vp, vp, vp, i32]),
@@ -129,6 +130,9 @@ class Context:
         n = C.c_int64()
         self._ck(LIB.ppgpu_last_cover_edges(self._h, C.byref(n)), "ppgpu_last_cover_edges")
         return n.value
+
+    def reserve_samples(self, max_samples, max_vertices=16):
+        self._ck(LIB.ppgpu_reserve_samples(self._h, max_samples, max_vertices), "ppgpu_reserve_samples")
 
     def synchronize(self):
         self._ck(LIB.ppgpu_synchronize(self._h), "ppgpu_synchronize")

@@ -140,6 +140,32 @@ __device__ __forceinline__ void pp_sincos_bounded(double x, double* sn, double* 
     *cs = ((n + 1) & 2) ? -c2 : c2;
 }
 
+// ----------------------------------------------------------------------------- correctly rounded sin / cos / atan2 / acos (pp_cr.h)
+#define PP_CR_FN __device__ __forceinline__
+#define PP_CR_CONST static __device__ const
+#include "pp_cr.h"
+__device__ __forceinline__ void pp_cr_sincos(double x, double* sn, double* cs) {
+    if (!(fabs(x) < PP_CR_MAX_ARG)) { sincos(x, sn, cs); return; }
+    PPdd s, c;
+    pp_cr_sincos_dd(x, &s, &c);
+    *sn = s.h + s.l; *cs = c.h + c.l;
+}
+__device__ __forceinline__ double pp_cr_atan2(double y, double x) {
+    const double t0 = atan2(y, x);
+    // zeros, the axes and non-finite input: the library's value is exact (0, +-pi/2, +-pi are what the reference returns too)
+    if (x == 0.0 || y == 0.0 || !(fabs(t0) > 1e-300) || !isfinite(x) || !isfinite(y)) return t0;
+    PPdd s, c;
+    pp_cr_sincos_dd(t0, &s, &c);
+    return pp_cr_atan2_step(y, x, t0, s, c);
+}
+__device__ __forceinline__ double pp_cr_acos(double v) {
+    const double t0 = acos(v);
+    if (!(fabs(v) < 1.0) || t0 == 0.0) return t0;              // +-1 (exact 0 / pi) and out-of-range input (NaN)
+    PPdd s, c;
+    pp_cr_sincos_dd(t0, &s, &c);
+    return pp_cr_acos_step(v, t0, s, c);
+}
+
 // ----------------------------------------------------------------------------- Dubins
 // Third-party `dubins_curves` C library (absent from the reference tree).  Same published
 // six-word formulation as path_planner_amd/csrc/dubins.c (the host library behind
@@ -170,7 +196,16 @@ __device__ __forceinline__ int pp_seg_type(int word, int i) {
 }
 
 // dubins_shortest_path(): normalise, evaluate the six words in enum order, keep the first
-// strictly-smallest t+p+q.
+// strictly-smallest t+p+q.  CR = true: every atan2 / acos / sin / cos is the correctly rounded one (pp_cr.h) — the edges the planner
+// builds (pp_k_solve_edges); CR = false: the device library's — the lengths that only rank samples (pp_k_dubins_lengths, the
+// push-order pipeline) and the Dubins-TSP heuristics' tables, where an ulp cannot change what comes out.
+template <bool CR>
+__device__ __forceinline__ double pp_dub_atan2(double y, double x) { if constexpr (CR) return pp_cr_atan2(y, x); else return atan2(y, x); }
+template <bool CR>
+__device__ __forceinline__ double pp_dub_acos(double v) { if constexpr (CR) return pp_cr_acos(v); else return acos(v); }
+template <bool CR>
+__device__ __forceinline__ void pp_dub_sincos(double x, double* s, double* c) { if constexpr (CR) pp_cr_sincos(x, s, c); else pp_sincos(x, s, c); }
+template <bool CR = false>
 __device__ inline void pp_dubins_shortest(double q0x, double q0y, double q0t, double q1x, double q1y, double q1t,
                                           double rho, PPDubins& out) {
     double dx = q1x - q0x;
@@ -178,14 +213,14 @@ __device__ inline void pp_dubins_shortest(double q0x, double q0y, double q0t, do
     double D = sqrt(dx * dx + dy * dy);
     double d = D / rho;
     double theta = 0;
-    if (d > 0) theta = pp_mod2pi(atan2(dy, dx));
+    if (d > 0) theta = pp_mod2pi(pp_dub_atan2<CR>(dy, dx));
     double alpha = pp_mod2pi(q0t - theta);
     double beta = pp_mod2pi(q1t - theta);
     double sa, ca, sb, cb;
-    pp_sincos(alpha, &sa, &ca);
-    pp_sincos(beta, &sb, &cb);
+    pp_dub_sincos<CR>(alpha, &sa, &ca);
+    pp_dub_sincos<CR>(beta, &sb, &cb);
     double c_ab, s_ab_unused;
-    pp_sincos(alpha - beta, &s_ab_unused, &c_ab);
+    pp_dub_sincos<CR>(alpha - beta, &s_ab_unused, &c_ab);
     double d_sq = d * d;
 
     double best = INFINITY;
@@ -196,7 +231,7 @@ __device__ inline void pp_dubins_shortest(double q0x, double q0y, double q0t, do
         double tmp0 = d + sa - sb;
         double p_sq = 2 + d_sq - (2 * c_ab) + (2 * d * (sa - sb));
         if (p_sq >= 0) {
-            double tmp1 = atan2((cb - ca), tmp0);
+            double tmp1 = pp_dub_atan2<CR>((cb - ca), tmp0);
             t = pp_mod2pi(tmp1 - alpha);
             p = sqrt(p_sq);
             q = pp_mod2pi(beta - tmp1);
@@ -208,7 +243,7 @@ __device__ inline void pp_dubins_shortest(double q0x, double q0y, double q0t, do
         double p_sq = -2 + (d_sq) + (2 * c_ab) + (2 * d * (sa + sb));
         if (p_sq >= 0) {
             p = sqrt(p_sq);
-            double tmp0 = atan2((-ca - cb), (d + sa + sb)) - atan2(-2.0, p);
+            double tmp0 = pp_dub_atan2<CR>((-ca - cb), (d + sa + sb)) - pp_dub_atan2<CR>(-2.0, p);
             t = pp_mod2pi(tmp0 - alpha);
             q = pp_mod2pi(tmp0 - pp_mod2pi(beta));
             double cost = t + p + q;
@@ -219,7 +254,7 @@ __device__ inline void pp_dubins_shortest(double q0x, double q0y, double q0t, do
         double p_sq = -2 + d_sq + (2 * c_ab) - (2 * d * (sa + sb));
         if (p_sq >= 0) {
             p = sqrt(p_sq);
-            double tmp0 = atan2((ca + cb), (d - sa - sb)) - atan2(2.0, p);
+            double tmp0 = pp_dub_atan2<CR>((ca + cb), (d - sa - sb)) - pp_dub_atan2<CR>(2.0, p);
             t = pp_mod2pi(alpha - tmp0);
             q = pp_mod2pi(beta - tmp0);
             double cost = t + p + q;
@@ -230,7 +265,7 @@ __device__ inline void pp_dubins_shortest(double q0x, double q0y, double q0t, do
         double tmp0 = d - sa + sb;
         double p_sq = 2 + d_sq - (2 * c_ab) + (2 * d * (sb - sa));
         if (p_sq >= 0) {
-            double tmp1 = atan2((ca - cb), tmp0);
+            double tmp1 = pp_dub_atan2<CR>((ca - cb), tmp0);
             t = pp_mod2pi(alpha - tmp1);
             p = sqrt(p_sq);
             q = pp_mod2pi(tmp1 - beta);
@@ -240,9 +275,9 @@ __device__ inline void pp_dubins_shortest(double q0x, double q0y, double q0t, do
     }
     {  // RLR
         double tmp0 = (6. - d_sq + 2 * c_ab + 2 * d * (sa - sb)) / 8.;
-        double phi = atan2(ca - cb, d - sa + sb);
+        double phi = pp_dub_atan2<CR>(ca - cb, d - sa + sb);
         if (fabs(tmp0) <= 1) {
-            p = pp_mod2pi((PP_TWO_PI) - acos(tmp0));
+            p = pp_mod2pi((PP_TWO_PI) - pp_dub_acos<CR>(tmp0));
             t = pp_mod2pi(alpha - phi + pp_mod2pi(p / 2.));
             q = pp_mod2pi(alpha - beta - t + pp_mod2pi(p));
             double cost = t + p + q;
@@ -251,9 +286,9 @@ __device__ inline void pp_dubins_shortest(double q0x, double q0y, double q0t, do
     }
     {  // LRL
         double tmp0 = (6. - d_sq + 2 * c_ab + 2 * d * (sb - sa)) / 8.;
-        double phi = atan2(ca - cb, d + sa - sb);
+        double phi = pp_dub_atan2<CR>(ca - cb, d + sa - sb);
         if (fabs(tmp0) <= 1) {
-            p = pp_mod2pi(PP_TWO_PI - acos(tmp0));
+            p = pp_mod2pi(PP_TWO_PI - pp_dub_acos<CR>(tmp0));
             t = pp_mod2pi(-alpha - phi + p / 2.);
             q = pp_mod2pi(pp_mod2pi(beta) - alpha - t + pp_mod2pi(p));
             double cost = t + p + q;
@@ -273,17 +308,18 @@ __device__ __forceinline__ double pp_dubins_length(const PPDubins& d, double rho
 
 // One Dubins segment advanced by t from (bx, by, bth) with sin/cos(bth) precomputed
 // (dubins_segment()).  Writes the un-normalised pose.
+template <bool CR = false>
 __device__ __forceinline__ void pp_segment(int type, double t, double bx, double by, double bth, double sb, double cb,
                                            double& x, double& y, double& th) {
     if (type == 0) {  // L
         double s, c;
-        pp_sincos(bth + t, &s, &c);
+        pp_dub_sincos<CR>(bth + t, &s, &c);
         x = (+s - sb) + bx;
         y = (-c + cb) + by;
         th = t + bth;
     } else if (type == 2) {  // R
         double s, c;
-        pp_sincos(bth - t, &s, &c);
+        pp_dub_sincos<CR>(bth - t, &s, &c);
         x = (-s + sb) + bx;
         y = (+c - cb) + by;
         th = -t + bth;
@@ -305,6 +341,7 @@ struct PPCurve {
     double s0, c0, s1, c1, s2, c2;             // sin/cos of the three base headings
 };
 
+template <bool CR = false>
 __device__ inline void pp_curve_init(PPCurve& c, double qx, double qy, double qth, double rho, const PPDubins& d) {
     c.qx = qx; c.qy = qy; c.qth = qth; c.rho = rho;
     {
@@ -315,11 +352,11 @@ __device__ inline void pp_curve_init(PPCurve& c, double qx, double qy, double qt
     c.length = pp_dubins_length(d, rho);
     int w = d.type < 0 ? 0 : d.type;
     c.t0 = pp_seg_type(w, 0); c.t1 = pp_seg_type(w, 1); c.t2 = pp_seg_type(w, 2);
-    pp_sincos(qth, &c.s0, &c.c0);
-    pp_segment(c.t0, d.p0, 0.0, 0.0, qth, c.s0, c.c0, c.b1x, c.b1y, c.b1th);
-    pp_sincos(c.b1th, &c.s1, &c.c1);
-    pp_segment(c.t1, d.p1, c.b1x, c.b1y, c.b1th, c.s1, c.c1, c.b2x, c.b2y, c.b2th);
-    pp_sincos(c.b2th, &c.s2, &c.c2);
+    pp_dub_sincos<CR>(qth, &c.s0, &c.c0);
+    pp_segment<CR>(c.t0, d.p0, 0.0, 0.0, qth, c.s0, c.c0, c.b1x, c.b1y, c.b1th);
+    pp_dub_sincos<CR>(c.b1th, &c.s1, &c.c1);
+    pp_segment<CR>(c.t1, d.p1, c.b1x, c.b1y, c.b1th, c.s1, c.c1, c.b2x, c.b2y, c.b2th);
+    pp_dub_sincos<CR>(c.b2th, &c.s2, &c.c2);
 }
 // one segment of dubins_path_sample(): advance by tt from base (bx, by, bth) whose sin/cos are (sb, cb)
 __device__ __forceinline__ void pp_curve_seg(int type, double tt, double bx, double by, double bth, double sb, double cb,

@@ -359,6 +359,9 @@ __device__ __forceinline__ long long pp_next_edge(const PPParams& p, int kern, P
     }
     return n;
 }
+#ifndef PP_CR_SOLVE
+#define PP_CR_SOLVE true     // the edges' curves with correctly rounded atan2 / acos / sin / cos (pp_cr.h)
+#endif
 __global__ __launch_bounds__(256) void pp_k_solve_edges(PPParams p) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     // the queue heads of the kernels that follow (all of them start after this kernel has ended, in stream order)
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(256) void pp_k_solve_edges(PPParams p) {
     dub.p0 = dub.p1 = dub.p2 = 0; dub.type = -1;
     if (vi >= (unsigned)p.nverts || (!p.wedges && (long long)target >= p.n_samples)) {
         S.sflags = PP_SETUP_MALFORMED;
-        pp_curve_init(cv, 0, 0, 0, 1.0, dub);
+        pp_curve_init<false>(cv, 0, 0, 0, 1.0, dub);
     } else {
         const ppgpu_vertex* V = p.verts + vi;
         const double srcX = V->x, srcY = V->y, srcH = V->heading, srcT = V->time;
@@ -390,14 +393,14 @@ __global__ __launch_bounds__(256) void pp_k_solve_edges(PPParams p) {
             dub.p0 = W->param[0]; dub.p1 = W->param[1]; dub.p2 = W->param[2]; dub.type = W->type;
             if (dub.type < 0 || dub.type > 5) dub.type = -1;
             rho = W->rho; speed = W->speed;
-            pp_curve_init(cv, W->qi[0], W->qi[1], W->qi[2], rho, dub);
+            pp_curve_init<PP_CR_SOLVE>(cv, W->qi[0], W->qi[1], W->qi[2], rho, dub);
             S.wStart = W->start_time; S.wEnd = W->end_time;
             S.approx = (S.wEnd - srcT) * 1.0;                         // Edge::setEnd(wrapper), Edge.cpp:208-216
         } else {
             const double tgtX = p.sx[target], tgtY = p.sy[target], tgtH = p.sh[target];
             if ((srcX == tgtX) && (srcY == tgtY) && (srcH == tgtH)) S.sflags |= PP_SETUP_COLOCATED;   // State::isCoLocated
-            pp_dubins_shortest(srcX, srcY, pp_yaw(srcH), tgtX, tgtY, pp_yaw(tgtH), rho, dub);
-            pp_curve_init(cv, srcX, srcY, pp_yaw(srcH), rho, dub);
+            pp_dubins_shortest<PP_CR_SOLVE>(srcX, srcY, pp_yaw(srcH), tgtX, tgtY, pp_yaw(tgtH), rho, dub);
+            pp_curve_init<PP_CR_SOLVE>(cv, srcX, srcY, pp_yaw(srcH), rho, dub);
             S.approx = cv.length / speed * 1.0;                     // Edge.cpp:17
             S.wStart = srcT;
             S.wEnd = srcT + cv.length / speed;                      // DubinsWrapper::setEndTime
@@ -2074,9 +2077,11 @@ __global__ __launch_bounds__(256) void pp_k_select_nearest(const double* lengths
 //      root, pushed onto a full heap of pairwise distinct costs and popped again, leaves the array exactly as it was (the hole
 //      sinks along the path the push shifted down and every element returns to its slot), so only the candidates at or below
 //      the current root — a few dozen of the hundreds to thousands — are taken through the exact steps.
-// More than PP_ORD_CAP candidates (4 096: a sample set of about a million), k above 63, or equal costs inside a heap fall back to
-// ascending length and raise *fallbacks (the caller reports it).
-#define PP_ORD_CAP 4096
+// Equal costs are handled exactly: the heap steps are libstdc++'s, and a candidate above the root is only skipped while no pair of
+// equal costs sits where the pop would take another way down than the push came up (`safe`, in the kernel).  More than PP_ORD_CAP
+// candidates (8 192 after the ring filter), k above 63, or such a pair turning up while the ring filter has dropped
+// candidates fall back to ascending length and raise *fallbacks (the caller reports it).
+#define PP_ORD_CAP 8192
 struct PPOrdHeap { double cost, len; int idx; };
 __device__ __forceinline__ void pp_ord_set(PPOrdHeap& h, int slot, double cost, double len, int idx) {   // slot and values are wave-uniform
     const bool mine = pp_lane() == slot;
@@ -2240,9 +2245,8 @@ __global__ __launch_bounds__(256) void pp_k_expand_candidates(const double* leng
 __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, double max_speed, double tpf, int two_radii, const double* bound,
                                                          const double* g_key, const int* g_val, const double* g_len, long long g_cap,
                                                          const int* cand_count, int* out_idx, unsigned* fallbacks) {
-    __shared__ double cd[PP_ORD_CAP];        // 80 KB of the CU's 160 KB LDS: distance, length, list position / sample index
-    __shared__ double cl[PP_ORD_CAP];
-    __shared__ int ci[PP_ORD_CAP];
+    __shared__ double cd[PP_ORD_CAP];        // 96 KB of the CU's 160 KB LDS: distance and list position (later sample index); the lengths
+    __shared__ int ci[PP_ORD_CAP];           // stay in the list in memory and are fetched by position when the replay gets there
     __shared__ double inner[PP_ORD_INNER];
     __shared__ int nInner, nKept;
     __shared__ double threshold;
@@ -2268,15 +2272,25 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
     if (tid == 0) { nInner = 0; nKept = 0; threshold = INFINITY; }
     __syncthreads();
     const bool filter = !fallback && (U < INFINITY) && M > 512;
-    const double dq = 0.25 * U;
+    double dq = 0.25 * U;
     if (filter) {
-        for (int i = tid; i < M; i += 256)
-            if (gk[i] <= dq) {
-                const int slot = atomicAdd(&nInner, 1);
-                if (slot < PP_ORD_INNER) inner[slot] = gl[i] / max_speed * tpf;
-            }
-        __syncthreads();
-        const int n = nInner;
+        int n = 0;
+        for (int attempt = 0; attempt < 12; attempt++) {
+            for (int i = tid; i < M; i += 256)
+                if (gk[i] <= dq) {
+                    const int slot = atomicAdd(&nInner, 1);
+                    if (slot < PP_ORD_INNER) inner[slot] = gl[i] / max_speed * tpf;
+                }
+            __syncthreads();
+            n = nInner;
+            if (n <= PP_ORD_INNER) break;
+            // a crowded ring (tens of thousands of samples under a loose bound): any ring with at least k candidates will do,
+            // halving the radius leaves about a quarter of them
+            __syncthreads();
+            if (tid == 0) nInner = 0;
+            dq *= 0.5;
+            __syncthreads();
+        }
         if (n >= k && n <= PP_ORD_INNER)
             for (int i = tid; i < n; i += 256) {
                 const double x = inner[i];
@@ -2294,7 +2308,7 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
         const double d = gk[i], len = gl[i];
         if (d <= dq || !(len / max_speed * tpf > T)) {
             const int slot = atomicAdd(&nKept, 1);
-            if (slot < PP_ORD_CAP) { cd[slot] = d; cl[slot] = len; ci[slot] = i; }
+            if (slot < PP_ORD_CAP) { cd[slot] = d; ci[slot] = i; }
         }
     }
     __syncthreads();
@@ -2306,7 +2320,7 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
     if (!fallback) {
         int n2 = 64;
         while (n2 < Mk) n2 <<= 1;
-        for (int i = Mk + tid; i < n2; i += 256) { cd[i] = INFINITY; cl[i] = INFINITY; ci[i] = 0x7fffffff; }
+        for (int i = Mk + tid; i < n2; i += 256) { cd[i] = INFINITY; ci[i] = 0x7fffffff; }
         // by (distance, sample index): list positions are not in sample order, so equal distances compare their samples
         for (int size = 2; size <= n2; size <<= 1)
             for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -2317,14 +2331,9 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
                     const int vi = ci[i], vj = ci[j];
                     bool gt = ki > kj;
                     if (ki == kj) gt = (vi == 0x7fffffff) ? (vj != 0x7fffffff) : (vj != 0x7fffffff && gv[vi] > gv[vj]);
-                    if (gt == ((i & size) == 0)) {
-                        const double li = cl[i], lj = cl[j];
-                        cd[i] = kj; cd[j] = ki; ci[i] = vj; ci[j] = vi; cl[i] = lj; cl[j] = li;
-                    }
+                    if (gt == ((i & size) == 0)) { cd[i] = kj; cd[j] = ki; ci[i] = vj; ci[j] = vi; }
                 }
             }
-        __syncthreads();
-        for (int i = tid; i < Mk; i += 256) ci[i] = gv[ci[i]];                // list position -> sample index
         __syncthreads();
     }
 #ifdef PP_DBG_ORD
@@ -2336,39 +2345,62 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
     PPOrdHeap h;
     h.cost = INFINITY; h.len = INFINITY; h.idx = -1;
     int hsize = 0;
-    bool dup = false, stopped = false;
+    bool unsafeFiltered = false, stopped = false;
+    // Skipping a candidate above the root is only right if pushing and popping it would put every element back (see above).  The
+    // push shifts the ancestors of slot k down along their path and the pop's hole walks down again choosing the larger child,
+    // the RIGHT one on equal costs: it retraces the path unless some ancestor whose path child is its left child has a right
+    // child of EQUAL cost, or k is a right child whose left sibling equals their parent (then the two equal entries trade
+    // places).  `safe` says that no such pair exists in the full heap as it stands; it changes only when the heap does.
+    bool safe = true;
+    auto heapSafe = [&]() -> bool {
+        bool ok = true;
+        for (int c = k; c > 0; c = (c - 1) >> 1) {
+            const int par = (c - 1) >> 1;
+            if (c & 1) { if (c + 1 < k) ok = ok && (pp_readlane(h.cost, c + 1) < pp_readlane(h.cost, par)); }
+            else if (c == k) ok = ok && (pp_readlane(h.cost, k - 1) < pp_readlane(h.cost, par));
+        }
+        return ok;
+    };
     if (!fallback) {
-        for (int base = 0; base < Mk && !stopped && !dup; base += PP_WAVE) {
+        for (int base = 0; base < Mk && !stopped && !unsafeFiltered; base += PP_WAVE) {
             const int c = base + lane;
             const bool have = c < Mk;
             const double d = have ? cd[c] : INFINITY;
-            const double len = have ? cl[c] : INFINITY;
-            const int idx = have ? ci[c] : -1;
+            const int pos = have ? ci[c] : 0;                           // position in the candidate list
+            const double len = have ? gl[pos] : INFINITY;
+            const int idx = have ? gv[pos] : -1;
             const double cost = len / max_speed * tpf;                 // Edge::computeApproxCost (Edge.cpp:17)
-            // the candidates of this chunk that can change the heap: every one while it is not full, afterwards those at or below the
-            // root's cost as it stands at the start of the chunk (the root only ever gets cheaper)
-            unsigned long long todo = (hsize < k) ? __ballot(have) : __ballot(have & (cost <= pp_readlane(h.cost, 0)));
-            if (hsize >= k && todo == 0ull) {
+            // the candidates of this chunk that can change the heap: every one while it is not full (or not `safe`), afterwards
+            // those at or below the root's cost as it stands at the start of the chunk (the root only ever gets cheaper)
+            unsigned long long rest = __ballot(have);
+            const unsigned long long low = __ballot(have & (cost <= pp_readlane(h.cost, 0)));
+            if (hsize >= k && safe && low == 0ull) {
                 // nobody enters the heap; the scan still ends at the first distance the worst kept length does not exceed
                 if (__ballot(have & !(pp_readlane(h.len, 0) > d)) != 0ull) stopped = true;
                 continue;
             }
-            while (todo) {
-                const int j = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
+            while (true) {
+                const unsigned long long cand = (hsize < k || !safe) ? rest : (rest & low);
+                if (!cand) break;
+                const int j = __ffsll((long long)cand) - 1;
+                rest &= ~((2ull << j) - 1ull);                          // j and the candidates before it (no-ops in this state) are done
                 const double dj = pp_readlane(d, j), lj = pp_readlane(len, j), cj = pp_readlane(cost, j);
                 const int ij = pp_readlane_i(idx, j);
                 if (hsize >= k) {
                     if (!(pp_readlane(h.len, 0) > dj)) { stopped = true; break; }        // :104-106, else branch :130-132
-                    if (cj > pp_readlane(h.cost, 0)) continue;                            // the root moved since the chunk began: a no-op
+                    if (safe && cj > pp_readlane(h.cost, 0)) continue;                    // the root moved since the chunk began: a no-op
                 }
-                if (__ballot((lane < hsize) & (h.cost == cj)) != 0ull) { dup = true; break; }
 #ifdef PP_DBG_ORD
                 nexact++;
 #endif
                 pp_ord_sift_up(h, hsize, cj, lj, ij);                                     // push_back + std::push_heap
                 hsize++;
                 if (hsize > k) { hsize--; pp_ord_pop(h, hsize); }                         // std::pop_heap + pop_back
+                if (hsize >= k) {
+                    safe = heapSafe();
+                    // the ring filter dropped candidates on the strength of "a no-op whenever its turn comes": not in this state
+                    if (!safe && Mk < M) { unsafeFiltered = true; break; }
+                }
             }
         }
     }
@@ -2376,9 +2408,12 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
     tk4 = wall_clock64();
     if (lane == 0 && vr < 4) printf("[ord] vr %d M %d inner %d kept %d exact %d | filter %lld keep %lld sort %lld replay %lld (x10ns)\n", vr, M, nInner, Mk, nexact, tk1 - tk0, tk2 - tk1, tk3 - tk2, tk4 - tk3);
 #endif
-    if (fallback || dup) {
+    if (fallback || unsafeFiltered) {
         // keep what a plain selection gives: the k cheapest of the list, ascending by (length, sample); only the push order is lost
         if (lane == 0) atomicAdd(fallbacks, 1u);
+#ifdef PP_DBG_ORD
+        if (lane == 0) printf("[ord] FALLBACK vr %d: k %d M %d cap %lld kept %d unsafeFiltered %d hsize %d\n", vr, k, M, g_cap, Mk, (int)unsafeFiltered, hsize);
+#endif
         const int Mc = (long long)M < g_cap ? M : (int)g_cap;
         double prevL = -INFINITY; int prevI = -1;
         for (int j = 0; j < k; j++) {

@@ -244,6 +244,26 @@ int ppgpu_last_cover_edges(ppgpu_ctx* c, int64_t* n_edges) {
     return PPGPU_OK;
 }
 
+int ppgpu_reserve_samples(ppgpu_ctx* c, int64_t max_samples, int32_t max_vertices) {
+    if (!c) return fail(PPGPU_EINVAL, "null context");
+    if (max_samples <= 0 || max_vertices <= 0) return fail(PPGPU_EINVAL, "reserve_samples: sizes must be positive");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t ns = (size_t)max_samples, nv = (size_t)max_vertices;
+    const size_t nblk = (ns + 255) / 256;
+    size_t cap = 64;
+    while (cap < ns && cap < 65536) cap <<= 1;
+    const size_t nq = 6 * (size_t)524288 + 8;                   // the sampler's largest batch (ppgpu_sampler_add)
+    int rc;
+    if ((rc = c->sx.reserve(ns + nv, true, st)) || (rc = c->sy.reserve(ns + nv, true, st)) || (rc = c->sh.reserve(ns + nv, true, st)) ||
+        (rc = c->s_cand.reserve((size_t)524288 * 3, false, st)) || (rc = c->s_bytes.reserve(nq + 64, false, st)) || (rc = c->s_u32a.reserve(nq + 64, false, st)) ||
+        (rc = c->tmp_lengths.reserve(nv * ns * 2, false, st)) ||
+        (rc = c->ord_key.reserve(nv * 2 * cap, false, st)) || (rc = c->ord_val.reserve(nv * 2 * cap, false, st)) || (rc = c->ord_len.reserve(nv * 2 * cap, false, st)) ||
+        (rc = c->ord_blockmin.reserve(nv * nblk * 2, false, st)) || (rc = c->ord_blockcnt.reserve(nv * nblk, false, st)))
+        return rc;
+    return PPGPU_OK;
+}
+
 int ppgpu_synchronize(ppgpu_ctx* c) {
     if (!c) return fail(PPGPU_EINVAL, "null context");
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -75,6 +75,13 @@ Planner::Stats Planner::plan(const RibbonManager&, const State&, PlannerConfig c
 // ------------------------------------------------------------------------------------------------ GpuContext
 GpuContext::GpuContext(int device) : m_Device(device) {
     if (ppgpu_create(device, &m_Handle) != PPGPU_OK) throw std::runtime_error(std::string("ppgpu_create: ") + ppgpu_last_error());
+    // The anytime search doubles its sample set every iteration; a 10 Hz cycle with a 100 ms budget reaches one to four million.
+    // Sizing the sample-dependent buffers once (8 M samples, batches of 16 vertices: 2.3 GB of 288) keeps device allocations out of
+    // every later cycle's budget.  PPAMD_RESERVE_SAMPLES=0 leaves them to grow on demand.
+    long long reserve = 8ll << 20;
+    if (const char* e = std::getenv("PPAMD_RESERVE_SAMPLES")) reserve = std::atoll(e);
+    if (reserve > 0 && ppgpu_reserve_samples(m_Handle, reserve, 16) != PPGPU_OK)
+        throw std::runtime_error(std::string("ppgpu_reserve_samples: ") + ppgpu_last_error());
     m_Thread = std::thread(&GpuContext::serve, this);
 }
 

@@ -123,6 +123,9 @@ int main(int argc, char** argv) {
                 st = planner.plan(rm, cur, config, prev, timeRemaining);
                 wall.push_back(1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count());
                 iters += st.Iterations; expanded += st.Expanded; samples += st.Samples;
+                if (cyc > 0 && wall.back() > 1.25e3 * timeRemaining)      // an overrun: what was the cycle doing?
+                    std::fprintf(stderr, "[replan] cycle %d: %.1f ms, %lu iterations, %lu samples, %lu expanded\n", cyc, wall.back(),
+                                 (unsigned long)st.Iterations, (unsigned long)st.Samples, (unsigned long)st.Expanded);
                 tNow += replanStep;
                 if (st.Plan.empty()) { failures++; cur.time() = tNow; prev = DubinsPlan(); continue; }
                 prev = st.Plan;

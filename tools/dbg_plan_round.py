@@ -42,3 +42,10 @@ with tempfile.TemporaryDirectory() as d:
         n = min(len(H), len(O))
         for j in range(n, min(max(len(H), len(O)), n + 4)):
             print("  extra", "H" if len(H) > len(O) else "O", j, np.array2string((H if len(H) > len(O) else O)[j], precision=10, max_line_width=400))
+    _scenario(w, sc, mp, t0, dt, calls, init, speculation=spec)
+    host = _run_cli(sc)
+    hp = np.array(host["plan"], dtype=np.float64).reshape(-1, 11)
+    print("host plan depth", host.get("plan_depth"), "oracle", st.plan_depth, "plan_h", host.get("plan_h"), st.plan_h)
+    for i in range(max(len(hp), len(plan))):
+        if i < len(hp): print("  H", i, np.array2string(hp[i], precision=15, max_line_width=400))
+        if i < len(plan): print("  O", i, np.array2string(plan[i], precision=15, max_line_width=400))

@@ -47,7 +47,10 @@ def judge(host, st, plan):
     try:
         _compare(host, st, plan)
         return "ok"
-    except AssertionError:
+    except AssertionError as ex:
+        if os.environ.get("FUZZ_VERBOSE"):
+            import traceback
+            print("   _compare:", traceback.format_exc().strip().splitlines()[-3:], flush=True)
         return "tie"
 
 
@@ -212,6 +215,12 @@ def one_round(rng, rid, d, verbose=True):
         elif v != "ok":
             why, v = v, "MISMATCH"
         out.append((which, v, why))
+        if os.environ.get("FUZZ_VERBOSE") and v != "ok":
+            hp = np.array(host["plan"], dtype=np.float64).reshape(-1, 11)
+            print(which, v, why, "| depth", host.get("plan_depth"), st.plan_depth, "plan_f", repr(host["plan_f"]), repr(st.plan_f), "plan_h", repr(host.get("plan_h")), repr(st.plan_h))
+            for i in range(max(len(hp), len(plan))):
+                if i < len(hp): print("  H", i, np.array2string(hp[i], precision=15, max_line_width=400))
+                if i < len(plan): print("  O", i, np.array2string(plan[i], precision=15, max_line_width=400))
         return host, st, plan
 
     host, st, plan = run("plan", t0, None, None)

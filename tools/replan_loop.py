@@ -23,6 +23,7 @@ with tempfile.TemporaryDirectory() as d:
         f.write(f"time_remaining {budget / 1e3!r}\nreplan {cycles} 0.1\n")
     out = subprocess.run([CLI, sc], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
+    sys.stderr.write("".join(l + "\n" for l in out.stderr.splitlines() if l.startswith("[replan]")))
     r = json.loads(out.stdout.strip().splitlines()[-1])
     r.update({"initial_samples": init, "speculation": spec if spec is not None else 16, "obstacles": 32, "workload": "cfg3 grid, 5 ribbons"})
     print(json.dumps(r))

@@ -30,7 +30,7 @@ out["dominant_kernel"] = "pp_k_cover_sweep"
 out["hbm_bytes_per_launch"] = dom.get("fetch_size_bytes", 0.0) + dom.get("write_size_bytes", 0.0)
 import hashlib
 _h = hashlib.sha256()
-for _f in ("ppgpu.hip", "pp_kernels.h", "pp_device.h", "pp_sampler.h"):
+for _f in ("ppgpu.hip", "pp_kernels.h", "pp_device.h", "pp_sampler.h", "pp_cr.h", "pp_cr_tables.h"):
     _h.update(open(os.path.join(ROOT, "path_planner_amd", "csrc", _f), "rb").read())
 out["kernel_sources_sha256"] = _h.hexdigest()       # bench.py reports these bytes only while the sources are the ones measured
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
