@@ -2412,7 +2412,7 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
         // keep what a plain selection gives: the k cheapest of the list, ascending by (length, sample); only the push order is lost
         if (lane == 0) atomicAdd(fallbacks, 1u);
 #ifdef PP_DBG_ORD
-        if (lane == 0) printf("[ord] FALLBACK vr %d: k %d M %d cap %lld kept %d unsafeFiltered %d hsize %d\n", vr, k, M, g_cap, Mk, (int)unsafeFiltered, hsize);
+        if (lane == 0) printf("[ord] FALLBACK vr %d: k %d M %d cap %lld kept %d unsafeFiltered %d hsize %d | U %g dq %g inner %d threshold %g\n", vr, k, M, g_cap, Mk, (int)unsafeFiltered, hsize, U, dq, nInner, threshold);
 #endif
         const int Mc = (long long)M < g_cap ? M : (int)g_cap;
         double prevL = -INFINITY; int prevI = -1;

@@ -83,7 +83,7 @@ def _same_curve(a, b, n=17):
     return True
 
 
-def _compare(host, st, plan):
+def _compare(host, st, plan, allow_order_fallbacks=False):
     assert "exception" not in host, host
     assert host["samples"] == st.samples
     assert host["iterations"] == st.iterations
@@ -118,7 +118,9 @@ def _compare(host, st, plan):
             assert min(a[3], a[5]) <= 1e-9 and min(b[3], b[5]) <= 1e-9, (hp, plan)
             assert np.max(np.abs(a[8:] - b[8:]) / np.maximum(np.abs(b[8:]), 1.0)) <= 1e-5, (hp, plan)
             assert _same_curve(a, b), (hp, plan)
-    assert host.get("order_fallbacks", 0) == 0
+    # lists whose push order the device could not replay (more candidates than it sorts: thousands of samples at EQUAL distance, e.g.
+    # ribbon projections piled up on a nearly covered ribbon, where the reference's own order is that of its heap sort's ties)
+    assert allow_order_fallbacks or host.get("order_fallbacks", 0) == 0
 
 
 @pytest.mark.parametrize("name,init,calls", [("cfg1", 64, 60), ("cfg2", 256, 40), ("cfg3", 512, 30)])
