@@ -577,6 +577,9 @@ __device__ __forceinline__ bool pp_chunk_clear_of(const PPObst& o, double x, dou
     const double rx = dx * o.cosYaw - dy * o.sinYaw, ry = dx * o.sinYaw + dy * o.cosYaw;
     return (fabs(rx) > o.halfL + slack) | (fabs(ry) > o.halfW + slack);
 }
+#define PP_SKIP_ALL 1     // track_skip bits: the chunk is not sampled at all
+#define PP_SKIP_GRID 2    // sampled, but no pose of it can lie on a blocked cell
+#define PP_SKIP_OBST 4    // sampled, but no pose of it can lie inside an obstacle
 template <bool GAUSSIAN>
 __device__ __forceinline__ void pp_plan_skips_thread(const PPParams& p) {
     // one THREAD per (edge, chunk): measured against one lane per edge walking its chunks (0.29 ms at config 3: 24 dependent
@@ -603,15 +606,15 @@ __device__ __forceinline__ void pp_plan_skips_thread(const PPParams& p) {
     const double wStart = S->wStart, speed = S->speed, length = S->length, rho = S->rho, rho_inv = S->rho_inv;
     const double tM = whole ? tg[k0 + PP_WAVE / 2] : tF, tL = whole ? tg[k0 + PP_WAVE - 1] : tF;
     const double tP = (k0 > 0) ? tg[k0 - 1] : 0.0;
-    bool ok = whole && tL < endTime;
     const double dP = (tP - wStart) * speed, dF = (tF - wStart) * speed, dM = (tM - wStart) * speed, dL = (tL - wStart) * speed;
-    ok = ok && (dF >= 0.0) && (dL <= length);
+    const bool okGeom = whole && tL < endTime && (dF >= 0.0) && (dL <= length);   // 64 steps, all before the end time, on the curve proper
     const double hs = fmax(dL - dM, dM - dF) * (1.0 + 1e-12) + 1e-9;      // how far (arc length) a step of the chunk is from the middle step
     const double ht = fmax(tL - tM, tM - tF);
     const double hi0 = S->seg[0].hi, hi1 = S->seg[1].hi;
     unsigned long long eqWord = ~0ull;
     double tpP = 0.0;
     int segP = 0;
+    bool okHead = true;                                        // the heading-unchanged bits of the chunk are known without sampling
     if (!cov) {
         // the step before the chunk: its heading is what the first step of the chunk is compared with
         tpP = (rho_inv != 0.0) ? dP * rho_inv : dP / rho;
@@ -620,34 +623,40 @@ __device__ __forceinline__ void pp_plan_skips_thread(const PPParams& p) {
         const int segL = pp_seg_of(tpL, hi0, hi1);
         const bool straight = S->seg[segL].type == 1;
         eqWord = straight ? ~0ull : 0ull;
-        ok = ok && (k0 > 0) && (dP >= 0.0) && (segP == segL) && (straight || (tpL - tpP) > 65.0 * 1e-9);
+        okHead = (k0 > 0) && (dP >= 0.0) && (segP == segL) && (straight || (tpL - tpP) > 65.0 * 1e-9);
     }
-    if (ok) {
+    // Two separate answers: no pose of the chunk can be on a blocked cell; no pose can be inside an obstacle.  Both, with the
+    // heading bits known, skip the chunk; one alone still spares the sweep that half of its per-step work (PP_SKIP_* bits).
+    bool gridClear = false, obstClear = false;
+    if (okGeom) {
         const double tpM = (rho_inv != 0.0) ? dM * rho_inv : dM / rho;
         const PPSeg* g = &S->seg[pp_seg_of(tpM, hi0, hi1)];
         double ux, uy, uth;
         pp_curve_seg(g->type, (tpM - g->o1) - g->o2, g->bx, g->by, g->bth, g->sb, g->cb, ux, uy, uth);
         const double x = ux * rho + S->qx, y = uy * rho + S->qy;
+        gridClear = true;
         if (p.grid.rows != 0) {
             const double cx = x * p.grid.inv_res, cy = y * p.grid.inv_res;
             const bool inside = (x >= 0.0) & (y >= 0.0) & (cx < (double)p.grid.cols) & (cy < (double)p.grid.rows);
             const int need = (int)(hs * p.grid.inv_res) + 2;
             int clear = 0;
             if (inside) clear = (int)p.grid.clearance[(size_t)(unsigned)cy * p.grid.cols + (unsigned)cx];
-            ok = inside && (need < PP_CLEAR_CAP) && (clear > need);
+            gridClear = inside && (need < PP_CLEAR_CAP) && (clear > need);
         }
         // only the obstacles that can come near this edge at all (pp_k_solve_edges left the list in the setup record)
         unsigned long long m = ((unsigned long long)(unsigned)S->seg[1].pad << 32) | (unsigned long long)(unsigned)S->seg[0].pad;
         if (p.n_obst > PP_WAVE) m = 0ull;
-        while (ok && m) {
+        obstClear = true;
+        while (obstClear && m) {
             const int j = __ffsll((long long)m) - 1;
             m &= m - 1;
-            ok = pp_chunk_clear_of<GAUSSIAN>(p.obst[j], x, y, tM, hs, ht);
+            obstClear = pp_chunk_clear_of<GAUSSIAN>(p.obst[j], x, y, tM, hs, ht);
         }
-        if (ok && p.n_obst > PP_WAVE)
-            for (int j = 0; j < p.n_obst && ok; j++) ok = pp_chunk_clear_of<GAUSSIAN>(p.obst[j], x, y, tM, hs, ht);
+        if (obstClear && p.n_obst > PP_WAVE)
+            for (int j = 0; j < p.n_obst && obstClear; j++) obstClear = pp_chunk_clear_of<GAUSSIAN>(p.obst[j], x, y, tM, hs, ht);
     }
-    *skipb = ok ? 1 : 0;
+    const bool ok = okGeom && okHead && gridClear && obstClear;
+    *skipb = ok ? PP_SKIP_ALL : (unsigned char)((gridClear ? PP_SKIP_GRID : 0) | (obstClear ? PP_SKIP_OBST : 0));
     if (ok) {
         p.track_chunk_hits[(size_t)e * p.nch + chunk] = 0u;
         if (!cov) p.track_eq[(size_t)e * p.nch + chunk] = eqWord;
@@ -748,7 +757,13 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
     const double* carry = p.track_carry + (size_t)e * p.nch;
     bool afterSkip = false, stop = false;
     for (int g0 = 0; !stop; g0 += PP_WAVE) {
-        const unsigned long long skips = skipb ? __ballot((g0 + lane < p.nch) && skipb[g0 + lane] != 0) : 0ull;
+        const unsigned sbits = (skipb && g0 + lane < p.nch) ? (unsigned)skipb[g0 + lane] : 0u;
+        const unsigned long long skips = __ballot((sbits & PP_SKIP_ALL) != 0u);
+#ifndef PP_NO_PARTIAL_SKIP
+        const unsigned long long gclear = __ballot((sbits & PP_SKIP_GRID) != 0u), oclear = __ballot((sbits & PP_SKIP_OBST) != 0u);
+#else
+        const unsigned long long gclear = 0ull, oclear = 0ull;
+#endif
         for (int ci = 0; ci < PP_WAVE; ci++) {
             const int base = (g0 + ci) * PP_WAVE;
 #ifdef PP_DBG_TRACE
@@ -756,6 +771,7 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
                 printf("[pose] chunk at %d: skip %d (eq word %llx)\n", base, (int)((skips >> ci) & 1ull), (unsigned long long)teq[base >> 6]);
 #endif
             if ((skips >> ci) & 1ull) { limit = base + PP_WAVE; afterSkip = true; continue; }
+            const bool gridClear = ((gclear >> ci) & 1ull) != 0ull, obstClear = ((oclear >> ci) & 1ull) != 0ull;
             const int k = base + lane;
             const double t = (k < p.ng) ? tg[k] : INFINITY;
             const double tFirst = pp_readlane(t, 0);
@@ -774,12 +790,14 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
                 // on edges that may not cover while turning
                 heading = cov ? 0.0 : pp_heading_from_yaw(pp_mod2pi(uth));
     #ifndef PP_ABL_NO_GRID
-                blk = valid & pp_is_blocked(p.grid, x, y);                // Edge.cpp:144
+                if (!gridClear) blk = valid & pp_is_blocked(p.grid, x, y);   // Edge.cpp:144 (pp_k_plan_skips may have ruled it out for the whole chunk)
     #endif
             }
             double dens = 0;
     #ifndef PP_ABL_NO_OBST
-            if (anyObstacle && laneCull) {                                // :150-151
+            if (anyObstacle && obstClear) {
+                // pp_k_plan_skips: no obstacle can hold a pose of this chunk
+            } else if (anyObstacle && laneCull) {                         // :150-151
                 // which obstacles can come near this chunk: lane i answers for obstacle i from its registers
                 const double dtc = tFirst - cullT0;
                 const double ddx = pp_readlane(x, 0) - (oX0 + oVx * dtc), ddy = pp_readlane(y, 0) - (oY0 + oVy * dtc);
