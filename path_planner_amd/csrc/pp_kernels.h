@@ -2369,7 +2369,7 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
     // the RIGHT one on equal costs: it retraces the path unless some ancestor whose path child is its left child has a right
     // child of EQUAL cost, or k is a right child whose left sibling equals their parent (then the two equal entries trade
     // places).  `safe` says that no such pair exists in the full heap as it stands; it changes only when the heap does.
-    bool safe = true;
+    bool safe = true, anyEqual = false;
     auto heapSafe = [&]() -> bool {
         bool ok = true;
         for (int c = k; c > 0; c = (c - 1) >> 1) {
@@ -2411,10 +2411,12 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
 #ifdef PP_DBG_ORD
                 nexact++;
 #endif
+                // equal costs are what can make the heap unsafe: until one has been pushed onto an equal entry there is nothing to check
+                anyEqual = anyEqual || (__ballot((lane < hsize) & (h.cost == cj)) != 0ull);
                 pp_ord_sift_up(h, hsize, cj, lj, ij);                                     // push_back + std::push_heap
                 hsize++;
                 if (hsize > k) { hsize--; pp_ord_pop(h, hsize); }                         // std::pop_heap + pop_back
-                if (hsize >= k) {
+                if (hsize >= k && anyEqual) {
                     safe = heapSafe();
                     // the ring filter dropped candidates on the strength of "a no-op whenever its turn comes": not in this state
                     if (!safe && Mk < M) { unsafeFiltered = true; break; }
