@@ -362,7 +362,10 @@ __device__ __forceinline__ long long pp_next_edge(const PPParams& p, int kern, P
 #ifndef PP_CR_SOLVE
 #define PP_CR_SOLVE true     // the edges' curves with correctly rounded atan2 / acos / sin / cos (pp_cr.h)
 #endif
-__global__ __launch_bounds__(256) void pp_k_solve_edges(PPParams p) {
+#ifndef PP_SOLVE_MIN_WAVES
+#define PP_SOLVE_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, PP_SOLVE_MIN_WAVES) void pp_k_solve_edges(PPParams p) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     // the queue heads of the kernels that follow (all of them start after this kernel has ended, in stream order)
     if (e < 4 * PP_NQ) p.work[(size_t)e * PP_QSTRIDE] = 0ull;
@@ -669,7 +672,10 @@ __device__ __forceinline__ void pp_plan_skips_thread(const PPParams& p) {
         p.track_carry[(size_t)e * p.nch + chunk] = pp_heading_from_yaw(pp_mod2pi(uth));
     }
 }
-__global__ __launch_bounds__(256) void pp_k_plan_skips(PPParams p) { pp_plan_skips_thread<false>(p); }
+#ifndef PP_PLAN_MIN_WAVES
+#define PP_PLAN_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, PP_PLAN_MIN_WAVES) void pp_k_plan_skips(PPParams p) { pp_plan_skips_thread<false>(p); }
 __global__ __launch_bounds__(256) void pp_k_plan_skips_gaussian(PPParams p) { pp_plan_skips_thread<true>(p); }
 
 // e = the edge's slot in the workspace.  GAUSSIAN: the dynamic obstacles are GaussianDynamicObstaclesManager's (its own
@@ -1015,7 +1021,10 @@ __device__ __forceinline__ bool pp_finish_quiet_edge(const PPParams& p, const PP
     for (int i = 0; i < 4 * nrib; i++) c[i] = rp[i];
     return true;
 }
-__global__ __launch_bounds__(256) void pp_k_approach_events(PPParams p) {
+#ifndef PP_APPROACH_MIN_WAVES
+#define PP_APPROACH_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, PP_APPROACH_MIN_WAVES) void pp_k_approach_events(PPParams p) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     const bool valid = e < p.n_edges;
     const PPEdgeSetup* S = p.setup + p.ws_base + (valid ? e : 0);
