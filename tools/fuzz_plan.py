@@ -120,7 +120,7 @@ def classify_tie(H, O, same_length=True):
     if same_length and len(H) != len(O):
         return False, f"the searches consume {len(H)} and {len(O)} edges"
     rel = lambda a, b: np.abs(a - b) / np.maximum(1.0, np.abs(b))
-    word_tie = retry = degenerate = False
+    word_tie = retry = degenerate = lastbit = False
     for i in range(min(len(H), len(O))):
         h, o = H[i], O[i]
         if np.max(rel(h[:5], o[:5])) > 1e-4:
@@ -150,10 +150,14 @@ def classify_tie(H, O, same_length=True):
             return False, f"edge {i}: infeasible flag differs"
         if np.max(r) > 1e-12:
             retry = True                                    # same edge, last digits differ: a parent's end pose moved by <= 1e-5 m
-    if not (word_tie or retry or degenerate):
+        elif np.any(h != o):
+            lastbit = True                                  # same edge to the last bit or two: h from child ribbons that carry the
+                                                            # sweeps' own rounding (corridor runs, per-step sincos: DESIGN.md 4.2)
+    if not (word_tie or retry or degenerate or lastbit):
         return False, "no upstream difference explains the other plan: the push / pop order itself differs"
     return True, " + ".join(x for x, on in (("equal-length Dubins words", word_tie), ("one-sided 1e-5 retry upstream", retry),
-                                            ("a Dubins problem whose shortest word flips under a 1e-11 perturbation", degenerate)) if on)
+                                            ("a Dubins problem whose shortest word flips under a 1e-11 perturbation", degenerate),
+                                            ("costs that differ in the last bit upstream (f ties broken by an ulp of h)", lastbit and not (word_tie or retry or degenerate))) if on)
 
 
 def make_round(rng, rid):
