@@ -626,7 +626,20 @@ __device__ __forceinline__ void pp_plan_skips_thread(const PPParams& p) {
         const int segL = pp_seg_of(tpL, hi0, hi1);
         const bool straight = S->seg[segL].type == 1;
         eqWord = straight ? ~0ull : 0ull;
-        okHead = (k0 > 0) && (dP >= 0.0) && (segP == segL) && (straight || (tpL - tpP) > 65.0 * 1e-9);
+        if (k0 > 0) {
+            okHead = (dP >= 0.0) && (segP == segL) && (straight || (tpL - tpP) > 65.0 * 1e-9);
+        } else {
+            // the first chunk: its first step is compared with the source vertex's heading (`lastHeading` starts there, Edge.cpp:96),
+            // which is one evaluation of the sweep's own heading expression — no sine or cosine in it
+            const double tpF = (rho_inv != 0.0) ? dF * rho_inv : dF / rho;
+            const int segF = pp_seg_of(tpF, hi0, hi1);
+            okHead = (dF >= 0.0) && (segF == segL) && (straight || (tpL - tpF) > 64.0 * 1e-9);
+            const PPSeg* g = &S->seg[segF];
+            const double tt = (tpF - g->o1) - g->o2;
+            const double uth0 = (g->type == 1) ? (0.0 + g->bth) : ((g->type == 0) ? (tt + g->bth) : (-tt + g->bth));
+            const bool same0 = pp_heading_from_yaw(pp_mod2pi(uth0)) == p.verts[S->vi].heading;
+            eqWord = (eqWord & ~1ull) | (same0 ? 1ull : 0ull);
+        }
     }
     // Two separate answers: no pose of the chunk can be on a blocked cell; no pose can be inside an obstacle.  Both, with the
     // heading bits known, skip the chunk; one alone still spares the sweep that half of its per-step work (PP_SKIP_* bits).
