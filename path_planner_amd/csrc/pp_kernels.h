@@ -43,7 +43,7 @@ struct PPParams {
     double* track_carry;                 // [edge][nch]  heading of the step before the chunk, for edges that may not cover while turning
     int2* track_far;                     // [edge] {first event the cover sweep's wave has to visit, last event before it} (pp_k_approach_events)
     unsigned long long* work;            // work-queue heads of the per-edge kernels (PP_Q_*), zeroed by pp_k_solve_edges
-    unsigned* live_list; unsigned* live_count;     // edges of the slice the cover sweep still has to visit (pp_k_approach_events)
+    unsigned* live_list; unsigned* live_count;     // {workspace slot, list position} of the edges the cover sweep still has to visit (pp_k_approach_events)
     unsigned* defer_list; unsigned* defer_count;   // edges whose heuristic the cover sweep left to pp_k_heuristic_lanes
     unsigned* need_big;                  // set by the cover sweep when some child has 9..12 ribbons (pp_k_heuristic_big then has work)
     int ngp, nch;                        // steps per edge rounded up to whole 64-step chunks, and that many chunks
@@ -1189,7 +1189,8 @@ __global__ __launch_bounds__(256, PP_APPROACH_MIN_WAVES) void pp_k_approach_even
         if (live) {
             unsigned at = s_base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
             for (int w = 0; w < wave; w++) at += s_cnt[w];
-            p.live_list[at] = (unsigned)e;
+            p.live_list[2 * at] = (unsigned)e;                                             // slot in the workspace ...
+            p.live_list[2 * at + 1] = (unsigned)pp_edge_position(p, p.e_base + e);         // ... and position in the caller's list (a 64-bit division the wave is spared)
         }
     }
 }
@@ -1660,8 +1661,8 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep(PP
     PPQueue qs = pp_queue_init();
     const long long n = p.live_list ? (long long)(unsigned)pp_const_i32(p.live_count)[0] : p.n_edges;
     for (PP_EACH_EDGE(i, 2, PP_Q_COVER, n, PP_Q_CHUNK_COVER)) {
-        const long long idx = p.live_list ? (long long)(unsigned)pp_const_i32(p.live_list + i)[0] : i;
-        const long long eg = pp_edge_position(p, p.e_base + idx);
+        const long long idx = p.live_list ? (long long)(unsigned)pp_const_i32(p.live_list + 2 * i)[0] : i;
+        const long long eg = p.live_list ? (long long)(unsigned)pp_const_i32(p.live_list + 2 * i)[1] : pp_edge_position(p, p.e_base + idx);
         pp_cover_sweep_edge<false>(p, p.ws_base + idx, eg, lds_all[wave]);
     }
 }
@@ -1671,8 +1672,9 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep_ga
     PPQueue qs = pp_queue_init();
     const long long n = p.live_list ? (long long)(unsigned)pp_const_i32(p.live_count)[0] : p.n_edges;
     for (PP_EACH_EDGE(i, 2, PP_Q_COVER, n, PP_Q_CHUNK_COVER)) {
-        const long long idx = p.live_list ? (long long)(unsigned)pp_const_i32(p.live_list + i)[0] : i;
-        pp_cover_sweep_edge<true>(p, p.ws_base + idx, pp_edge_position(p, p.e_base + idx), lds_all[wave]);
+        const long long idx = p.live_list ? (long long)(unsigned)pp_const_i32(p.live_list + 2 * i)[0] : i;
+        const long long eg = p.live_list ? (long long)(unsigned)pp_const_i32(p.live_list + 2 * i)[1] : pp_edge_position(p, p.e_base + idx);
+        pp_cover_sweep_edge<true>(p, p.ws_base + idx, eg, lds_all[wave]);
     }
 }
 

@@ -801,8 +801,8 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     p.defer_h = (p.fuse_h && big && PP_LANE_HEUR && c->lane_heuristic && total < (1ll << 32) &&
                  (p.heuristic == PPGPU_H_TSP_POINT_ALL || p.heuristic == PPGPU_H_TSP_POINT_K)) ? 1 : 0;
     p.quiet_finish = (p.track_far && c->quiet_finish) ? 1 : 0;
-    if (p.track_far && slice < (1ll << 32)) {
-        int rc = c->live_list.reserve((size_t)slice, false, c->stream);
+    if (p.track_far && total < (1ll << 32)) {
+        int rc = c->live_list.reserve((size_t)slice * 2, false, c->stream);
         if (rc) return rc;
         p.live_list = c->live_list.p; p.live_count = c->need_big.p + 12;
     }
