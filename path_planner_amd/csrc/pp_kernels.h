@@ -755,7 +755,7 @@ __device__ __forceinline__ void pp_plan_skips_thread(const PPParams& p) {
     }
 }
 #ifndef PP_PLAN_MIN_WAVES
-#define PP_PLAN_MIN_WAVES 1
+#define PP_PLAN_MIN_WAVES 8   // 62 VGPRs, no spills; 0.28 -> 0.27 ms against the compiler's own choice (6 waves)
 #endif
 __global__ __launch_bounds__(256, PP_PLAN_MIN_WAVES) void pp_k_plan_skips(PPParams p) { pp_plan_skips_thread<false>(p); }
 __global__ __launch_bounds__(256) void pp_k_plan_skips_gaussian(PPParams p) { pp_plan_skips_thread<true>(p); }
