@@ -1857,13 +1857,27 @@ __device__ __forceinline__ unsigned pp_lane_tsp_drop(unsigned srt, int c) {     
 // The last two levels in one piece when both remaining ribbons are branched on (K >= 2, or the All variant): eight leaves from
 // ten table entries that do not depend on one another, instead of two nested loops of dependent lookups.  The order in which
 // the two ribbons are tried does not matter for a minimum, so their sort is skipped.
+// the two entries (pt, start of ribbon r) and (pt, end of ribbon r) of the triangle, pt not an endpoint of r: adjacent when pt is the
+// larger index, one row apart otherwise (a third of pp_tri's arithmetic, and the lookups are most of this kernel)
+__device__ __forceinline__ void pp_tri_pair(int pt, int r, int& i0, int& i1) {
+    const bool above = pt > 2 * r;
+    const int rowp = (pt * (pt - 1)) >> 1;
+    i0 = above ? rowp + 2 * r : r * (2 * r - 1) + pt;
+    i1 = above ? rowp + 2 * r + 1 : r * (2 * r + 1) + pt;
+}
 __device__ __forceinline__ double pp_lane_tsp_last2(const PPLaneTsp& c, double sf, unsigned ord, int pt) {
     const int a = (int)(ord & 0xfu), b = (int)((ord >> 4) & 0xfu);
     const double la = c.T[a * (2 * a + 1) + 2 * a], lb = c.T[b * (2 * b + 1) + 2 * b];
-    const double pas = c.T[pp_tri(pt, 2 * a)], pae = c.T[pp_tri(pt, 2 * a + 1)];
-    const double pbs = c.T[pp_tri(pt, 2 * b)], pbe = c.T[pp_tri(pt, 2 * b + 1)];
-    const double xss = c.T[pp_tri(2 * a, 2 * b)], xse = c.T[pp_tri(2 * a, 2 * b + 1)];
-    const double xes = c.T[pp_tri(2 * a + 1, 2 * b)], xee = c.T[pp_tri(2 * a + 1, 2 * b + 1)];
+    int ia0, ia1, ib0, ib1;
+    pp_tri_pair(pt, a, ia0, ia1);
+    pp_tri_pair(pt, b, ib0, ib1);
+    const double pas = c.T[ia0], pae = c.T[ia1], pbs = c.T[ib0], pbe = c.T[ib1];
+    // the four distances between an endpoint of a and an endpoint of b: rows 2B and 2B + 1 of the larger ribbon B, columns 2A, 2A + 1
+    const int A = a < b ? a : b, B = a < b ? b : a;
+    const int rowE = B * (2 * B - 1) + 2 * A, rowO = B * (2 * B + 1) + 2 * A;
+    const double xss = c.T[rowE], xee = c.T[rowO + 1];
+    const double u = c.T[rowE + 1], v = c.T[rowO];           // (end of A, start of B), (start of A, end of B)
+    const double xes = a < b ? u : v, xse = a < b ? v : u;
     const double baseA = sf + la - c.twoW, baseB = sf + lb - c.twoW;
     const double a0 = fmax(baseA + pas, 0) + lb - c.twoW;          // a from its start: now at a's end, b to go
     const double a1 = fmax(baseA + pae, 0) + lb - c.twoW;          // a from its end: now at a's start
@@ -1889,7 +1903,9 @@ __device__ __forceinline__ double pp_lane_tsp(const PPLaneTsp& c, double sf, uns
 #pragma unroll
             for (int i = 0; i < REM; i++) {
                 const int r = (int)((ord >> (4 * i)) & 0xfu);
-                key[i] = fmin(c.T[pp_tri(pt, 2 * r)], c.T[pp_tri(pt, 2 * r + 1)]);
+                int i0, i1;
+                pp_tri_pair(pt, r, i0, i1);
+                key[i] = fmin(c.T[i0], c.T[i1]);
             }
             srt = pp_lane_tsp_order<REM>(key, ord);
         }
@@ -1899,8 +1915,10 @@ __device__ __forceinline__ double pp_lane_tsp(const PPLaneTsp& c, double sf, uns
             const int rid = (int)((srt >> (4 * cc)) & 0xfu);
             const double len = c.T[rid * (2 * rid + 1) + 2 * rid];         // = pp_tri(2 rid, 2 rid + 1)
             const double base = sf + len - c.twoW;
-            const double fromStart = fmax(base + c.T[pp_tri(pt, 2 * rid)], 0);       // enter at the start, leave from the end
-            const double fromEnd = fmax(base + c.T[pp_tri(pt, 2 * rid + 1)], 0);
+            int i0, i1;
+            pp_tri_pair(pt, rid, i0, i1);
+            const double fromStart = fmax(base + c.T[i0], 0);                         // enter at the start, leave from the end
+            const double fromEnd = fmax(base + c.T[i1], 0);
             if constexpr (REM == 1) {
                 best = fmin(best, fmin(fromStart, fromEnd));
             } else {
