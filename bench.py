@@ -26,11 +26,11 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X datasheet, non-matrix fp64 (not in the
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=65536, help="sample attempts per GPU per step")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: SURVEY config 4 — ONE iteration batch of --total attempts split over the ranks "
@@ -39,30 +39,116 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--open-vertex-run", action="store_true",
                     help="also time the 64-open-vertex x 4096-sample launch of SURVEY config 3 (extra launches: not in profiled runs)")
-    args = ap.parse_args()
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched ranks are stopped after this many seconds")
+    return ap.parse_args()
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
 
-    from path_planner_amd import api, sharding, workloads
-    from path_planner_amd.types import RESULT_DTYPE, F_INFEASIBLE
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N rank processes here, BEFORE this process has touched
+    the GPU (it never does: no torch import, no HIP call), each with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
+    torch.distributed.run would set them, and pass rank 0's JSON line through.  A rank that fails stops the others (by PID)."""
+    import signal
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "PP_BENCH_SELF_LAUNCHED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr, start_new_session=True))
+    deadline = time.time() + args.launch_timeout
+    rc = 0
+    live = set(range(args.gpus))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+        if live and (rc != 0 or time.time() > deadline):
+            if rc == 0:
+                rc = 124
+                print("bench.py: --launch-timeout reached; stopping the ranks", file=sys.stderr, flush=True)
+            for r in live:                       # exactly the processes started above
+                try:
+                    os.killpg(procs[r].pid, signal.SIGTERM)
+                except ProcessLookupError:
+                    pass
+            t_end = time.time() + 10
+            for r in live:
+                try:
+                    procs[r].wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    try:
+                        os.killpg(procs[r].pid, signal.SIGKILL)
+                    except ProcessLookupError:
+                        pass
+                    procs[r].wait()
+            live.clear()
+        if live:
+            time.sleep(0.05)
+    return rc
 
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    run_rank(args)
+
+
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+
+    import numpy as np
+    from path_planner_amd import api, sharding, workloads
+    from path_planner_amd.types import RESULT_DTYPE, F_INFEASIBLE
+
+    # PP_BENCH_REHEARSAL=1 (developer aid for a one-GPU box, never set by the driver): every rank uses device 0, torch's group is
+    # gloo and the incumbents are combined through the host — RCCL refuses two ranks on one device, so this rehearses the
+    # launcher, the sharding and the aggregation only; the line it prints is marked and is not a measurement
+    rehearsal = os.environ.get("PP_BENCH_REHEARSAL") == "1" and world > 1
+    if rehearsal:
+        local = 0
+    ctx = api.Context(local)                 # first device call of the process: no gfx950 device = PpgpuError here, nothing else runs
+    import torch
+    import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    if world > 1:
+    rccl_ranks = None
+    if rehearsal:
+        dist.init_process_group("gloo")
+    elif world > 1:
+        # torch's process group carries the barrier and the max-over-ranks of the timing contract; the data path's one
+        # collective per step goes through the product's own communicator (ppgpu_comm_* / ppgpu_allreduce_best)
         dist.init_process_group("nccl", device_id=dev)
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(api.Context.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        torch.cuda.synchronize(dev)
+        ctx.comm_init_rank(world, rank, bytes(uid.cpu().numpy().tobytes()))
+        rccl_ranks, my = ctx.comm_info()     # read back from RCCL: ncclCommCount / ncclCommUserRank
+        assert rccl_ranks == world and my == rank, (rccl_ranks, my)
 
     w = workloads.config3()
     B = args.batch                                  # attempts per GPU per step (weak scaling: the default)
     total_attempts = args.total if args.strong else B * world
     if args.strong:
         B = -(-total_attempts // world)             # the largest shard
-    ctx = api.Context(local)
     stream = torch.cuda.Stream(dev)          # a real (non-null) stream shared by the kernels, torch events and RCCL
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
@@ -70,15 +156,14 @@ def main():
     ctx.set_grid(w.grid, w.res)
     ctx.set_obstacles(w.obst)
     ctx.set_vertices(w.root(), w.ribbons4)
-    ctx.enable_timing(True)                  # HIP events between the four kernels of a costing launch, on this stream
+    ctx.enable_timing(True)                  # HIP events between the kernels of a costing launch, on this stream
 
     max_edges = 4 * B
     d_res = torch.zeros(max_edges * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     d_key2 = torch.zeros(2, dtype=torch.int64, device=dev)
-    d_gather = torch.zeros(2 * world, dtype=torch.int64, device=dev)
     kernel_events = []
 
-    def step(timed):
+    def step():
         ctx.sampler_init(w.bounds6, w.seed, w.ribbons4)
         lo, hi = sharding.shard_attempts(total_attempts, rank, world)   # this rank's slice of the iteration's batch
         if lo:
@@ -87,9 +172,15 @@ def main():
         ne = 4 * n
         ctx.cost_edges_dense(0, 1, 0, n, 0xF, d_res.data_ptr())
         ctx.best_edge(ne, d_res.data_ptr(), d_key2.data_ptr(), goal_only=False, base=sharding.edge_index_base(rank, max_edges))
-        if world > 1:
-            dist.all_gather_into_tensor(d_gather, d_key2)          # one collective: 16 B per rank over xGMI
-            ctx.key_min(world, d_gather.data_ptr(), d_key2.data_ptr())
+        if rehearsal:
+            mine = d_key2.cpu()
+            allk = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(allk, mine)
+            d_all = torch.cat(allk).to(dev)
+            ctx.key_min(world, d_all.data_ptr(), d_key2.data_ptr())
+            ctx.synchronize()
+        elif world > 1:
+            ctx.allreduce_best(d_key2.data_ptr())     # the one collective of the iteration: 16 B per rank over xGMI + local min
         return ne
 
     def fence():
@@ -98,20 +189,24 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        step(False)
+        step()
     fence()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     edges = 0
-    for _ in range(args.steps):
-        edges += step(True)
+    marks[0].record(stream)
+    for k in range(args.steps):
+        edges += step()
+        marks[k + 1].record(stream)
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = np.array([marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)])
     # (solve, pose, cover, heuristic) ms of the last timed steps' launches, from the HIP events the library recorded between its
     # kernels on this stream inside the timed region (a ring of 8 sets: read back here, so no step waited for its own events)
     for back in range(min(args.steps, 8)):
         kernel_events.append(ctx.past_timing(back))
 
-    tot = torch.tensor([float(edges), elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(edges), elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world > 1:
         e_sum = tot[0:1].clone()
         t_max = tot[1:2].clone()
@@ -120,6 +215,23 @@ def main():
         total_edges, t = float(e_sum.item()), float(t_max.item())
     else:
         total_edges, t = float(edges), elapsed
+
+    # end to end: the same step followed by the D2H copy of its records into pinned host memory (the host A* needs
+    # all of them).  Its own loop after the timed region; never part of `value`.
+    e2e_ms = None
+    if rank == 0:
+        h_res = torch.empty(max_edges * RESULT_DTYPE.itemsize, dtype=torch.uint8, pin_memory=True)
+    fence()
+    n_e2e = max(1, min(args.steps, 10))
+    t0 = time.perf_counter()
+    for _ in range(n_e2e):
+        ne = step()
+        if rank == 0:
+            h_res[: ne * RESULT_DTYPE.itemsize].copy_(d_res[: ne * RESULT_DTYPE.itemsize], non_blocking=True)
+            stream.synchronize()
+    fence()
+    if rank == 0:
+        e2e_ms = 1e3 * (time.perf_counter() - t0) / n_e2e
 
     if rank == 0:
         solve_ms, pose_ms, cover_ms, heur_ms = [float(x) for x in np.mean(np.array(kernel_events), axis=0)]
@@ -131,43 +243,36 @@ def main():
         feas_frac = float(((res["flags"] & F_INFEASIBLE) == 0).mean())
         M = 0 if w.obst is None else len(w.obst)
         R = len(w.ribbons4)
-        # algorithmic bytes / flops per edge with the MEASURED mean step count.  The per-edge figure is
-        # the whole edge's (descriptor, source vertex, ribbons in and out, record, grid bits); the cover sweep is the
-        # kernel that reads the ribbons and writes the record and the child ribbons.
+        # algorithmic bytes / flops per edge with the MEASURED mean step count
         bytes_per_edge = 88 + 32 + 32 * R + 56 * M / 4.0 + 150 + steps_mean / 8.0
         flops_per_edge = 1000 + steps_mean * (70 + 21 * M) + 4e4        # solve + sweeps + heuristic
-        # the cover sweep visits the edges the approach prepass could not finish itself (a packed list); the record, the ribbons
-        # in and out and the track words of those edges are its algorithmic bytes
         cover_edges = ctx.last_cover_edges()
-        ach_gbs = bytes_per_edge * cover_edges / (kern_ms * 1e-3) / 1e9
-        # over the whole costing launch: the cover sweep's wave also runs the edge's heuristic (PP_FUSE_HEUR), so the kernels
-        # are not priced separately
+        # "roofline.achieved must be F x edges/s / fp64-vector peak": F x the edges of one costing launch over the
+        # launch's kernel time (HIP events, live).  F is the survey's model of the reference's arithmetic, not a counter.
         ach_tf = flops_per_edge * n_edges_launch / (launch_ms * 1e-3) / 1e12
-        # what goes through HBM between the kernels of one launch: the solved curve (384 B), the pose
-        # sweep's summary (16 B) and its per-chunk words (12 B per 64 steps); poses are recomputed, not stored
-        workspace_bytes_per_edge = 384 + 16 + 12.0 * (steps_mean / 64.0)
+        hbm_model_gbs = bytes_per_edge * n_edges_launch / (launch_ms * 1e-3) / 1e9
+        cover_gbs = bytes_per_edge * cover_edges / (kern_ms * 1e-3) / 1e9
         traffic = None
+        per_kernel = None
         sweep_hbm = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")   # written from separate rocprofv3 --pmc passes (tools/traffic.sh)
         if os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
-                # the counters were collected in separate rocprofv3 --pmc passes (tools/traffic.sh) over a particular build of the
-                # kernels: they describe THIS run only if the kernel sources are still the ones they were measured on
+                # the counters describe THIS run only if the kernel sources are still the ones they were measured on
                 if tj.get("kernel_sources_sha256") != kernel_sources_sha256():
                     raise ValueError("profiles/traffic.json was measured on other kernel sources")
-                traffic = tj.get("hbm_bytes_per_launch")
+                traffic = tj.get("hbm_bytes_per_costing_launch", tj.get("hbm_bytes_per_launch"))
+                per_kernel = {k: v.get("fetch_size_bytes", 0.0) + v.get("write_size_bytes", 0.0) for k, v in tj["kernels"].items()}
                 # "achieved HBM GB/s on the collision sweep against the chip's peak" (BASELINE north_star): counter bytes of the
                 # pose sweep (collision checks) over its live kernel time.  Low is good here: the sweep is ALU-bound.
-                nbytes = 0.0
-                for kname in ("pp_k_plan_skips", "pp_k_pose_sweep"):        # the interval the events bracket: planner + sweep
-                    ps = tj["kernels"].get(kname, {})
-                    nbytes += ps.get("fetch_size_bytes", 0.0) + ps.get("write_size_bytes", 0.0)
+                nbytes = sum(per_kernel.get(k, 0.0) for k in ("pp_k_plan_skips", "pp_k_pose_sweep"))
                 sweep_hbm = {"kernel": "pp_k_plan_skips+pp_k_pose_sweep", "pmc_bytes_per_launch": nbytes, "GBps": nbytes / (pose_ms * 1e-3) / 1e9,
                              "frac_of_peak": nbytes / (pose_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             except Exception:
-                traffic = None
+                traffic = per_kernel = sweep_hbm = None
         key = d_key2.cpu().numpy().view(np.uint64)
+        alg_bytes_launch = bytes_per_edge * n_edges_launch
         out = {
             "metric": "Dubins edges costed/sec on 2048x2048 grid",
             "value": total_edges / t,
@@ -176,32 +281,52 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * t / args.steps,
+            "ms_per_step_median": float(np.median(step_ms)),
+            "ms_per_step_p99": float(np.percentile(step_ms, 99)),
+            "e2e_ms_per_step": e2e_ms,
+            "e2e_note": f"rank 0, {n_e2e} further steps after the timed region, each followed by the D2H copy of its records "
+                        f"({n_edges_launch * RESULT_DTYPE.itemsize / 1e6:.1f} MB) into pinned host memory; never part of value",
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "rccl_ranks": rccl_ranks,
+            **({"rehearsal": "PP_BENCH_REHEARSAL=1: all ranks on device 0, gloo, host combine - NOT a measurement"} if rehearsal else {}),
+            "launched_by": ("bench.py itself" if os.environ.get("PP_BENCH_SELF_LAUNCHED") else ("an external launcher" if world > 1 else "single process")),
             "config": {"workload": (f"cfg4_2048_10pct_{total_attempts}_obst{M}_over_{world}gpus" if args.strong else w.name),
                        "grid": "2048x2048 @0.1m, 10% blocked", "samples_per_iter_per_gpu": B, "samples_per_iter_total": total_attempts,
                        "dynamic_obstacles": M, "obstacle_placement": "uniform in the map (SURVEY 8d), seed 3",
                        "ribbons": R, "heuristic": "TspPointRobotNoSplitKRibbons K=2",
-                       "edges_per_iter_per_gpu": n_edges_launch, "sharding": "sample batch split by rank, 1 all-gather/iter"},
-            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                         "achieved_is": "algorithmic bytes per edge (model, SURVEY 8d) x edges the kernel processed / its time measured live with HIP events",
-                         "traffic": traffic, "traffic_is": ("PMC bytes per launch from profiles/traffic.json, measured on these kernel sources"
-                                                            if traffic is not None else "null: no PMC pass on these kernel sources (tools/traffic.sh)"),
-                         "kernel": "pp_k_cover_sweep", "kernel_ms": kern_ms, "edges_in_kernel": cover_edges,
+                       "edges_per_iter_per_gpu": n_edges_launch,
+                       "sharding": "sample batch split by rank; one RCCL collective per iteration (ppgpu_allreduce_best: all-gather of 16 B per rank + local min)"},
+            "roofline": {"bound": "fp64_valu", "achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TFLOPS,
+                         "achieved_is": "SURVEY 8(d): algorithmic flops per edge F (model of the reference's arithmetic with the measured mean step count) "
+                                        "x edges of one costing launch / the launch's kernel time, measured live with HIP events between the kernels",
+                         "algorithmic_flops_per_edge": flops_per_edge,
+                         "kernel": "the costing launch (pp_k_solve_edges .. pp_k_heuristic_lanes); dominant kernel pp_k_cover_sweep",
+                         "launch_ms": launch_ms, "kernel_ms": kern_ms, "edges_in_kernel": cover_edges,
                          "kernels_ms": {"pp_k_solve_edges": solve_ms, "pp_k_plan_skips+pp_k_pose_sweep": pose_ms, "pp_k_cover_sweep": cover_ms,
                                         "others": heur_ms},
                          "kernels_note": "HIP events between the kernels of each costing launch of the timed region (last 8 steps); "
                                          "'others' = pp_k_approach_events (finishes the edges whose coverage state machine has nothing to do: "
                                          "edges_in_kernel is what is left for the cover sweep) + pp_k_deferred_list + pp_k_heuristic_lanes + "
                                          "pp_k_heuristic_big; the four add up to the launch",
-                         "algorithmic_bytes_per_edge": bytes_per_edge, "workspace_bytes_per_edge": workspace_bytes_per_edge,
-                         "collision_sweep_hbm": sweep_hbm,
-                         "note": "all four kernels are fp64-VALU bound, not HBM bound (SURVEY 8d): see valu_fp64"},
-            "valu_fp64": {"achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TFLOPS,
-                          "algorithmic_flops_per_edge": flops_per_edge},
+                         "traffic": traffic,
+                         "traffic_is": ("PMC bytes per costing launch from profiles/traffic.json, measured on these kernel sources"
+                                        if traffic is not None else "null: no PMC pass on these kernel sources (tools/traffic.sh)"),
+                         "hbm": {"bound": "hbm", "achieved": hbm_model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_model_gbs / HBM_PEAK_GBS,
+                                 "achieved_is": "algorithmic bytes per edge (model, SURVEY 8d) x edges of the launch / launch_ms",
+                                 "algorithmic_bytes_per_edge": bytes_per_edge, "algorithmic_bytes_per_launch": alg_bytes_launch,
+                                 "counter_bytes_per_launch": traffic,
+                                 "counter_to_algorithmic": (traffic / alg_bytes_launch if traffic else None),
+                                 "counter_GBps": (traffic / (launch_ms * 1e-3) / 1e9 if traffic else None),
+                                 "counter_bytes_per_kernel": per_kernel,
+                                 "cover_sweep": {"achieved": cover_gbs, "frac": cover_gbs / HBM_PEAK_GBS,
+                                                 "achieved_is": "algorithmic bytes of the edges pp_k_cover_sweep visited / its own time"},
+                                 "collision_sweep": sweep_hbm,
+                                 "note": "reported because BASELINE's north_star asks for it; the path is fp64-VALU bound (SURVEY 8d: 630 flop/B "
+                                         "against a machine balance of 10), so for HBM lower is better"}},
             "workload_stats": {"mean_sweep_steps_per_edge": steps_mean, "feasible_fraction": feas_frac,
                                "kernel_edges_per_s": n_edges_launch / (launch_ms * 1e-3),
                                "best_f": float(np.array([key[0]], dtype=np.uint64).view(np.float64)[0]), "best_edge": int(key[1])},
@@ -214,6 +339,9 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        torch.cuda.synchronize(dev)
+        if not rehearsal:
+            ctx.comm_destroy()
         dist.destroy_process_group()
 
 

@@ -341,9 +341,28 @@ int ppgpu_best_edge(ppgpu_ctx* ctx, int64_t n, const ppgpu_edge_result* d_result
  * combine step after an all-gather issued on the caller's own communicator. Asynchronous. */
 int ppgpu_key_min(ppgpu_ctx* ctx, int32_t n, const uint64_t* d_keys, uint64_t* d_key2);
 
+/* The communicator of a sharded iteration (SURVEY.md 8 e: the sample batch is split over the GPUs of a node, every rank
+ * costs the edges to its own samples, the incumbents are combined once per iteration).  The reference has no counterpart:
+ * its incumbent update is AStarPlanner.cpp:109-117 on one thread.  RCCL is loaded at the first call (dlopen), so a
+ * single-GPU user never needs it.
+ *   one process per GPU:  rank 0 calls ppgpu_comm_unique_id and hands the 128 bytes to the other ranks by any means (a
+ *     file, a TCP store, MPI); every rank then calls ppgpu_comm_init_rank on its own handle (collective: returns when all
+ *     world ranks have called it).
+ *   one process, several GPUs:  ppgpu_comm_init_all on the n handles (one per device, rank i = ctxs[i]); each handle's
+ *     ppgpu_allreduce_best must then be issued from its own host thread (the call blocks until every rank has joined).
+ * ppgpu_comm_info reads the size and this handle's rank back from RCCL (ncclCommCount / ncclCommUserRank).
+ * The handle owns its communicator; ppgpu_destroy releases it. */
+#define PPGPU_COMM_ID_BYTES 128
+int ppgpu_comm_unique_id(uint8_t* h_id128);
+int ppgpu_comm_init_rank(ppgpu_ctx* ctx, int32_t world, int32_t rank, const uint8_t* h_id128);
+int ppgpu_comm_init_all(ppgpu_ctx** ctxs, int32_t n);
+int ppgpu_comm_info(ppgpu_ctx* ctx, int32_t* world, int32_t* rank);
+int ppgpu_comm_destroy(ppgpu_ctx* ctx);
+
 /* Global incumbent across the ranks of one node: lexicographic min of the
- * per-rank keys with one RCCL collective over xGMI.  rccl_comm is an
- * ncclComm_t created by the caller.  In place on d_key2. */
+ * per-rank keys with one RCCL collective over xGMI (all-gather of 16 bytes per rank, then ppgpu_key_min; RCCL has no
+ * MINLOC and 64 bits cannot carry a full-precision f and an index).  rccl_comm is an ncclComm_t created by the caller,
+ * or NULL for the handle's own communicator (ppgpu_comm_init_*).  In place on d_key2, asynchronous on the handle's stream. */
 int ppgpu_allreduce_best(ppgpu_ctx* ctx, void* rccl_comm, uint64_t* d_key2);
 
 #ifdef __cplusplus

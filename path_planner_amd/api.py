@@ -62,6 +62,11 @@ def _load():
         "ppgpu_best_edge": (C.c_int, [vp, i64, vp, i32, u64, vp]),
         "ppgpu_key_min": (C.c_int, [vp, i32, vp, vp]),
         "ppgpu_allreduce_best": (C.c_int, [vp, vp, vp]),
+        "ppgpu_comm_unique_id": (C.c_int, [vp]),
+        "ppgpu_comm_init_rank": (C.c_int, [vp, i32, i32, vp]),
+        "ppgpu_comm_init_all": (C.c_int, [C.POINTER(vp), i32]),
+        "ppgpu_comm_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),
+        "ppgpu_comm_destroy": (C.c_int, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError here = the library does not export what the header declares
@@ -287,3 +292,31 @@ class Context:
 
     def key_min(self, n, d_keys, d_key2):
         self._ck(LIB.ppgpu_key_min(self._h, n, _ptr(d_keys), _ptr(d_key2)), "ppgpu_key_min")
+
+    # ---- the communicator of a sharded iteration (RCCL, loaded by the library at the first call)
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes from ncclGetUniqueId: rank 0 makes them, every rank passes them to comm_init_rank."""
+        buf = (C.c_uint8 * 128)()
+        rc = LIB.ppgpu_comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc != 0:
+            raise PpgpuError(f"ppgpu_comm_unique_id failed ({rc}): {LIB.ppgpu_last_error().decode()}")
+        return bytes(buf)
+
+    def comm_init_rank(self, world, rank, id128):
+        assert len(id128) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(id128)
+        self._ck(LIB.ppgpu_comm_init_rank(self._h, world, rank, C.cast(buf, C.c_void_p)), "ppgpu_comm_init_rank")
+
+    def comm_info(self):
+        """(ranks, this handle's rank) as RCCL reports them (ncclCommCount, ncclCommUserRank)."""
+        w, r = C.c_int32(), C.c_int32()
+        self._ck(LIB.ppgpu_comm_info(self._h, C.byref(w), C.byref(r)), "ppgpu_comm_info")
+        return w.value, r.value
+
+    def comm_destroy(self):
+        self._ck(LIB.ppgpu_comm_destroy(self._h), "ppgpu_comm_destroy")
+
+    def allreduce_best(self, d_key2, comm=None):
+        """One collective per iteration: the global incumbent, in place on d_key2 (the handle's own communicator by default)."""
+        self._ck(LIB.ppgpu_allreduce_best(self._h, comm, _ptr(d_key2)), "ppgpu_allreduce_best")

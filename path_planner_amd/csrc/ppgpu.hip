@@ -136,6 +136,7 @@ struct ppgpu_ctx {
     void* stage_in = nullptr; size_t stage_in_cap = 0;      // pinned host staging of ppgpu_expand_host
     void* stage_out = nullptr; size_t stage_out_cap = 0;
     DevBuf<unsigned long long> gather;
+    void* comm = nullptr;               // ncclComm_t owned by the handle (ppgpu_comm_init_rank / ppgpu_comm_init_all)
 };
 
 static int require_cfg(ppgpu_ctx* c) {
@@ -179,6 +180,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     if (!c) return PPGPU_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)ppgpu_comm_destroy(c);
     c->grid.release(); c->grid_clear.release(); c->grid_rowclear.release(); c->obst.release(); c->verts.release(); c->ribbons.release(); c->tgrid.release();
     c->sx.release(); c->sy.release(); c->sh.release(); c->samp_ribbons.release();
     c->s_bytes.release(); c->s_u64.release(); c->s_u32a.release(); c->s_u32b.release(); c->s_cand.release();
@@ -1188,35 +1190,147 @@ int ppgpu_key_min(ppgpu_ctx* c, int32_t n, const uint64_t* d_keys, uint64_t* d_k
 
 }  // extern "C"
 
-// RCCL is loaded lazily so that single-GPU users (and the CPU-only build check) do not need it.
+// ------------------------------------------------------------------------------ RCCL (incumbent exchange between ranks)
+// RCCL is loaded lazily so that single-GPU users (and the CPU-only build check) do not need it.  The NCCL ABI is used through
+// dlsym: ncclUniqueId = 128 opaque bytes passed by value, ncclUint64 == 5, ncclSuccess == 0.
 #include <dlfcn.h>
-extern "C" int ppgpu_allreduce_best(ppgpu_ctx* c, void* comm, uint64_t* d_key2) {
-    if (!c || !comm || !d_key2) return fail(PPGPU_EINVAL, "allreduce_best: null argument");
-    HIP_TRY(hipSetDevice(c->device));
-    typedef int (*allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
-    typedef int (*count_t)(void*, int*);
-    // resolved once, published only when complete (contexts may live on several threads)
-    struct Rccl { allgather_t allgather = nullptr; count_t count = nullptr; std::string error; };
-    static Rccl rccl;
+namespace {
+struct PPNcclId { char internal[PPGPU_COMM_ID_BYTES]; };
+struct Rccl {
+    int (*get_unique_id)(PPNcclId*) = nullptr;
+    int (*comm_init_rank)(void**, int, PPNcclId, int) = nullptr;
+    int (*comm_init_all)(void**, int, const int*) = nullptr;
+    int (*comm_count)(void*, int*) = nullptr;
+    int (*comm_user_rank)(void*, int*) = nullptr;
+    int (*comm_destroy)(void*) = nullptr;
+    int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*error_string)(int) = nullptr;
+    std::string error;
+    bool ok = false;
+};
+// resolved once, published only when complete (contexts may live on several threads)
+const Rccl& rccl_table() {
+    static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
         void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!lib) { rccl.error = std::string("cannot load librccl.so: ") + dlerror(); return; }
-        allgather_t ag = (allgather_t)dlsym(lib, "ncclAllGather");
-        count_t cn = (count_t)dlsym(lib, "ncclCommCount");
-        if (!ag || !cn) { rccl.error = "librccl.so lacks ncclAllGather/ncclCommCount"; return; }
-        rccl.allgather = ag; rccl.count = cn;
+        if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) { r.error = std::string("cannot load librccl.so: ") + dlerror(); return; }
+        r.get_unique_id = (decltype(r.get_unique_id))dlsym(lib, "ncclGetUniqueId");
+        r.comm_init_rank = (decltype(r.comm_init_rank))dlsym(lib, "ncclCommInitRank");
+        r.comm_init_all = (decltype(r.comm_init_all))dlsym(lib, "ncclCommInitAll");
+        r.comm_count = (decltype(r.comm_count))dlsym(lib, "ncclCommCount");
+        r.comm_user_rank = (decltype(r.comm_user_rank))dlsym(lib, "ncclCommUserRank");
+        r.comm_destroy = (decltype(r.comm_destroy))dlsym(lib, "ncclCommDestroy");
+        r.all_gather = (decltype(r.all_gather))dlsym(lib, "ncclAllGather");
+        r.error_string = (decltype(r.error_string))dlsym(lib, "ncclGetErrorString");
+        if (!r.get_unique_id || !r.comm_init_rank || !r.comm_init_all || !r.comm_count || !r.comm_user_rank || !r.comm_destroy || !r.all_gather) {
+            r.error = "librccl.so lacks one of ncclGetUniqueId/CommInitRank/CommInitAll/CommCount/CommUserRank/CommDestroy/AllGather";
+            return;
+        }
+        r.ok = true;
     });
-    if (!rccl.allgather || !rccl.count) return fail(PPGPU_ERCCL, rccl.error);
-    const allgather_t allgather = rccl.allgather;
-    const count_t count = rccl.count;
-    int world = 0;
-    if (count(comm, &world) != 0 || world <= 0) return fail(PPGPU_ERCCL, "ncclCommCount failed");
-    int rc = c->gather.reserve((size_t)world * 2, false, c->stream);
-    if (rc) return rc;
+    return r;
+}
+int rccl_fail(const Rccl& r, const char* what, int code) {
+    return fail(PPGPU_ERCCL, std::string(what) + " failed: " + (r.error_string ? r.error_string(code) : "") + " (ncclResult " + std::to_string(code) + ")");
+}
+}  // namespace
+
+extern "C" int ppgpu_comm_unique_id(uint8_t* id128) {
+    if (!id128) return fail(PPGPU_EINVAL, "comm_unique_id: null argument");
+    const Rccl& r = rccl_table();
+    if (!r.ok) return fail(PPGPU_ERCCL, r.error);
+    PPNcclId id;
+    std::memset(&id, 0, sizeof(id));
+    const int rc = r.get_unique_id(&id);
+    if (rc != 0) return rccl_fail(r, "ncclGetUniqueId", rc);
+    std::memcpy(id128, id.internal, PPGPU_COMM_ID_BYTES);
+    return PPGPU_OK;
+}
+
+extern "C" int ppgpu_comm_init_rank(ppgpu_ctx* c, int32_t world, int32_t rank, const uint8_t* id128) {
+    if (!c || !id128) return fail(PPGPU_EINVAL, "comm_init_rank: null argument");
+    if (world <= 0 || rank < 0 || rank >= world) return fail(PPGPU_EINVAL, "comm_init_rank: rank must lie in [0, world)");
+    if (c->comm) return fail(PPGPU_ESTATE, "comm_init_rank: the handle already has a communicator (ppgpu_comm_destroy first)");
+    const Rccl& r = rccl_table();
+    if (!r.ok) return fail(PPGPU_ERCCL, r.error);
+    HIP_TRY(hipSetDevice(c->device));
+    PPNcclId id;
+    std::memcpy(id.internal, id128, PPGPU_COMM_ID_BYTES);
+    void* comm = nullptr;
+    const int rc = r.comm_init_rank(&comm, world, id, rank);
+    if (rc != 0 || !comm) return rccl_fail(r, "ncclCommInitRank", rc);
+    c->comm = comm;
+    int rc2 = c->gather.reserve((size_t)world * 2, false, c->stream);
+    if (rc2) return rc2;
+    return PPGPU_OK;
+}
+
+extern "C" int ppgpu_comm_init_all(ppgpu_ctx** ctxs, int32_t n) {
+    if (!ctxs || n <= 0) return fail(PPGPU_EINVAL, "comm_init_all: bad arguments");
+    std::vector<int> devs((size_t)n);
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i]) return fail(PPGPU_EINVAL, "comm_init_all: null context");
+        if (ctxs[i]->comm) return fail(PPGPU_ESTATE, "comm_init_all: a handle already has a communicator");
+        devs[(size_t)i] = ctxs[i]->device;
+        for (int j = 0; j < i; j++)
+            if (devs[(size_t)j] == devs[(size_t)i]) return fail(PPGPU_EINVAL, "comm_init_all: RCCL takes one rank per device; two handles share device " + std::to_string(devs[(size_t)i]));
+    }
+    const Rccl& r = rccl_table();
+    if (!r.ok) return fail(PPGPU_ERCCL, r.error);
+    std::vector<void*> comms((size_t)n, nullptr);
+    const int rc = r.comm_init_all(comms.data(), n, devs.data());
+    if (rc != 0) return rccl_fail(r, "ncclCommInitAll", rc);
+    for (int i = 0; i < n; i++) {
+        ctxs[i]->comm = comms[(size_t)i];
+        HIP_TRY(hipSetDevice(ctxs[i]->device));
+        int rc2 = ctxs[i]->gather.reserve((size_t)n * 2, false, ctxs[i]->stream);
+        if (rc2) return rc2;
+    }
+    return PPGPU_OK;
+}
+
+extern "C" int ppgpu_comm_info(ppgpu_ctx* c, int32_t* world, int32_t* rank) {
+    if (!c) return fail(PPGPU_EINVAL, "comm_info: null context");
+    if (!c->comm) return fail(PPGPU_ESTATE, "comm_info: the handle has no communicator");
+    const Rccl& r = rccl_table();
+    if (!r.ok) return fail(PPGPU_ERCCL, r.error);
+    int w = 0, k = 0, rc;
+    if ((rc = r.comm_count(c->comm, &w)) != 0) return rccl_fail(r, "ncclCommCount", rc);
+    if ((rc = r.comm_user_rank(c->comm, &k)) != 0) return rccl_fail(r, "ncclCommUserRank", rc);
+    if (world) *world = w;
+    if (rank) *rank = k;
+    return PPGPU_OK;
+}
+
+extern "C" int ppgpu_comm_destroy(ppgpu_ctx* c) {
+    if (!c) return fail(PPGPU_EINVAL, "comm_destroy: null context");
+    if (!c->comm) return PPGPU_OK;
+    const Rccl& r = rccl_table();
+    if (!r.ok) return fail(PPGPU_ERCCL, r.error);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    const int rc = r.comm_destroy(c->comm);
+    c->comm = nullptr;
+    if (rc != 0) return rccl_fail(r, "ncclCommDestroy", rc);
+    return PPGPU_OK;
+}
+
+extern "C" int ppgpu_allreduce_best(ppgpu_ctx* c, void* comm, uint64_t* d_key2) {
+    if (!c || !d_key2) return fail(PPGPU_EINVAL, "allreduce_best: null argument");
+    if (!comm) comm = c->comm;
+    if (!comm) return fail(PPGPU_ESTATE, "allreduce_best: no communicator (pass one, or ppgpu_comm_init_rank / ppgpu_comm_init_all first)");
+    HIP_TRY(hipSetDevice(c->device));
+    const Rccl& r = rccl_table();
+    if (!r.ok) return fail(PPGPU_ERCCL, r.error);
+    int world = 0, rc;
+    if ((rc = r.comm_count(comm, &world)) != 0 || world <= 0) return rccl_fail(r, "ncclCommCount", rc);
+    int rc2 = c->gather.reserve((size_t)world * 2, false, c->stream);
+    if (rc2) return rc2;
     // one collective: 16 bytes per rank over xGMI; ncclUint64 == 5 in the NCCL ABI
-    if (allgather(d_key2, c->gather.p, 2, 5, comm, c->stream) != 0) return fail(PPGPU_ERCCL, "ncclAllGather failed");
+    if ((rc = r.all_gather(d_key2, c->gather.p, 2, 5, comm, c->stream)) != 0) return rccl_fail(r, "ncclAllGather", rc);
     hipLaunchKernelGGL(pp_k_key_min_n, dim3(1), dim3(64), 0, c->stream, c->gather.p, world, (unsigned long long*)d_key2);
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;

@@ -31,3 +31,13 @@ def _prepasses_on_small_launches(monkeypatch):
     setting gives the same bytes.  (Read by ppgpu_create, also in the plan_cli subprocesses.)"""
     monkeypatch.setenv("PPGPU_PREPASS_MIN_EDGES", "0")
     yield
+
+
+@pytest.fixture(params=["prepasses_always", "production_route"])
+def prepass_route(request, monkeypatch, _prepasses_on_small_launches):
+    """The plan-level oracle tests run twice: with the prepasses forced onto every launch (above), and with the production
+    setting — PPGPU_PREPASS_MIN_EDGES unset, so the 40-edge launches of the reference-shaped expand() path
+    (SamplingBasedPlanner.cpp:52-151) skip pp_k_plan_skips / pp_k_approach_events exactly as they do outside the tests."""
+    if request.param == "production_route":
+        monkeypatch.delenv("PPGPU_PREPASS_MIN_EDGES", raising=False)
+    return request.param

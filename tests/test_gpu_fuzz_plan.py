@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("seed,rounds", [(1, 24), (7, 12), (21, 23)])   # seed 21: rounds 8 and 22 meet degenerate Dubins problems
-def test_random_plan_calls_agree_with_the_oracle_planner(seed, rounds):
+def test_random_plan_calls_agree_with_the_oracle_planner(seed, rounds, prepass_route):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_plan
     import oracle as orc

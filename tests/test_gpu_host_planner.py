@@ -124,7 +124,7 @@ def _compare(host, st, plan, allow_order_fallbacks=False):
 
 
 @pytest.mark.parametrize("name,init,calls", [("cfg1", 64, 60), ("cfg2", 256, 40), ("cfg3", 512, 30)])
-def test_host_planner_matches_oracle_plan(name, init, calls):
+def test_host_planner_matches_oracle_plan(name, init, calls, prepass_route):
     import oracle as orc
     from path_planner_amd import workloads
     w = workloads.by_name(name)
@@ -332,7 +332,7 @@ def _late_goal_workload(name, frac, gseed, blob):
 
 
 @pytest.mark.parametrize("name,frac,gseed,blob,init,expect", LATE_GOALS)
-def test_first_goal_iteration_matches_when_the_first_goal_comes_late(name, frac, gseed, blob, init, expect):
+def test_first_goal_iteration_matches_when_the_first_goal_comes_late(name, frac, gseed, blob, init, expect, prepass_route):
     """BASELINE's second metric on cases where it can differ: the first goal is found at iteration 6 to 8 (after as many
     doublings of the sample set), and the host planner must find it in the same iteration, with the same statistics and the
     same plan segment by segment."""

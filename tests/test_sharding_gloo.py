@@ -111,3 +111,31 @@ def test_key_order_matches_float_order_and_ties_take_lowest_index():
     assert np.array_equal(sharding.local_best_key([1.0], [False]), sharding.NO_KEY)
     g = sharding.combine_keys([[sharding.f_bits(2.0), 900], [sharding.f_bits(2.0), 17], sharding.NO_KEY])
     assert g[1] == 17
+
+
+def test_bench_launches_its_own_ranks_and_fails_at_the_device_not_at_the_launcher():
+    """`python bench.py --gpus 2` with no launcher around it starts the two ranks itself (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set per rank, before any GPU call).  On a box without a GPU each rank must die in ppgpu_create — the product has no
+    CPU fallback — and the launcher must stop the others and report failure promptly instead of hanging."""
+    import subprocess
+    import time
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the GPU suite runs the launcher for real (test_gpu_bench.py)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    assert "ppgpu_create" in out.stderr and "WORLD_SIZE" not in out.stderr, out.stderr[-2000:]
+    assert "stopping the other ranks" in out.stderr
+    assert out.stdout.strip() == ""
+    assert time.time() - t0 < 120
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=4" in out.stderr
