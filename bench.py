@@ -114,6 +114,10 @@ def run_rank(args):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
 
     import numpy as np
+    # torch BEFORE the HIP library: the wheel carries its own ROCm runtime, and whichever libamdhip64 is loaded first serves both
+    # (loaded the other way round torch finds "No HIP GPUs").  Importing torch does not touch the device.
+    import torch
+    import torch.distributed as dist
     from path_planner_amd import api, sharding, workloads
     from path_planner_amd.types import RESULT_DTYPE, F_INFEASIBLE
 
@@ -124,8 +128,6 @@ def run_rank(args):
     if rehearsal:
         local = 0
     ctx = api.Context(local)                 # first device call of the process: no gfx950 device = PpgpuError here, nothing else runs
-    import torch
-    import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     rccl_ranks = None

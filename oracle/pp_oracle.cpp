@@ -772,6 +772,10 @@ double computeApproxToGo(Vertex& v, const Config& cfg) {  // Vertex.cpp:49-64 (p
         v.approxToGo = 0;
         return 0;
     }
+    if (cfg.skipHeuristicValue) {
+        v.approxToGo = 0;
+        return 0;
+    }
     double max = v.ribbons.approximateDistanceUntilDone(v.state.x, v.state.y, v.state.heading);
     v.approxToGo = max / cfg.maxSpeed * cfg.timePenaltyFactor;
     return v.approxToGo;

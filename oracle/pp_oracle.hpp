@@ -160,6 +160,10 @@ struct Config {
     // Checker-only knob mirroring the DEVICE contract (include/ppgpu.h, PPGPU_F_RIBBON_OVF): with a TSP heuristic
     // and more ribbons than this, h is reported as 0 instead of enumerating 2^n n! tours.  0 = no limit (reference).
     int tspRibbonLimit = 0;
+    // Checker-only: leave the heuristic's VALUE out (h = 0) where the comparison discards it anyway; flags are decided as usual.
+    // The reference's Dubins-TSP recursion (RibbonManager.cpp:97-140) solves a Dubins problem per tree node: 2^n n! leaves, 6 s per
+    // edge at 8 ribbons, minutes at 9 — what made a randomized round look hung.
+    bool skipHeuristicValue = false;
     double slowSpeed() const { return slowSpeedRaw <= 0 ? maxSpeed : slowSpeedRaw; }  // PlannerConfig.h:168-171
 };
 

@@ -3,6 +3,8 @@
 // records (include/ppgpu.h) the HIP library produces.  Not linked into any product library.
 #include <cmath>
 #include <cstring>
+#include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -18,7 +20,21 @@ struct World {
     ppgpu_config pc{};
     bool have_cfg = false;
     int tsp_limit = 8;   // PP_TSP_MAX of the device path; ppo_world_set_tsp_limit(0) restores the unbounded reference
+    bool skip_heuristic_value = false;   // Config::skipHeuristicValue
 };
+
+// No C++ exception may cross the ctypes boundary (it would end the test process with std::terminate): anything other than the
+// SampleError the records have a flag for is kept here and turns the call's return code into -2.
+std::mutex g_error_mutex;
+std::string g_error;
+void note_error(const char* where, const std::exception& e) {
+    std::lock_guard<std::mutex> lock(g_error_mutex);
+    if (g_error.empty()) g_error = std::string(where) + ": " + e.what();
+}
+bool take_error() {
+    std::lock_guard<std::mutex> lock(g_error_mutex);
+    return !g_error.empty();
+}
 
 Config make_config(const World& w) {
     Config c;
@@ -37,6 +53,7 @@ Config make_config(const World& w) {
     c.map = &w.map;
     c.obstacles = &w.obstacles;
     c.tspRibbonLimit = w.tsp_limit;
+    c.skipHeuristicValue = w.skip_heuristic_value;
     RibbonManager::RibbonWidth = p.ribbon_width;
     return c;
 }
@@ -242,6 +259,15 @@ void* ppo_world_create() { return new World(); }
 void ppo_world_destroy(void* w) { delete (World*)w; }
 void ppo_world_set_config(void* w, const ppgpu_config* c) { ((World*)w)->pc = *c; ((World*)w)->have_cfg = true; RibbonManager::RibbonWidth = c->ribbon_width; }
 void ppo_world_set_tsp_limit(void* w, int limit) { ((World*)w)->tsp_limit = limit; }
+void ppo_world_set_skip_heuristic_value(void* w, int on) { ((World*)w)->skip_heuristic_value = on != 0; }
+// message of the first exception a call swallowed (empty string: none); reading clears it
+const char* ppo_last_error() {
+    static thread_local std::string out;
+    std::lock_guard<std::mutex> lock(g_error_mutex);
+    out = g_error;
+    g_error.clear();
+    return out.c_str();
+}
 void ppo_world_set_grid(void* w, const uint8_t* cells, int rows, int cols, double res) {
     World* W = (World*)w;
     if (rows == 0) { W->map = GridMap(); return; }
@@ -386,8 +412,14 @@ static void cost_one(const World& W, const Config& cfg, const ppgpu_vertex* vert
     double rho = cov ? cfg.coverageTurningRadius : cfg.turningRadius;
     double speed = (c & PPGPU_EDGE_SLOW) ? cfg.slowSpeed() : cfg.maxSpeed;
     State tgt(sx[target], sy[target], sh[target], speed, 0);
-    Vertex end = connectState(src, 0, tgt, rho, cov);
-    finish_edge(W, cfg, src, end, out, child, stride);
+    try {
+        Vertex end = connectState(src, 0, tgt, rho, cov);
+        finish_edge(W, cfg, src, end, out, child, stride);
+    } catch (const std::exception& e) {   // not a SampleError (finish_edge turns those into PPGPU_F_THROWS): a checker failure
+        memset(out, 0, sizeof(*out));
+        out->flags = PPGPU_F_THROWS | PPGPU_F_INFEASIBLE;
+        note_error("ppo_cost_edges", e);
+    }
 }
 
 int ppo_cost_edges(void* w, const ppgpu_vertex* verts, const double* pool, const double* sx, const double* sy,
@@ -407,7 +439,7 @@ int ppo_cost_edges(void* w, const ppgpu_vertex* verts, const double* pool, const
         for (int t = 0; t < n_threads; t++) th.emplace_back(work, n * t / n_threads, n * (t + 1) / n_threads);
         for (auto& t : th) t.join();
     }
-    return 0;
+    return take_error() ? -2 : 0;
 }
 
 // Vertex::connect(start, DubinsWrapper, coverageAllowed) + computeTrueCost (Vertex.cpp:28-36, Edge.cpp:208-216): what
@@ -436,9 +468,12 @@ int ppo_cost_wrapper_edges(void* w, const ppgpu_vertex* verts, const double* poo
             finish_edge(*W, cfg, src, end, out + e, child_ribbons ? child_ribbons + (size_t)e * stride * 4 : nullptr, stride);
         } catch (SampleError&) {     // sampling the wrapper's end state threw while connecting
             out[e].flags = PPGPU_F_THROWS | PPGPU_F_INFEASIBLE;
+        } catch (const std::exception& ex) {
+            out[e].flags = PPGPU_F_THROWS | PPGPU_F_INFEASIBLE;
+            note_error("ppo_cost_wrapper_edges", ex);
         }
     }
-    return 0;
+    return take_error() ? -2 : 0;
 }
 
 // Dubins lengths (Edge::computeApproxCost's wrapper.length()), layout as ppgpu_dubins_lengths.

@@ -76,6 +76,8 @@ for _n, _r, _a in [
     ("ppo_world_destroy", None, [vp]),
     ("ppo_world_set_config", None, [vp, C.POINTER(PpgpuConfig)]),
     ("ppo_world_set_tsp_limit", None, [vp, i32]),
+    ("ppo_world_set_skip_heuristic_value", None, [vp, i32]),
+    ("ppo_last_error", C.c_char_p, []),
     ("ppo_world_set_grid", None, [vp, vp, i32, i32, dbl]),
     ("ppo_world_load_grid_text", i32, [vp, C.c_char_p, C.POINTER(i32), C.POINTER(dbl)]),
     ("ppo_world_get_cells", None, [vp, vp]),
@@ -155,6 +157,10 @@ class World:
             k = O.ppo_add_samples(self.h, _p(b), seed, r.shape[0], _p(r) if r.shape[0] else None, skip, n, _p(out))
         return out[:k].copy()
 
+    def skip_heuristic_value(self, on=True):
+        """Checker-only: report h = 0 instead of enumerating (for comparisons that discard h and f anyway; flags unchanged)."""
+        O.ppo_world_set_skip_heuristic_value(self.h, 1 if on else 0)
+
     def cost_edges(self, vertices, ribbons4, sx, sy, sh, edges, stride=0, threads=1):
         O.ppo_world_set_config(self.h, C.byref(self.cfg))
         v = np.ascontiguousarray(vertices, dtype=VERTEX_DTYPE)
@@ -166,7 +172,7 @@ class World:
         out = np.zeros(e.shape[0], dtype=RESULT_DTYPE)
         child = np.zeros((e.shape[0], stride, 4), dtype=np.float64) if stride > 0 else None
         rc = O.ppo_cost_edges(self.h, _p(v), _p(r), _p(sx), _p(sy), _p(sh), e.shape[0], _p(e), _p(out), _p(child), stride, threads)
-        assert rc == 0
+        assert rc == 0, (rc, O.ppo_last_error().decode())
         return (out, child) if stride > 0 else out
 
     def cost_wrapper_edges(self, vertices, ribbons4, wedges, stride=0):
@@ -181,7 +187,7 @@ class World:
         out = np.zeros(e.shape[0], dtype=RESULT_DTYPE)
         child = np.zeros((e.shape[0], stride, 4), dtype=np.float64) if stride > 0 else None
         rc = O.ppo_cost_wrapper_edges(self.h, _p(v), _p(r), e.shape[0], _p(e), _p(out), _p(child), stride)
-        assert rc == 0
+        assert rc == 0, (rc, O.ppo_last_error().decode())
         return (out, child) if stride > 0 else out
 
     def dubins_lengths(self, vertices, v0, nv, sx, sy, sh):

@@ -2,12 +2,15 @@
 """GPU box: randomized differential test of the HIP path against the CPU oracle.  Each round draws a world (grid density and
 resolution, obstacle model and count, ribbon layout and width, speeds, radii, horizon, increment, heuristic) and a few hundred
 edges, and requires identical flags / word / ribbon counts / step counts and costs within 1e-5.
-usage: tools/fuzz_parity.py [rounds] [seed]"""
+usage: tools/fuzz_parity.py [rounds] [seed]
+       FUZZ_SIDE=oracle tools/fuzz_parity.py ...   the same rounds on a box without a GPU (the oracle stands in for the device)
+       FUZZ_SIDE=oracle FUZZ_SAVE_RNG=177:tests/golden/fuzz_seed102_round177_rng.json tools/fuzz_parity.py 177 102
+           writes the generator state before that round, so a test can run that one round (tests/test_gpu_parity.py)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np, torch
-from path_planner_amd import api, workloads
+import numpy as np
+from path_planner_amd import workloads
 from path_planner_amd.types import RESULT_DTYPE, edge_pack, make_config, H_MAX_DISTANCE, H_TSP_POINT_ALL, H_TSP_POINT_K, H_TSP_DUBINS_ALL, H_TSP_DUBINS_K
 from path_planner_amd.workloads import root_vertex
 from parity import compare_results
@@ -27,12 +30,71 @@ def degenerate_dubins(cfg, vert, ti, cbits, sx, sy, sh, grec):
     return ok
 
 
+class GpuSide:
+    """The HIP library through the C ABI (what the tool compares with the oracle)."""
+    def __init__(self, cfg, grid, res):
+        import torch
+        from path_planner_amd import api
+        self.torch, self.ctx = torch, api.Context(0)
+        self.ctx.set_config(cfg); self.ctx.set_grid(grid, res)
+
+    def set_obstacles(self, model, ob):
+        if model == "gaussian":
+            self.ctx.set_gaussian_obstacles(ob)
+        else:
+            self.ctx.set_obstacles(ob if model == "binary" else None)
+
+    def dense(self, root, rib, sx, sy, sh):
+        torch, n = self.torch, len(sx)
+        self.ctx.set_vertices(root, rib); self.ctx.set_samples(sx, sy, sh)
+        ne = 4 * n
+        d_res = torch.zeros(ne * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
+        d_child = torch.zeros(ne * 20 * 4, dtype=torch.float64, device="cuda:0")
+        self.ctx.cost_edges_dense(0, 1, 0, n, 0xF, d_res.data_ptr(), d_child.data_ptr(), 20); self.ctx.synchronize()
+        return d_res.cpu().numpy().view(RESULT_DTYPE), d_child.cpu().numpy().reshape(ne, 20, 4)
+
+    def edge_list(self, v, pool, sx, sy, sh, e2):
+        torch = self.torch
+        self.ctx.set_vertices(v, pool)
+        self.ctx.set_samples(sx, sy, sh)
+        d_e = torch.from_numpy(e2.view(np.int64)).to("cuda:0")
+        d_res2 = torch.zeros(len(e2) * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
+        d_child2 = torch.zeros(len(e2) * 20 * 4, dtype=torch.float64, device="cuda:0")
+        self.ctx.cost_edges_list(len(e2), d_e.data_ptr(), d_res2.data_ptr(), d_child2.data_ptr(), 20); self.ctx.synchronize()
+        return d_res2.cpu().numpy().view(RESULT_DTYPE), d_child2.cpu().numpy().reshape(len(e2), 20, 4)
+
+    def wrapper(self, v, pool, we):
+        self.ctx.set_vertices(v, pool)
+        return self.ctx.cost_wrapper_edges_host(we, stride=20)
+
+
+class OracleSide:
+    """No device: the oracle's own answers stand in for the device's, so that a round — its random draws included, which depend on
+    the results only through flags the two sides agree on — can be replayed on a box without a GPU (FUZZ_SIDE=oracle; how the
+    abort recorded in round 2's fz_hang.log was found: DESIGN.md)."""
+    def __init__(self, cfg, grid, res):
+        self.world = None
+
+    def set_obstacles(self, model, ob):
+        pass
+
+    def dense(self, root, rib, sx, sy, sh):
+        n = len(sx); ne = 4 * n
+        e = edge_pack(np.zeros(ne, dtype=np.uint64), np.repeat(np.arange(n), 4), np.tile(np.arange(4), n))
+        return self.world.cost_edges(root, rib, sx, sy, sh, e, stride=20)
+
+    def edge_list(self, v, pool, sx, sy, sh, e2):
+        return self.world.cost_edges(v, pool, sx, sy, sh, e2, stride=20)
+
+    def wrapper(self, v, pool, we):
+        return self.world.cost_wrapper_edges(v, pool, we, stride=20)
+
+
 def wrapper_leg(rng, ctx, world, cfg, v, pool, sx, sy, sh, dub_h, per_vertex=10):
     """Edges whose curve is given (ppgpu_cost_wrapper_edges_host, the previous plan's segments): the oracle's shortest path from
     each vertex to a few targets, at the planner's or a foreign speed, some entered part-way along (curve start time before
     the vertex's time) and some cut short (DubinsWrapper::updateEndTime)."""
     from path_planner_amd.types import WRAPPER_EDGE_DTYPE
-    ctx.set_vertices(v, pool)
     we = []
     for i in range(len(v)):
         for t in rng.choice(len(sx), size=min(per_vertex, len(sx)), replace=False):
@@ -59,7 +121,11 @@ def wrapper_leg(rng, ctx, world, cfg, v, pool, sx, sy, sh, dub_h, per_vertex=10)
     if not we:
         return True
     we = np.array(we, dtype=WRAPPER_EDGE_DTYPE)
-    gpu, gchild = ctx.cost_wrapper_edges_host(we, stride=20)
+    if hasattr(ctx, "wrapper"):
+        gpu, gchild = ctx.wrapper(v, pool, we)
+    else:                                   # a bare api.Context (tests/test_gpu_parity.py::test_wrapper_edges_match_oracle)
+        ctx.set_vertices(v, pool)
+        gpu, gchild = ctx.cost_wrapper_edges_host(we, stride=20)
     cpu, cchild = world.cost_wrapper_edges(v, pool, we, stride=20)
     rep = compare_results(gpu, cpu, gchild, cchild, allow_word_ties=False, skip_heuristic=dub_h)
     print("    wrapper edges:", len(we), "->", "ok" if rep["ok"] else "MISMATCH", "worst_rel %.2e" % rep["worst_rel"], "feasible", rep["n_feasible"], flush=True)
@@ -74,7 +140,8 @@ def wrapper_leg(rng, ctx, world, cfg, v, pool, sx, sy, sh, dub_h, per_vertex=10)
     return rep["ok"]
 
 
-def one_round(rng, rid):
+def one_round(rng, rid, side=None):
+    Side = side or (OracleSide if os.environ.get("FUZZ_SIDE") == "oracle" else GpuSide)
     size = int(rng.choice([128, 256, 400]))
     res = float(rng.choice([0.25, 0.5, 1.0]))
     extent = size * res
@@ -116,18 +183,25 @@ def one_round(rng, rid):
     orc.O.ppo_set_ribbon_width(cfg.ribbon_width)
     model = rng.choice(["none", "binary", "binary", "gaussian"])
     nob = int(rng.integers(1, 90))
-    ctx = api.Context(0)
-    ctx.set_config(cfg); ctx.set_grid(grid, res)
+    ctx = Side(cfg, grid, res)
+    ob = None
     if model == "binary":
         ob = workloads.obstacles(nob, int(rng.integers(1, 1 << 30)), extent, time=t0, width=float(rng.uniform(2, 8)), length=float(rng.uniform(4, 20)),
                                  keep_free=(cx, cy, 8))
-        ctx.set_obstacles(ob); world = orc.World(cfg, grid, res, ob)
+        world = orc.World(cfg, grid, res, ob)
     elif model == "gaussian":
         ob = np.column_stack([rng.uniform(0, extent, nob), rng.uniform(0, extent, nob), rng.uniform(0, 2 * np.pi, nob), rng.uniform(0, 3, nob),
                               np.full(nob, t0)])
-        ctx.set_gaussian_obstacles(ob); world = orc.World(cfg, grid, res, gauss=ob)
+        world = orc.World(cfg, grid, res, gauss=ob)
     else:
-        ctx.set_obstacles(None); world = orc.World(cfg, grid, res)
+        world = orc.World(cfg, grid, res)
+    ctx.set_obstacles(str(model), ob)
+    ctx.world = world
+    if heur in (H_TSP_DUBINS_ALL, H_TSP_DUBINS_K):
+        # h and f are not compared in this tool for the Dubins-TSP heuristics (dub_h below), so the checker does not enumerate them:
+        # the reference's recursion solves a Dubins problem per tree node, 2^n n! leaves — 6 s per edge at 8 ribbons, minutes at 9,
+        # which is what stopped seed 102 in round 177
+        world.skip_heuristic_value(True)
     root = root_vertex(cx, cy, float(rng.uniform(0, 2 * np.pi)), max_speed, t0 + float(rng.choice([0.0, 0.37])), rib,
                        cct=(t0 if nrib == 0 else -1.0))
     n = 160
@@ -140,19 +214,15 @@ def one_round(rng, rid):
     far = np.hypot(sx - cx, sy - cy) > 2 * cfg.collision_checking_increment
     sx, sy, sh = sx[far], sy[far], sh[far]
     n = len(sx)
-    ctx.set_vertices(root, rib); ctx.set_samples(sx, sy, sh)
     ne = 4 * n
-    d_res = torch.zeros(ne * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
-    d_child = torch.zeros(ne * 20 * 4, dtype=torch.float64, device="cuda:0")
-    ctx.cost_edges_dense(0, 1, 0, n, 0xF, d_res.data_ptr(), d_child.data_ptr(), 20); ctx.synchronize()
-    gpu, gchild = d_res.cpu().numpy().view(RESULT_DTYPE), d_child.cpu().numpy().reshape(ne, 20, 4)
+    gpu, gchild = ctx.dense(root, rib, sx, sy, sh)
     e = edge_pack(np.zeros(ne, dtype=np.uint64), np.repeat(np.arange(n), 4), np.tile(np.arange(4), n))
     cpu, cchild = world.cost_edges(root, rib, sx, sy, sh, e, stride=20)
     dub_h = heur in (H_TSP_DUBINS_ALL, H_TSP_DUBINS_K)     # see DESIGN.md "Numerics": compared by the dedicated tests, not here
     rep = compare_results(gpu, cpu, gchild, cchild, allow_word_ties=True, skip_heuristic=dub_h)
     if os.environ.get("FUZZ_DUMP") == str(rid):
         import pickle
-        pickle.dump({"cfg_kw": kw, "grid": grid, "res": res, "model": str(model), "ob": (ob if model != "none" else None), "root": root, "rib": rib,
+        pickle.dump({"cfg_kw": kw, "grid": grid, "res": res, "model": str(model), "ob": ob, "root": root, "rib": rib,
                      "sx": sx, "sy": sy, "sh": sh}, open(os.path.join(ROOT, "gpurun_out", "fuzz_case.pkl"), "wb"))
     tag = f"round {rid}: grid {size}@{res} rib {nrib} w {cfg.ribbon_width} heur {heur} K {cfg.tsp_k} obst {model}/{nob} t0 {t0} inc {cfg.collision_checking_increment}"
     print(tag, "->", "ok" if rep["ok"] else "MISMATCH", "worst_rel %.2e" % rep["worst_rel"], "feasible", rep["n_feasible"], "of", rep["n"], flush=True)
@@ -171,8 +241,6 @@ def one_round(rng, rid):
             v[k2] = (r_["end_x"], r_["end_y"], r_["end_heading"], r_["end_speed"], r_["end_time"], r_["g"], r_["coverage_completed_time"], off, nr)
             pool.append(cchild[ei, :nr]); off += nr
         pool = np.concatenate(pool) if off else np.zeros((0, 4))
-        ctx.set_vertices(v, pool)
-        ctx.set_samples(sx, sy, sh)
         m = min(n, 24)
         vi = np.repeat(np.arange(len(pick)), m * 2)
         ti = np.tile(np.repeat(rng.choice(n, size=m, replace=False), 2), len(pick))
@@ -181,11 +249,7 @@ def one_round(rng, rid):
         # drop edges whose target is closer than the increment to the source (never built by the reference)
         keep = np.hypot(sx[ti] - v["x"][vi], sy[ti] - v["y"][vi]) > 2 * cfg.collision_checking_increment
         e2 = np.ascontiguousarray(e2[keep])
-        d_e = torch.from_numpy(e2.view(np.int64)).to("cuda:0")
-        d_res2 = torch.zeros(len(e2) * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
-        d_child2 = torch.zeros(len(e2) * 20 * 4, dtype=torch.float64, device="cuda:0")
-        ctx.cost_edges_list(len(e2), d_e.data_ptr(), d_res2.data_ptr(), d_child2.data_ptr(), 20); ctx.synchronize()
-        gpu2, gchild2 = d_res2.cpu().numpy().view(RESULT_DTYPE), d_child2.cpu().numpy().reshape(len(e2), 20, 4)
+        gpu2, gchild2 = ctx.edge_list(v, pool, sx, sy, sh, e2)
         cpu2, cchild2 = world.cost_edges(v, pool, sx, sy, sh, e2, stride=20)
         rep2 = compare_results(gpu2, cpu2, gchild2, cchild2, allow_word_ties=True, skip_heuristic=dub_h)
         ok2 = rep2["ok"]
@@ -257,6 +321,17 @@ def one_round(rng, rid):
     return rep["ok"] and ok2 and ok3
 
 
+def rng_from_saved(path):
+    """The numpy Generator a FUZZ_SAVE_RNG file describes."""
+    import json
+    d = json.load(open(path))
+    rng = np.random.default_rng(0)
+    assert rng.bit_generator.state["bit_generator"] == d["bit_generator"]
+    rng.bit_generator.state = {"bit_generator": d["bit_generator"], "state": {k: int(v) for k, v in d["state"].items()},
+                               "has_uint32": d["has_uint32"], "uinteger": d["uinteger"]}
+    return rng, d["before_round"]
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -265,6 +340,14 @@ def main():
     t = time.time()
     for r in range(rounds):
         bad += 0 if one_round(rng, r) else 1
+    save = os.environ.get("FUZZ_SAVE_RNG")
+    if save:
+        import json
+        at, path = save.split(":", 1)
+        assert int(at) == rounds, "FUZZ_SAVE_RNG=<round>:<file> saves the state after `rounds` rounds"
+        st = rng.bit_generator.state
+        json.dump({"seed": seed, "before_round": rounds, "bit_generator": st["bit_generator"], "state": {k: str(v) for k, v in st["state"].items()},
+                   "has_uint32": st["has_uint32"], "uinteger": st["uinteger"]}, open(path, "w"), indent=1)
     orc.O.ppo_set_ribbon_width(1.5)
     print(f"{rounds} rounds, {bad} with mismatches, {time.time() - t:.0f} s")
     sys.exit(1 if bad else 0)
