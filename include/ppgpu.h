@@ -106,6 +106,11 @@ typedef struct ppgpu_vertex {
 #define PPGPU_F_RIBBON_OVF   0x04u /* child ribbon list exceeded ribbon_stride or 64, or the heuristic's enumeration limit
                                       * (8 ribbons for the brute-force TSP heuristics; 12 for TspPointRobotNoSplitKRibbons
                                       * while its tree has fewer than 2^21 prefixes): h = 0, f = g, never silent */
+#define PPGPU_F_RIBBON_LOST  0x40u /* the child's list outgrew the device's 64 ribbons per vertex while the edge was swept: pieces
+                                      * were DROPPED, so the record's coverage state is not the reference's (which has no limit) and
+                                      * must not be searched on.  Always together with PPGPU_F_RIBBON_OVF.  Without this bit,
+                                      * PPGPU_F_RIBBON_OVF on a record whose child count fits ribbon_stride means only that the
+                                      * heuristic was not enumerated: the list itself came back whole */
 #define PPGPU_F_DUBINS_ERR   0x08u /* dubins_path_sample failed twice (DubinsWrapper.cpp:43-45)    */
 #define PPGPU_F_GOAL         0x10u /* SamplingBasedPlanner::goalCondition(child)                   */
 #define PPGPU_F_DONE         0x20u /* child->done()                                                */

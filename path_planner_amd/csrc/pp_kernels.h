@@ -1231,7 +1231,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
 
     // this vertex's ribbons, one per lane (Vertex::connect copies the parent's RibbonManager, Vertex.cpp:24)
     PPRibbon rib = {0, 0, 0, 0};
-    if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
+    if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF | PPGPU_F_RIBBON_LOST; }
     if (lane < nrib) {
         const double* rp = p.ribbons + 4 * ((size_t)V->ribbon_offset + lane);
         rib.sx = rp[0]; rib.sy = rp[1]; rib.ex = rp[2]; rib.ey = rp[3];
@@ -1366,7 +1366,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                 nrib = pp_ribbons_event(rib, nrib, w, xj, yj, ((coverMask >> j) & 1ull) != 0ull, lds, D, adv);
                 PP_CNT(if (adv == -3) dbgFar++; else if (adv == -2) dbgNoChange++; else if (adv >= 0) dbgInPlace++);
                 PP_TRACE("[wave]   event %d: adv %d D %.17g nrib %d cover %d x %.17g y %.17g\n", base + j, adv, D, nrib, (int)((coverMask >> j) & 1ull), xj, yj);
-                if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
+                if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF | PPGPU_F_RIBBON_LOST; }
 
 #ifndef PP_NO_CORRIDOR_RUN
                 if (adv >= 0 && j + 1 < climit && !runFailed) {
@@ -1494,7 +1494,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
             double Dunused;
             int advUnused;
             nrib = pp_ribbons_event(rib, nrib, w, ix, iy, true, lds, Dunused, advUnused);
-            if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF; }
+            if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF | PPGPU_F_RIBBON_LOST; }
         }
         if (nrib == 0) {
             if (cct == -1) cct = tfinal;
@@ -2373,7 +2373,7 @@ __global__ __launch_bounds__(256) void pp_k_expand_candidates(const double* leng
 #define PP_ORD_INNER 1024            // candidates of the inner ring whose costs set the filter threshold
 __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, double max_speed, double tpf, int two_radii, const double* bound,
                                                          const double* g_key, const int* g_val, const double* g_len, long long g_cap,
-                                                         const int* cand_count, int* out_idx, unsigned* fallbacks) {
+                                                         const int* cand_count, const double* lengths, int* out_idx, unsigned* fallbacks) {
     __shared__ double cd[PP_ORD_CAP];        // 96 KB of the CU's 160 KB LDS: distance and list position (later sample index); the lengths
     __shared__ int ci[PP_ORD_CAP];           // stay in the list in memory and are fetched by position when the replay gets there
     __shared__ double inner[PP_ORD_INNER];
@@ -2545,13 +2545,19 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
 #ifdef PP_DBG_ORD
         if (lane == 0) printf("[ord] FALLBACK vr %d: k %d M %d cap %lld kept %d unsafeFiltered %d hsize %d | U %g dq %g inner %d threshold %g\n", vr, k, M, g_cap, Mk, (int)unsafeFiltered, hsize, U, dq, nInner, threshold);
 #endif
-        const int Mc = (long long)M < g_cap ? M : (int)g_cap;
+        // More candidates within the bound than the list holds (M > g_cap: slots beyond it were dropped in the order the atomics
+        // happened to arrive): the truncated list is not a set anyone can name, so the selection runs over the vertex's whole row
+        // of lengths instead (-1 = closer than the increment, never a candidate: SamplingBasedPlanner.cpp:111)
+        const bool fullRow = (long long)M > g_cap;
+        const long long Mc = fullRow ? ns : (long long)M;
+        const double* row = lengths + (size_t)(vr >> 1) * (size_t)ns * 2 + r;
         double prevL = -INFINITY; int prevI = -1;
         for (int j = 0; j < k; j++) {
             double bl = INFINITY; int bi = 0x7fffffff;
-            for (int c = lane; c < Mc; c += PP_WAVE) {
-                const double l = gl[c];
-                const int i = gv[c];
+            for (long long c = lane; c < Mc; c += PP_WAVE) {
+                const double l = fullRow ? row[2 * c] : gl[c];
+                const int i = fullRow ? (int)c : gv[c];
+                if (fullRow && !(l >= 0)) continue;
                 const bool after = (l > prevL) || (l == prevL && i > prevI);
                 if (after && (l < bl || (l == bl && i < bi))) { bl = l; bi = i; }
             }

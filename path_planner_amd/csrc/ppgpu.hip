@@ -699,7 +699,7 @@ static int launch_expand_order(ppgpu_ctx* c, int nv, int k) {
     hipLaunchKernelGGL(pp_k_expand_candidates, dim3((unsigned)nblk, (unsigned)nv), dim3(256), 0, c->stream, c->tmp_lengths.p, c->verts.p, c->sx.p,
                        c->sy.p, ns, two_radii, c->ord_bound.p, c->ord_key.p, c->ord_val.p, c->ord_len.p, cap, c->ord_count.p);
     hipLaunchKernelGGL(pp_k_expand_order, dim3((unsigned)(nv * 2)), dim3(256), 0, c->stream, ns, k, c->cfg.max_speed, c->cfg.time_penalty_factor,
-                       two_radii, c->ord_bound.p, c->ord_key.p, c->ord_val.p, c->ord_len.p, cap, c->ord_count.p, c->ord_idx.p, c->ord_fallbacks.p);
+                       two_radii, c->ord_bound.p, c->ord_key.p, c->ord_val.p, c->ord_len.p, cap, c->ord_count.p, c->tmp_lengths.p, c->ord_idx.p, c->ord_fallbacks.p);
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;
 }

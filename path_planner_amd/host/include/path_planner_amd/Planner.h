@@ -6,6 +6,7 @@
 // The A* control flow, the open list and the clock polling stay on the host in the reference's order, so that with the same
 // injected clock and seed the same vertices are expanded in the same order.
 #pragma once
+#include <algorithm>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -41,6 +42,7 @@ public:
         long FirstGoalIteration = -1;
         unsigned long EdgesCosted = 0;
         unsigned long HostHeuristics = 0;     // children whose ribbon list exceeded the device's TSP enumeration: h computed on the host
+        unsigned long DeadlineStops = 0;      // round trips / sample doublings not started because they could not end before the deadline
         unsigned long OrderFallbacks = 0;     // (vertex, radius) lists whose push order the device could not replay (ppgpu_order_fallbacks)
     };
     Planner();
@@ -75,6 +77,27 @@ public:
     // run `job` on this context's thread; wait() blocks until it has finished and rethrows what it threw
     void run(std::function<void()> job);
     void wait();
+
+    // What this device's recent round trips and sample doublings took (wall seconds), kept with the context so that the first
+    // cycle of a new planner already knows: the deadline guard (PlannerConfig::deadlineGuard) predicts the next one from them.
+    // Written and read by the planning thread only.
+    struct Observed { double samples = 0, seconds = 0; };
+    Observed trips[4];        // the last round trips of expandBatch: sample count, duration
+    int tripSlot = 0;
+    Observed doubling;        // the last addSamples: attempts, duration
+    void noteTrip(double samples, double seconds) { trips[tripSlot] = {samples, seconds}; tripSlot = (tripSlot + 1) % 4; }
+    // a round trip over `samples` samples: no longer than the recent ones scaled up to that sample count (their cost grows
+    // less than linearly), plus a margin
+    double predictTrip(double samples) const {
+        double worst = 0;
+        for (const Observed& o : trips)
+            if (o.seconds > 0) worst = std::max(worst, o.seconds * std::max(1.0, samples / std::max(1.0, o.samples)));
+        return worst * 1.15 + 1e-4;
+    }
+    double predictDoubling(double attempts) const {
+        if (doubling.seconds <= 0) return 0;
+        return doubling.seconds * std::max(1.0, attempts / std::max(1.0, doubling.samples)) * 1.15 + 1e-4;
+    }
 
 private:
     ppgpu_ctx* m_Handle = nullptr;

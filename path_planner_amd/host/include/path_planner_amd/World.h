@@ -196,6 +196,14 @@ public:
     void setSlowSpeed(double s) { m_SlowSpeed = s; }
     // How many open vertices one device round trip expands (this planner only; 1 = one vertex at a time, exactly the
     // reference's call pattern).  Results do not depend on it, only when the arithmetic happens.
+    // "Guaranteed to return before timeRemaining has elapsed" (Planner.h:42): the reference only polls now() between expansions
+    // (AStarPlanner.cpp:61,136), which is enough when an expansion takes microseconds.  Here one device round trip costs 0.3-3 ms
+    // and a doubling of the sample set more, so with the guard on (the default) the planner does not START a round trip or a sample
+    // doubling that its own measurements of the previous ones say cannot end before the deadline.  It uses the value of the poll
+    // the reference makes anyway — no extra now() call — and assumes the clock advances while the device works.  A clock that
+    // does not (the counting clock of the oracle comparisons: t0 + calls * dt) must switch it off.
+    bool deadlineGuard() const { return m_DeadlineGuard; }
+    void setDeadlineGuard(bool on) { m_DeadlineGuard = on; }
     int speculation() const { return m_Speculation; }
     void setSpeculation(int n) { m_Speculation = n < 1 ? 1 : n; }
     // PlannerConfig.h:60-80,116-118: the search dump.  The device keeps no per-step poses, so the planner rebuilds the
@@ -214,6 +222,7 @@ private:
     double m_CollisionCheckingIncrement = 0.05;
     int m_InitialSamples = 100;
     bool m_UseBrownPaths = false;
+    bool m_DeadlineGuard = true;
     bool m_Visualizations = false;
     Visualizer::SharedPtr m_Visualizer;
     std::ostream* m_VisualizationStream = nullptr;

@@ -80,8 +80,12 @@ GpuContext::GpuContext(int device) : m_Device(device) {
     // every later cycle's budget.  PPAMD_RESERVE_SAMPLES=0 leaves them to grow on demand.
     long long reserve = 8ll << 20;
     if (const char* e = std::getenv("PPAMD_RESERVE_SAMPLES")) reserve = std::atoll(e);
-    if (reserve > 0 && ppgpu_reserve_samples(m_Handle, reserve, 16) != PPGPU_OK)
-        throw std::runtime_error(std::string("ppgpu_reserve_samples: ") + ppgpu_last_error());
+    if (reserve > 0 && ppgpu_reserve_samples(m_Handle, reserve, 16) != PPGPU_OK) {
+        const std::string why = ppgpu_last_error();
+        ppgpu_destroy(m_Handle);      // the destructor does not run for a constructor that throws
+        m_Handle = nullptr;
+        throw std::runtime_error("ppgpu_reserve_samples: " + why);
+    }
     m_Thread = std::thread(&GpuContext::serve, this);
 }
 
@@ -331,15 +335,22 @@ void GpuAStarPlanner::addSamples(long n) {   // SamplingBasedPlanner::addSamples
             left -= chunk;
         }
     };
+    const double w0 = HostProfile::now();
     if (m_Ctxs.size() == 1) {
         draw(*m_Ctx, total);
     } else {
         std::vector<int64_t> kept(m_Ctxs.size(), 0);
         for (size_t d = 0; d < m_Ctxs.size(); d++) m_Ctxs[d]->run([&, d] { draw(*m_Ctxs[d], kept[d]); });
-        for (auto& ctx : m_Ctxs) ctx->wait();
+        // every job refers to `kept` and `draw`: wait for ALL of them before anything is thrown
+        std::exception_ptr first;
+        for (auto& ctx : m_Ctxs) {
+            try { ctx->wait(); } catch (...) { if (!first) first = std::current_exception(); }
+        }
+        if (first) std::rethrow_exception(first);
         total = kept[0];
         for (int64_t t : kept) if (t != total) throw std::runtime_error("the devices disagree on the sample set");
     }
+    if (n > 0) m_Ctx->doubling = {(double)n, HostProfile::now() - w0};
     if (n > 0) m_NumSamples = (long)total;
     m_Speculated.clear();   // children costed ahead were chosen among the old samples
 }
@@ -351,8 +362,10 @@ GpuAStarPlanner::Node GpuAStarPlanner::makeChild(int source, unsigned cfgBits, c
     const int nChild = (int)((r.info >> 8) & 0xff);
     // PPGPU_F_RIBBON_OVF on a list that came back whole means only that the device's TSP enumeration stops at 8 (12) ribbons: the
     // reference enumerates any length (RibbonManager.cpp:53-140), so h is computed here, with the same arithmetic as the root's
-    const bool hostHeuristic = (r.flags & PPGPU_F_RIBBON_OVF) && nChild <= stride;
-    if ((r.flags & PPGPU_F_DUBINS_ERR) || ((r.flags & PPGPU_F_RIBBON_OVF) && !hostHeuristic))
+    // (PPGPU_F_RIBBON_LOST: the sweep itself ran out of its 64 ribbons per vertex and dropped pieces — that record is not the
+    // reference's and is refused, whatever the count says)
+    const bool hostHeuristic = (r.flags & PPGPU_F_RIBBON_OVF) && !(r.flags & PPGPU_F_RIBBON_LOST) && nChild <= stride;
+    if ((r.flags & (PPGPU_F_DUBINS_ERR | PPGPU_F_RIBBON_LOST)) || ((r.flags & PPGPU_F_RIBBON_OVF) && !hostHeuristic))
         throw std::runtime_error("Edge cost evaluation exceeded a device capacity (flags " + std::to_string(r.flags) + ", child ribbons " +
                                  std::to_string(nChild) + ", parent ribbons " + std::to_string(m_Nodes[source].ribbons.count()) + ")");
     const Node& src = m_Nodes[source];
@@ -510,6 +523,10 @@ void GpuAStarPlanner::expandOn(GpuContext& ctx, const std::vector<int>& sources,
 // gets vertices of every priority and the one the search is waiting for sits first on device 0), one host thread per device.
 void GpuAStarPlanner::expandBatch(const std::vector<int>& sources) {
     g_prof.trips++;
+    struct TripTimer {
+        GpuContext& c; double samples, w0;
+        ~TripTimer() { c.noteTrip(samples, HostProfile::now() - w0); }
+    } tripTimer{*m_Ctx, (double)m_NumSamples, HostProfile::now()};
     const size_t D = std::min(m_Ctxs.size(), sources.size());
     std::vector<std::vector<std::pair<int, Costed>>> parts(std::max<size_t>(D, 1));
     std::vector<unsigned long> costed(parts.size(), 0);
@@ -571,7 +588,7 @@ void GpuAStarPlanner::expand(int source) {
             g_dump.write(m_Nodes[source].state, r, cov ? m_Config.coverageTurningRadius() : m_Config.turningRadius(), cov);
         }
         const bool truncated = (r.flags & PPGPU_F_RIBBON_OVF) && (int)((r.info >> 8) & 0xff) > costed.stride;
-        const bool plainInfeasible = (r.flags & PPGPU_F_INFEASIBLE) && !(r.flags & (PPGPU_F_THROWS | PPGPU_F_DUBINS_ERR)) && !truncated;
+        const bool plainInfeasible = (r.flags & PPGPU_F_INFEASIBLE) && !(r.flags & (PPGPU_F_THROWS | PPGPU_F_DUBINS_ERR | PPGPU_F_RIBBON_LOST)) && !truncated;
         if (plainInfeasible && !watch) continue;
         m_Nodes.push_back(makeChild(source, costed.cfgBits[e], r, costed.childRibbons.data() + e * (size_t)costed.stride * 4, costed.stride));
         visualizeTrajectory(m_Nodes.back());   // in the reference each edge streams its sweep, then its vertex is pushed
@@ -582,10 +599,18 @@ void GpuAStarPlanner::expand(int source) {
 
 int GpuAStarPlanner::aStar(double endTime) {   // AStarPlanner.cpp:134-148
     int vertex = popVertexQueue();
-    while (now() < endTime) {
+    const bool guard = m_Config.deadlineGuard();
+    double t;
+    while ((t = now()) < endTime) {
         if (goalCondition(m_Nodes[vertex])) {
             visualizeVertex(vertex, "vertex", false);
             return vertex;
+        }
+        // Planner.h:42 "guaranteed to return before timeRemaining has elapsed": an expansion whose children are not costed yet is a
+        // device round trip; one that, going by the last ones, would end after the deadline is not started
+        if (guard && !m_Speculated.count(vertex) && t + m_Ctx->predictTrip((double)m_NumSamples) >= endTime) {
+            m_Stats.DeadlineStops++;
+            return -1;
         }
         expand(vertex);
         if (m_Queue.empty()) return -1;
@@ -704,8 +729,8 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
                 g_dump.write(m_Nodes[lastPlanEnd].state, r, dp.rho, cov);
                 if (r.flags & PPGPU_F_THROWS) throw std::runtime_error("Invalid time in sample for Dubins path (previous plan)");
                 const int nChild = (int)((r.info >> 8) & 0xff);
-                const bool hostHeuristic = (r.flags & PPGPU_F_RIBBON_OVF) && nChild <= kRibbonStride;
-                if ((r.flags & PPGPU_F_DUBINS_ERR) || ((r.flags & PPGPU_F_RIBBON_OVF) && !hostHeuristic))
+                const bool hostHeuristic = (r.flags & PPGPU_F_RIBBON_OVF) && !(r.flags & PPGPU_F_RIBBON_LOST) && nChild <= kRibbonStride;
+                if ((r.flags & (PPGPU_F_DUBINS_ERR | PPGPU_F_RIBBON_LOST)) || ((r.flags & PPGPU_F_RIBBON_OVF) && !hostHeuristic))
                     throw std::runtime_error("Edge cost evaluation exceeded a device capacity");
                 Node c;
                 c.parent = lastPlanEnd;
@@ -737,7 +762,8 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
     }
 
     // big loop (:61-119)
-    while (now() < endTime) {
+    double tPoll;
+    while ((tPoll = now()) < endTime) {
         m_Queue.clear();
         if (m_Best >= 0 && m_Nodes[m_Best].f() <= m_Nodes[startV].f()) {
             *m_Config.output() << "Found best possible plan, assuming heuristic admissibility" << std::endl;
@@ -772,8 +798,14 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
             costStateEdges(startV, t, c, si);
         }
         // first iteration: initialSamples; afterwards double them (:101-102)
-        if (m_NumSamples < m_Config.initialSamples()) addSamples(m_Config.initialSamples());
-        else addSamples(m_NumSamples);
+        const long moreSamples = m_NumSamples < m_Config.initialSamples() ? m_Config.initialSamples() : m_NumSamples;
+        // the deadline guard: a doubling that, with the one round trip that makes it worth anything, cannot end in time is not started
+        if (m_Config.deadlineGuard() && m_Stats.Iterations > 0 &&
+            tPoll + m_Ctx->predictDoubling((double)moreSamples) + m_Ctx->predictTrip((double)(m_NumSamples + moreSamples)) >= endTime) {
+            m_Stats.DeadlineStops++;
+            break;
+        }
+        addSamples(moreSamples);
         visualizeSamples();
         int v = aStar(endTime);
         if (m_Best < 0 || (v >= 0 && m_Nodes[v].f() + 0.0 < m_Nodes[m_Best].f())) {

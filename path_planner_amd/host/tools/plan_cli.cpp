@@ -115,14 +115,14 @@ int main(int argc, char** argv) {
             // along the returned plan, hand the plan back as previousPlan, repeat.  Real clock, fixed budget per cycle.
             double tNow = t0;
             State cur = start;
-            unsigned long iters = 0, expanded = 0, failures = 0, samples = 0;
+            unsigned long iters = 0, expanded = 0, failures = 0, samples = 0, deadlineStops = 0;
             for (int cyc = 0; cyc < replans; cyc++) {
                 const auto w0 = std::chrono::steady_clock::now();
                 config.setNowFunction([&]() { return tNow + std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count(); });
                 GpuAStarPlanner planner(contexts);
                 st = planner.plan(rm, cur, config, prev, timeRemaining);
                 wall.push_back(1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count());
-                iters += st.Iterations; expanded += st.Expanded; samples += st.Samples;
+                iters += st.Iterations; expanded += st.Expanded; samples += st.Samples; deadlineStops += st.DeadlineStops;
                 if (cyc > 0 && wall.back() > 1.25e3 * timeRemaining)      // an overrun: what was the cycle doing?
                     std::fprintf(stderr, "[replan] cycle %d: %.1f ms, %lu iterations, %lu samples, %lu expanded\n", cyc, wall.back(),
                                  (unsigned long)st.Iterations, (unsigned long)st.Samples, (unsigned long)st.Expanded);
@@ -141,9 +141,9 @@ int main(int argc, char** argv) {
             std::sort(wall.begin(), wall.end());
             const double p50 = wall[wall.size() / 2], p99 = wall[std::min(wall.size() - 1, (size_t)(0.99 * wall.size()))];
             std::printf("{\"replans\": %d, \"budget_ms\": %.3f, \"first_cycle_ms\": %.3f, \"wall_ms_p50\": %.3f, \"wall_ms_p99\": %.3f, \"wall_ms_max\": %.3f, "
-                        "\"mean_iterations\": %.2f, \"mean_expanded\": %.1f, \"mean_samples\": %.1f, \"failed_plans\": %lu, \"devices\": %zu}\n",
+                        "\"mean_iterations\": %.2f, \"mean_expanded\": %.1f, \"mean_samples\": %.1f, \"failed_plans\": %lu, \"deadline_stops\": %lu, \"devices\": %zu}\n",
                         replans, 1e3 * timeRemaining, firstCycle, p50, p99, wall.back(), (double)iters / replans, (double)expanded / replans,
-                        (double)samples / replans, failures, contexts.size());
+                        (double)samples / replans, failures, deadlineStops, contexts.size());
             return 0;
         }
         for (int rep = 0; rep < repeat; rep++) {
@@ -153,6 +153,7 @@ int main(int argc, char** argv) {
                 config.setNowFunction([&]() { return t0 + std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count(); });
             else
                 config.setNowFunction([&]() { return t0 + (double)(calls++) * dt; });
+            config.setDeadlineGuard(realClock);   // a counting clock does not advance while the device works
             GpuAStarPlanner planner(contexts);   // a fresh planner every cycle, like Executive::planLoop (executive.cpp:85-90)
             st = planner.plan(rm, start, config, prev, timeRemaining);
             wall.push_back(1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count());

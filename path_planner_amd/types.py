@@ -28,6 +28,7 @@ H_MAX_DISTANCE, H_TSP_POINT_ALL, H_TSP_POINT_K, H_TSP_DUBINS_ALL, H_TSP_DUBINS_K
 OBST_NONE, OBST_BINARY = 0, 1
 EDGE_COVERAGE, EDGE_SLOW = 1, 2
 F_INFEASIBLE, F_THROWS, F_RIBBON_OVF, F_DUBINS_ERR, F_GOAL, F_DONE = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
+F_RIBBON_LOST = 0x40   # the sweep ran out of its 64 ribbons per vertex and dropped pieces (always with F_RIBBON_OVF)
 
 
 def make_config(**kw):

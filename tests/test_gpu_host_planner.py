@@ -441,7 +441,7 @@ def test_ten_hertz_replan_loop_with_32_moving_obstacles(monkeypatch):
     from path_planner_amd import workloads
     monkeypatch.delenv("PPGPU_PREPASS_MIN_EDGES", raising=False)      # the production setting
     w = workloads.config3()
-    w.obst = workloads.obstacles(32, 3, 204.8, time=float(w.start5[4]), keep_free=(float(w.start5[0]), float(w.start5[1]), 25))
+    w.obst = workloads.obstacles(32, 3, 204.8, time=float(w.start5[4]))      # uniform in the map, as SURVEY 8(d) config 5 says: no free disc
     with tempfile.TemporaryDirectory() as d:
         mp = os.path.join(d, "grid.map")
         _write_map(w.grid, w.res, mp)
@@ -451,6 +451,8 @@ def test_ten_hertz_replan_loop_with_32_moving_obstacles(monkeypatch):
             f.write("time_remaining 0.1\nreplan 40 0.1\n")
         r = _run_cli(sc)
     print(r)
-    assert r["failed_plans"] == 0 and r["replans"] == 40
+    assert r["replans"] == 40 and r["failed_plans"] <= 2, r          # a start that an obstacle is sitting on has no collision-free plan
     assert r["mean_iterations"] >= 2 and r["mean_expanded"] >= 100
-    assert r["wall_ms_p50"] <= 125.0 and r["wall_ms_p99"] <= 160.0, r      # 100 ms budget + the batch in flight at the deadline
+    # "Guaranteed to return before timeRemaining has elapsed" (Planner.h:42): the deadline guard does not start a round trip or a
+    # sample doubling that cannot end in time, so what is left above the budget is one mispredicted round trip and OS jitter
+    assert r["wall_ms_p50"] <= 100.5 and r["wall_ms_p99"] <= 105.0, r

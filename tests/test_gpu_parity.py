@@ -853,3 +853,68 @@ def test_nearest_selection_corner_cases(torch_cuda, case):
         want = np.full(k, -1); want[:len(order)] = order
         assert idx[0, r].tolist() == want.tolist(), (case, r)
         assert np.array_equal(ln[0, r][:len(order)], col[order]) and np.all(ln[0, r][len(order):] == -1.0)
+
+
+def test_a_list_that_outgrows_64_ribbons_is_flagged_lost_not_just_overflowed(torch_cuda):
+    """PPGPU_F_RIBBON_OVF alone means "heuristic not enumerated, list whole"; a sweep that runs out of the device's 64
+    ribbons per vertex drops pieces and must say so with PPGPU_F_RIBBON_LOST.  60 parallel ribbons 1 m apart (closer than their
+    width, so that every step is a coverage event once the first one has come), a straight edge across their middles: each
+    crossing splits one ribbon in two (Ribbon.cpp:9-17)."""
+    import oracle as orc
+    from path_planner_amd import api
+    from path_planner_amd.types import make_config, edge_pack, H_MAX_DISTANCE, F_RIBBON_OVF, F_RIBBON_LOST, F_INFEASIBLE
+    from path_planner_amd.workloads import root_vertex
+    from parity import compare_results
+    cfg = make_config(start_state_time=1.0, heuristic=H_MAX_DISTANCE, ribbon_width=0.6)
+    orc.O.ppo_set_ribbon_width(cfg.ribbon_width)
+    try:
+        rib = np.array([[0.0, float(y), 20.0, float(y)] for y in range(60)])
+        root = root_vertex(10.0, -2.0, 0.0, 2.5, 1.0, rib)               # heading 0 = along +y
+        # the first event comes 10 m in (toCoverDistance = distance to the nearest endpoint, Edge.cpp:153-157): 4 crossings / 22
+        sx, sy, sh = np.array([10.0, 10.0]), np.array([11.5, 30.0]), np.array([0.0, 0.0])
+        ctx = api.Context(0)
+        ctx.set_config(cfg); ctx.set_grid(None, 0.0); ctx.set_obstacles(None)
+        ctx.set_vertices(root, rib); ctx.set_samples(sx, sy, sh)
+        e = edge_pack(np.zeros(2, dtype=np.uint64), np.arange(2), np.zeros(2, dtype=np.int64))
+        gpu, gchild = ctx.cost_edges_host(e, stride=64)
+        world = orc.World(cfg, None, 0.0, None)
+        cpu, cchild = world.cost_edges(root, rib, sx, sy, sh, e, stride=100)
+        cchild = cchild[:, :64]
+        n0, n1 = [int((x >> 8) & 0xFF) for x in cpu["info"]]
+        assert n0 == 64 and n1 > 64, (n0, n1)
+        # the list that still fits: whole, no flag, same pieces as the oracle's
+        assert gpu["flags"][0] & (F_RIBBON_OVF | F_RIBBON_LOST) == 0
+        rep = compare_results(gpu[:1], cpu[:1], gchild[:1], cchild[:1])
+        assert rep["ok"], rep
+        # the one that does not: both bits, never OVF alone
+        assert gpu["flags"][1] & F_RIBBON_LOST and gpu["flags"][1] & F_RIBBON_OVF, hex(int(gpu["flags"][1]))
+        assert not (gpu["flags"][1] & F_INFEASIBLE)
+    finally:
+        orc.O.ppo_set_ribbon_width(1.5)
+
+
+def test_expand_order_with_more_candidates_than_the_list_holds(torch_cuda):
+    """with more than 65 536 candidates inside the bound (here: 70 000 samples on one circle around the vertex, so every
+    distance is below every length) the candidate list is truncated in atomic-arrival order; the fallback must then select the k
+    cheapest from the vertex's whole row of lengths, not from whatever the truncated list happened to keep."""
+    from path_planner_amd import api, workloads
+    w = workloads.config1()
+    ctx = api.Context(0)
+    ctx.set_config(w.cfg); ctx.set_grid(None, 0.0); ctx.set_obstacles(None)
+    ctx.set_vertices(w.root(), w.ribbons4)
+    rng = np.random.default_rng(12)
+    n = 70000
+    a = rng.uniform(0, 2 * np.pi, n)
+    x0, y0 = float(w.start5[0]), float(w.start5[1])
+    ctx.set_samples(x0 + 100.0 * np.cos(a), y0 + 100.0 * np.sin(a), rng.uniform(0, 2 * np.pi, n))
+    d_len = torch_cuda.zeros(n * 2, dtype=torch_cuda.float64, device="cuda:0")
+    torch_cuda.cuda.synchronize()
+    ctx.dubins_lengths(0, 1, d_len.data_ptr()); ctx.synchronize()
+    ln = d_len.cpu().numpy().reshape(n, 2)
+    k = 9
+    for attempt in range(3):                                   # the truncation is nondeterministic: the answer must not be
+        idx, fb = ctx.expand_order(1, k)
+        assert fb == 2                                         # both radii fall back (and say so)
+        for r in range(2):
+            want = np.lexsort((np.arange(n), ln[:, r]))[:k]
+            assert idx[0, r].tolist() == want.tolist(), (attempt, r)

@@ -14,7 +14,7 @@ budget = float(sys.argv[2]) if len(sys.argv) > 2 else 100.0
 init = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 spec = int(sys.argv[4]) if len(sys.argv) > 4 else None
 w = workloads.config3()
-w.obst = workloads.obstacles(32, 3, 204.8, time=float(w.start5[4]), keep_free=(float(w.start5[0]), float(w.start5[1]), 25))
+w.obst = workloads.obstacles(32, 3, 204.8, time=float(w.start5[4]))      # uniform in the map: no free disc around the start
 with tempfile.TemporaryDirectory() as d:
     mp = os.path.join(d, "grid.map"); _write_map(w.grid, w.res, mp)
     sc = os.path.join(d, "s.txt")
