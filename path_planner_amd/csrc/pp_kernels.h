@@ -54,7 +54,7 @@ struct PPParams {
 // one-WAVE-per-edge sweep.  384 bytes, device-only.
 #define PP_SETUP_MALFORMED 1u   // descriptor out of range
 #define PP_SETUP_COLOCATED 2u   // State::isCoLocated(start, end): the reference throws
-struct __attribute__((aligned(128))) PPEdgeSetup {
+struct PPEdgeSetupBody {
     PPSeg seg[3];                          // what the sweep keeps one of in registers at a time
     double qx, qy, rho, rho_inv, length;   // DubinsPath::qi (position), rho, path length
     double wStart, wEnd, speed;            // DubinsWrapper start / end time and speed
@@ -64,7 +64,15 @@ struct __attribute__((aligned(128))) PPEdgeSetup {
     int type;                              // DubinsPathType, -1 = no path
     unsigned vi, cbits, sflags;
 };
-static_assert(sizeof(PPEdgeSetup) == 384, "PPEdgeSetup is sized for three 128-byte lines");
+struct __attribute__((aligned(128))) PPEdgeSetup : PPEdgeSetupBody {};
+static_assert(sizeof(PPEdgeSetup) == 384 && sizeof(PPEdgeSetupBody) == 360, "PPEdgeSetup is sized for three 128-byte lines");
+// The lane-per-edge prepasses read a record per LANE.  Straight from memory that is one 64-line gather per field; they stage the
+// records of their workgroup in LDS instead (contiguous, coalesced 8-byte-per-lane loads) and read the fields from there.  The
+// LDS copy holds the 45 doubles that carry data, at a stride of 45: odd in 8-byte units, so lanes reading one field of
+// consecutive records fall on different banks.
+#define PP_SETUP_GLOBAL_WORDS 48
+#define PP_SETUP_WORDS 45
+#define PP_SETUP_LDS_STRIDE 45
 
 // ------------------------------------------------------------------------------------------
 // Clearance map of the occupancy grid (PPGrid::clearance), built whenever a grid is set: chessboard (L-infinity) distance in cells
@@ -583,20 +591,12 @@ __device__ __forceinline__ bool pp_chunk_clear_of(const PPObst& o, double x, dou
 #define PP_SKIP_ALL 1     // track_skip bits: the chunk is not sampled at all
 #define PP_SKIP_GRID 2    // sampled, but no pose of it can lie on a blocked cell
 #define PP_SKIP_OBST 4    // sampled, but no pose of it can lie inside an obstacle
-template <bool GAUSSIAN>
-__device__ __forceinline__ void pp_plan_skips_thread(const PPParams& p) {
-    // one THREAD per (edge, chunk): measured against one lane per edge walking its chunks (0.29 ms at config 3: 24 dependent
-    // iterations on 3 700 wavefronts) this mapping takes 0.21 ms, most threads of a short edge leaving after two loads
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.n_edges * p.nch) return;
-    long long el;
-    int chunk;
-    if (i < (1ll << 32)) { el = (long long)((unsigned)i / (unsigned)p.nch); chunk = (int)((unsigned)i - (unsigned)el * (unsigned)p.nch); }
-    else { el = i / p.nch; chunk = (int)(i - el * p.nch); }
-    const long long e = p.ws_base + el;
+#define PP_PLAN_EDGES_MAX 32          // edges a workgroup of the skip planner stages at most (12.3 KB of LDS)
+template <bool GAUSSIAN, bool OBST_LDS>
+__device__ __forceinline__ void pp_plan_skips_chunk(const PPParams& p, const PPEdgeSetupBody* S, const PPObst* OB, const long long e, const int chunk) {
+    {
     const int k0 = chunk * PP_WAVE;
     unsigned char* skipb = p.track_skip + (size_t)e * p.nch + chunk;
-    const PPEdgeSetup* S = p.setup + e;
     const bool sane = !(S->sflags & (PP_SETUP_MALFORMED | PP_SETUP_COLOCATED)) && S->type >= 0;
     const bool whole = k0 + PP_WAVE - 1 < p.ng;                // only whole chunks can be skipped ...
     const double endTime = fmin(p.horizon + 1e-12 + p.sst, S->wEnd);
@@ -700,10 +700,10 @@ __device__ __forceinline__ void pp_plan_skips_thread(const PPParams& p) {
         while (decided && m) {
             const int j = __ffsll((long long)m) - 1;
             m &= m - 1;
-            against(p.obst[j]);
+            against(OB[j]);
         }
         if (p.n_obst > PP_WAVE)
-            for (int j = 0; j < p.n_obst && decided; j++) against(p.obst[j]);
+            for (int j = 0; j < p.n_obst && decided; j++) against(OB[j]);
         obstClear = decided && nInside == 0;
 #else
         const double tpM = (rho_inv != 0.0) ? dM * rho_inv : dM / rho;
@@ -726,10 +726,10 @@ __device__ __forceinline__ void pp_plan_skips_thread(const PPParams& p) {
         while (obstClear && m) {
             const int j = __ffsll((long long)m) - 1;
             m &= m - 1;
-            obstClear = pp_chunk_clear_of<GAUSSIAN>(p.obst[j], x, y, tM, hs, ht);
+            obstClear = pp_chunk_clear_of<GAUSSIAN>(OB[j], x, y, tM, hs, ht);
         }
         if (obstClear && p.n_obst > PP_WAVE)
-            for (int j = 0; j < p.n_obst && obstClear; j++) obstClear = pp_chunk_clear_of<GAUSSIAN>(p.obst[j], x, y, tM, hs, ht);
+            for (int j = 0; j < p.n_obst && obstClear; j++) obstClear = pp_chunk_clear_of<GAUSSIAN>(OB[j], x, y, tM, hs, ht);
         decided = obstClear;
 #endif
     }
@@ -753,12 +753,50 @@ __device__ __forceinline__ void pp_plan_skips_thread(const PPParams& p) {
         pp_curve_seg(g->type, (tpP - g->o1) - g->o2, g->bx, g->by, g->bth, g->sb, g->cb, ux, uy, uth);
         p.track_carry[(size_t)e * p.nch + chunk] = pp_heading_from_yaw(pp_mod2pi(uth));
     }
+    }
+}
+// One workgroup per `epw` consecutive edges (host: as many as give it 256 (edge, chunk) pairs, at most PP_PLAN_EDGES_MAX), one
+// THREAD per (edge, chunk) — measured against one lane per edge walking its chunks (0.29 ms at config 3: 24 dependent iterations
+// on 3 700 wavefronts) this mapping took 0.21 ms, most threads of a short edge leaving after two loads.  Round 3: the workgroup
+// first copies its edges' setup records (contiguous in the workspace) and the obstacle table into LDS.  A thread reads some 40
+// fields of its record and ten doubles per obstacle it tests; from memory every one of those was a vector load whose lanes hit
+// two or three different lines, ≈ 200 per thread, and the kernel ran at the rate the L1 serves such loads, not at the VALU's.
+template <bool GAUSSIAN, bool OBST_LDS>
+__device__ __forceinline__ void pp_plan_skips_thread(const PPParams& p, int epw) {
+    __shared__ double s_setup[PP_PLAN_EDGES_MAX * PP_SETUP_LDS_STRIDE];
+    __shared__ PPObst s_obst[OBST_LDS ? PP_WAVE : 1];
+    const int tid = (int)threadIdx.x;
+    const long long el0 = (long long)blockIdx.x * epw;
+    const int ne = (int)((p.n_edges - el0 < (long long)epw) ? (p.n_edges - el0) : (long long)epw);
+    {
+        const double* src = reinterpret_cast<const double*>(p.setup + p.ws_base + el0);
+        for (int i = tid; i < ne * PP_SETUP_GLOBAL_WORDS; i += 256) {
+            const int ed = i / PP_SETUP_GLOBAL_WORDS, w = i - ed * PP_SETUP_GLOBAL_WORDS;
+            if (w < PP_SETUP_WORDS) s_setup[ed * PP_SETUP_LDS_STRIDE + w] = src[i];
+        }
+        if (OBST_LDS) {
+            const double* os = reinterpret_cast<const double*>(p.obst);
+            double* od = reinterpret_cast<double*>(s_obst);
+            for (int i = tid; i < p.n_obst * (int)(sizeof(PPObst) / sizeof(double)); i += 256) od[i] = os[i];
+        }
+    }
+    __syncthreads();
+    // (blockIdx.y: further tiles of 256 chunks when one edge alone has more than 256 of them)
+    const int t = (int)blockIdx.y * 256 + tid;
+    if (t >= ne * p.nch) return;
+    const int el = (int)((unsigned)t / (unsigned)p.nch);
+    const int chunk = t - el * p.nch;
+    const PPEdgeSetupBody* S = reinterpret_cast<const PPEdgeSetupBody*>(&s_setup[el * PP_SETUP_LDS_STRIDE]);
+    pp_plan_skips_chunk<GAUSSIAN, OBST_LDS>(p, S, OBST_LDS ? s_obst : p.obst, p.ws_base + el0 + el, chunk);
 }
 #ifndef PP_PLAN_MIN_WAVES
 #define PP_PLAN_MIN_WAVES 8   // 62 VGPRs, no spills; 0.28 -> 0.27 ms against the compiler's own choice (6 waves)
 #endif
-__global__ __launch_bounds__(256, PP_PLAN_MIN_WAVES) void pp_k_plan_skips(PPParams p) { pp_plan_skips_thread<false>(p); }
-__global__ __launch_bounds__(256) void pp_k_plan_skips_gaussian(PPParams p) { pp_plan_skips_thread<true>(p); }
+// the obstacle table in LDS (up to 64 obstacles) / read from memory (more)
+__global__ __launch_bounds__(256, PP_PLAN_MIN_WAVES) void pp_k_plan_skips(PPParams p, int epw) { pp_plan_skips_thread<false, true>(p, epw); }
+__global__ __launch_bounds__(256) void pp_k_plan_skips_many(PPParams p, int epw) { pp_plan_skips_thread<false, false>(p, epw); }
+__global__ __launch_bounds__(256) void pp_k_plan_skips_gaussian(PPParams p, int epw) { pp_plan_skips_thread<true, true>(p, epw); }
+__global__ __launch_bounds__(256) void pp_k_plan_skips_gaussian_many(PPParams p, int epw) { pp_plan_skips_thread<true, false>(p, epw); }
 
 // e = the edge's slot in the workspace.  GAUSSIAN: the dynamic obstacles are GaussianDynamicObstaclesManager's (its own
 // instantiation: exp() and the density bookkeeping would otherwise cost the common kernel registers).
@@ -992,7 +1030,7 @@ __device__ __forceinline__ int pp_event_stride(double D, double inc_d, double in
 // case "no event changed anything") and marks the edge PP_FAR_DONE; the cover sweep's wave then drops it at once.  Nearly half
 // the edges of config 3.
 #define PP_FAR_DONE (-2)
-__device__ __forceinline__ void pp_lane_pose(const PPEdgeSetup* S, double t, double wStart, double speed, double length, double rho, double rho_inv,
+__device__ __forceinline__ void pp_lane_pose(const PPEdgeSetupBody* S, double t, double wStart, double speed, double length, double rho, double rho_inv,
                                              double qx, double qy, double hi0, double hi1, double& x, double& y, double& uth, bool& err) {
     double dist = (t - wStart) * speed;                                     // DubinsWrapper.cpp:36
     if (dist < 0 || dist > length) dist = dist - 1e-5;                      // EDUBPARAM retry, :39-42
@@ -1005,7 +1043,7 @@ __device__ __forceinline__ void pp_lane_pose(const PPEdgeSetup* S, double t, dou
     y = uy * rho + qy;
 }
 // -> true: the edge's record and child ribbons are written.  false: nothing was written, the wave does the edge.
-__device__ __forceinline__ bool pp_finish_quiet_edge(const PPParams& p, const PPEdgeSetup* S, const ppgpu_vertex* V, long long e, long long eg,
+__device__ __forceinline__ bool pp_finish_quiet_edge(const PPParams& p, const PPEdgeSetupBody* S, const ppgpu_vertex* V, long long e, long long eg,
                                                      int limit, int lastEv, const double* rp, const double* tg) {
     const int nrib = V->ribbon_count;                                       // > 0, no piece short enough to be erased
     const PPTrackSummary* sum = p.track_summary + e;
@@ -1106,10 +1144,43 @@ __device__ __forceinline__ bool pp_finish_quiet_edge(const PPParams& p, const PP
 #ifndef PP_APPROACH_MIN_WAVES
 #define PP_APPROACH_MIN_WAVES 1
 #endif
-__global__ __launch_bounds__(256, PP_APPROACH_MIN_WAVES) void pp_k_approach_events(PPParams p) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+#ifndef PP_APPROACH_LDS
+#define PP_APPROACH_LDS 0            // 1: stage the workgroup's setup records in LDS (measured slower: see below)
+#endif
+#ifndef PP_APPROACH_THREADS
+#define PP_APPROACH_THREADS 256
+#endif
+#ifndef PP_APPROACH_MAX_EVENTS
+#define PP_APPROACH_MAX_EVENTS 0     // > 0: a lane hands its edge to the wave after this many approach events (bounds the kernel's tail)
+#endif
+__global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp_k_approach_events(PPParams p) {
+    const long long e0 = (long long)blockIdx.x * PP_APPROACH_THREADS;
+    const long long e = e0 + threadIdx.x;
     const bool valid = e < p.n_edges;
-    const PPEdgeSetup* S = p.setup + p.ws_base + (valid ? e : 0);
+#if PP_APPROACH_LDS
+    // Every lane reads ITS edge's setup record — 17 scalars up front, then eight fields of a segment per event; from memory each
+    // of those loads touches 64 different lines.  Staging the workgroup's records (contiguous in the workspace) in LDS with
+    // coalesced loads and reading them there was measured in round 3: 84 -> 109 us (128 threads per workgroup; 113 with 64, 134
+    // with 256).  The kernel is bound by its longest per-lane chain of events, each a dependent load -> pose -> distance, and
+    // hides that latency only with all its 14 waves per CU resident; 45 KB of LDS per 128 lanes leaves room for 6.
+    __shared__ double s_setup[PP_APPROACH_THREADS * PP_SETUP_LDS_STRIDE];
+    {
+        const int ne = (int)((p.n_edges - e0 < (long long)PP_APPROACH_THREADS) ? (p.n_edges - e0) : (long long)PP_APPROACH_THREADS);
+        const double2* src = reinterpret_cast<const double2*>(p.setup + p.ws_base + e0);
+        for (int i = (int)threadIdx.x; i < ne * (PP_SETUP_GLOBAL_WORDS / 2); i += PP_APPROACH_THREADS) {
+            const int ed = i / (PP_SETUP_GLOBAL_WORDS / 2), w = 2 * (i - ed * (PP_SETUP_GLOBAL_WORDS / 2));
+            if (w < PP_SETUP_WORDS) {
+                const double2 v = src[i];
+                s_setup[ed * PP_SETUP_LDS_STRIDE + w] = v.x;
+                if (w + 1 < PP_SETUP_WORDS) s_setup[ed * PP_SETUP_LDS_STRIDE + w + 1] = v.y;
+            }
+        }
+    }
+    __syncthreads();
+    const PPEdgeSetupBody* S = reinterpret_cast<const PPEdgeSetupBody*>(&s_setup[(valid ? (int)threadIdx.x : 0) * PP_SETUP_LDS_STRIDE]);
+#else
+    const PPEdgeSetupBody* S = p.setup + p.ws_base + (valid ? e : 0);
+#endif
     int2 out; out.x = 0; out.y = -1;
     const unsigned sflags = S->sflags;
     const int dubType = S->type;
@@ -1128,12 +1199,18 @@ __global__ __launch_bounds__(256, PP_APPROACH_MIN_WAVES) void pp_k_approach_even
             for (int i = 0; i < nrib; i++) tiny |= pp_sq_len(rp[4 * i], rp[4 * i + 1], rp[4 * i + 2], rp[4 * i + 3]) < minLength0 * minLength0 / (2.0 * 2.0);
             int k = 0, lastEv = -1;
             bool handOver = tiny;               // the wave has events to visit (or an error to flag)
+#if PP_APPROACH_MAX_EVENTS > 0
+            int budget = PP_APPROACH_MAX_EVENTS;
+#endif
             // a piece short enough to be erased makes every event a real one (Ribbon::covered is checked wherever the vehicle is)
             while (!tiny) {
                 if (k >= limit) break;
                 const double t = tg[k];
                 if (!(t < endTime0)) break;
                 if ((t - wStart) * speed / rho > tfar) { k = 0x3fffffff; break; }       // the rest of the curve is clear: no event is visited
+#if PP_APPROACH_MAX_EVENTS > 0
+                if (--budget < 0) { handOver = true; break; }                           // a long chain: the wave goes on from event k
+#endif
                 double dist = (t - wStart) * speed;                                     // DubinsWrapper.cpp:36
                 if (dist < 0 || dist > length) dist = dist - 1e-5;                      // EDUBPARAM retry, :39-42
                 if (dist < 0 || dist > length) { handOver = true; break; }              // the wavefront's code flags the error
@@ -1174,7 +1251,7 @@ __global__ __launch_bounds__(256, PP_APPROACH_MIN_WAVES) void pp_k_approach_even
     // the edges the cover sweep's waves still have to visit, packed (one atomic per workgroup; the order of the launch — long
     // edges first — survives up to the order in which workgroups get here)
     if (p.live_list) {
-        __shared__ unsigned s_cnt[4];
+        __shared__ unsigned s_cnt[PP_APPROACH_THREADS / 64];
         __shared__ unsigned s_base;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const bool live = valid && out.x != PP_FAR_DONE;
@@ -1182,7 +1259,8 @@ __global__ __launch_bounds__(256, PP_APPROACH_MIN_WAVES) void pp_k_approach_even
         if (lane == 0) s_cnt[wave] = (unsigned)__popcll(m);
         __syncthreads();
         if (threadIdx.x == 0) {
-            const unsigned tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            unsigned tot = 0;
+            for (int w = 0; w < PP_APPROACH_THREADS / 64; w++) tot += s_cnt[w];
             s_base = tot ? atomicAdd(p.live_count, tot) : 0u;
         }
         __syncthreads();

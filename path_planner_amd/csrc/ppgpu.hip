@@ -840,16 +840,21 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         hipLaunchKernelGGL(pp_k_solve_edges, dim3((unsigned)((p.n_edges + 255) / 256)), dim3(256), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         if (p.track_skip) {                                          // timed with the pose sweep
-            const unsigned blocks = (unsigned)((p.n_edges * p.nch + 255) / 256);
-            if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN) hipLaunchKernelGGL(pp_k_plan_skips_gaussian, dim3(blocks), dim3(256), 0, c->stream, p);
-            else hipLaunchKernelGGL(pp_k_plan_skips, dim3(blocks), dim3(256), 0, c->stream, p);
+            // one workgroup per epw consecutive edges: as many as give it 256 (edge, chunk) threads
+            int epw = 256 / p.nch;
+            if (epw < 1) epw = 1;
+            if (epw > PP_PLAN_EDGES_MAX) epw = PP_PLAN_EDGES_MAX;
+            const unsigned blocks = (unsigned)((p.n_edges + epw - 1) / epw);
+            const bool gauss = p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN, many = p.n_obst > PP_WAVE;
+            void (*planner)(PPParams, int) = gauss ? (many ? pp_k_plan_skips_gaussian_many : pp_k_plan_skips_gaussian) : (many ? pp_k_plan_skips_many : pp_k_plan_skips);
+            hipLaunchKernelGGL(planner, dim3(blocks, (unsigned)((epw * p.nch + 255) / 256)), dim3(256), 0, c->stream, p, epw);
         }
         if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN)
             hipLaunchKernelGGL(pp_k_pose_sweep_gaussian, dim3(resident_grid(c, 0, pp_k_pose_sweep_gaussian, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
         else
             hipLaunchKernelGGL(pp_k_pose_sweep, dim3(resident_grid(c, 1, pp_k_pose_sweep, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-        if (p.track_far) hipLaunchKernelGGL(pp_k_approach_events, dim3((unsigned)((p.n_edges + 255) / 256)), dim3(256), 0, c->stream, p);
+        if (p.track_far) hipLaunchKernelGGL(pp_k_approach_events, dim3((unsigned)((p.n_edges + PP_APPROACH_THREADS - 1) / PP_APPROACH_THREADS)), dim3(PP_APPROACH_THREADS), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[5], c->stream));
         if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN)
             hipLaunchKernelGGL(pp_k_cover_sweep_gaussian, dim3(resident_grid(c, 2, pp_k_cover_sweep_gaussian, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
