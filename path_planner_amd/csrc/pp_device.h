@@ -93,6 +93,7 @@ __device__ __forceinline__ double pp_heading_to(double x, double y, double x1, d
 // argument; error below 1 ulp).  It replaces the general-purpose device sincos, whose huge-argument path and extra
 // selects cost about twice as many instructions; arguments outside the fast range take the library call.
 // Like any libm pair, results can differ from the host libm's in the last bit: see DESIGN.md "Numerics".
+template <bool TAB = false>
 __device__ __forceinline__ void pp_sincos_bounded(double x, double* sn, double* cs);
 __device__ __forceinline__ void pp_sincos(double x, double* sn, double* cs) {
     if (__ballot(!(fabs(x) < 1.0e5)) != 0ull) { sincos(x, sn, cs); return; }
@@ -102,30 +103,46 @@ __device__ __forceinline__ void pp_sincos(double x, double* sn, double* cs) {
 // their arguments are segment base heading +- arc, and pp_k_solve_edges refuses (PPGPU_F_DUBINS_ERR) any curve for which
 // |start yaw| + arcs reaches 9e4 rad.  The library call's huge-argument reduction would otherwise sit in the sweep loop
 // and set its register budget.
+// TAB: the sixteen constants come from memory through scalar loads at the point of use instead of being literals.  As literals
+// the compiler keeps them in registers across the cover sweep's whole per-edge loop — 32 registers the loop does not have: they
+// were spilled to scratch in the kernel's prologue and reloaded at every window — (the pose sweep, which has the registers, keeps
+// the literals).  Same values, same expressions.
+__device__ const double pp_sincos_tab[16] = {
+    6.36619772367581382433e-01, 1.57079632673412561417e+00, 6.07710050630396597660e-11, 2.02226624879595063154e-21,
+    -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04, 2.75573137070700676789e-06,
+    -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+    4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05, -2.75573143513906633035e-07,
+    2.08757232129817482790e-09, -1.13596475577881948265e-11};
+template <bool TAB>
 __device__ __forceinline__ void pp_sincos_bounded(double x, double* sn, double* cs) {
-    const double fn = rint(x * 6.36619772367581382433e-01);          // x * 2/pi, to nearest
+    const double* tabp = pp_sincos_tab;
+    if (TAB) asm volatile("" : "+s"(tabp));                        // keep the loads here, not hoisted out of the caller's loops
+    const __attribute__((address_space(4))) double* K = (const __attribute__((address_space(4))) double*)(unsigned long long)tabp;
+#define PP_SC(i, lit) (TAB ? K[i] : (lit))
+    const double fn = rint(x * PP_SC(0, 6.36619772367581382433e-01));          // x * 2/pi, to nearest
     const int n = (int)fn;
     // pi/2 = pio2_1 + pio2_2 + pio2_2t (+ ...), the leading parts having 33 significant bits each
-    double r = fma(-fn, 1.57079632673412561417e+00, x);             // exact either way: the product has <= 53 bits
+    double r = fma(-fn, PP_SC(1, 1.57079632673412561417e+00), x);             // exact either way: the product has <= 53 bits
     double wlo;
     {
         const double t = r;
-        wlo = fn * 6.07710050630396597660e-11;                         // pio2_2
+        wlo = fn * PP_SC(2, 6.07710050630396597660e-11);                         // pio2_2
         r = t - wlo;
-        wlo = fn * 2.02226624879595063154e-21 - ((t - r) - wlo);       // pio2_2t
+        wlo = fn * PP_SC(3, 2.02226624879595063154e-21) - ((t - r) - wlo);       // pio2_2t
     }
     const double y0 = r - wlo;
     const double y1 = (r - y0) - wlo;
     const double z = y0 * y0;
     // sin(y0 + y1)
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
-                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double S1 = PP_SC(4, -1.66666666666666324348e-01), S2 = PP_SC(5, 8.33333333332248946124e-03), S3 = PP_SC(6, -1.98412698298579493134e-04),
+                 S4 = PP_SC(7, 2.75573137070700676789e-06), S5 = PP_SC(8, -2.50507602534068634195e-08), S6 = PP_SC(9, 1.58969099521155010221e-10);
     const double v = z * y0;
     const double rs = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
     const double sinv = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
     // cos(y0 + y1)
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
-                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double C1 = PP_SC(10, 4.16666666666666019037e-02), C2 = PP_SC(11, -1.38888888888741095749e-03), C3 = PP_SC(12, 2.48015872894767294178e-05),
+                 C4 = PP_SC(13, -2.75573143513906633035e-07), C5 = PP_SC(14, 2.08757232129817482790e-09), C6 = PP_SC(15, -1.13596475577881948265e-11);
+#undef PP_SC
     const double rc = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
     const double ax = fabs(y0);
     double qx = __hiloint2double(__double2hiint(ax) - 0x00200000, 0);  // |y0| / 4, low word cleared
@@ -359,6 +376,7 @@ __device__ inline void pp_curve_init(PPCurve& c, double qx, double qy, double qt
     pp_dub_sincos<CR>(c.b2th, &c.s2, &c.c2);
 }
 // one segment of dubins_path_sample(): advance by tt from base (bx, by, bth) whose sin/cos are (sb, cb)
+template <bool TAB = false>
 __device__ __forceinline__ void pp_curve_seg(int type, double tt, double bx, double by, double bth, double sb, double cb,
                                              double& ux, double& uy, double& uth) {
     if (type == 1) {            // straight: no transcendental
@@ -368,7 +386,7 @@ __device__ __forceinline__ void pp_curve_seg(int type, double tt, double bx, dou
     } else {
         const double arg = (type == 0) ? (bth + tt) : (bth - tt);
         double s, co;
-        pp_sincos_bounded(arg, &s, &co);
+        pp_sincos_bounded<TAB>(arg, &s, &co);
         if (type == 0) { ux = (+s - sb) + bx; uy = (-co + cb) + by; uth = tt + bth; }
         else           { ux = (-s + sb) + bx; uy = (+co - cb) + by; uth = -tt + bth; }
     }
@@ -735,8 +753,26 @@ __device__ __forceinline__ bool pp_any_erasable_piece(const PPRibbon& r, int n, 
     return __ballot((pp_lane() < n) & (pp_sq_len(r.sx, r.sy, r.ex, r.ey) < minLength * minLength / (2.0 * 2.0))) != 0ull;
 }
 
+//
+// Long runs (round 3): ell > 0.  A slow edge crawling along a ribbon (0.5 m/s: one centimetre per collision-check step) stays inside
+// one piece's corridor for hundreds of steps; taken 64 steps at a time every window costs a window of poses and a run check to
+// learn "the same again".  When a run has just filled a whole window the caller therefore tries the next stretch with one SAMPLE
+// every s steps (lane i = step base + i s) and ell = the arc length of s steps; every decision is made at the samples with a margin
+// that covers the steps between them:
+//   * every step between samples i-1 and i lies within ell of sample i, so a bound that holds at the sample with ell to spare —
+//     inside the strict corridor, outside another piece's reach / extent / strict corridor — holds at those steps;
+//   * the vehicle advances along the piece (the chord between consecutive samples makes an angle with the piece of less than 90
+//     degrees minus the turn the curve can make between them; sinDt >= sin(ell / rho)), so projections move monotonically: each
+//     step's projection lies between the previous step's (the moving endpoint) and the far end, which is what containsProjection
+//     asks for; the half that must survive is shortest at the LAST step covered, where it is checked; the half that vanishes is at
+//     most ell long (the caller checks ell is shorter than the minimum length);
+//   * bit i of coverMask says cover() runs at EVERY step sample i vouches for.
+// The run covers samples first .. first + L - 1; the endpoint moves to the projection of the last of them, the same expression the
+// step-by-step run applies at its last step.  A sample that does not clear its margins ends the long run there and ordinary
+// windows take over: flags cannot differ.  With ell = 0 (and sinDt = 0) every expression below is the step-by-step one.
 __device__ inline int pp_corridor_run(const PPRibbon& r, int n, double w, int adv, bool moveEnd, double x, double y, bool stepOk,
-                                      unsigned long long coverMask, int first, double span, double& newX, double& newY) {
+                                      unsigned long long coverMask, int first, double span, double& newX, double& newY,
+                                      double ell = 0.0, double sinDt = 0.0) {
     const int lane = pp_lane();
     if (pp_any_erasable_piece(r, n, w)) return 0;      // every step of a corridor run calls cover(): it would erase that piece first
     const double Sx = pp_readlane(r.sx, adv), Sy = pp_readlane(r.sy, adv), Ex = pp_readlane(r.ex, adv), Ey = pp_readlane(r.ey, adv);
@@ -747,10 +783,17 @@ __device__ inline int pp_corridor_run(const PPRibbon& r, int n, double w, int ad
     const double px = dxr * dot / sqL + Sx;
     const double py = dyr * dot / sqL + Sy;
     const double num = dyr * x - dxr * y + Ex * Sy - Ey * Sx;
-    const bool strictOk = (num * num) < (((w / 2.0) * (w / 2.0)) * sqL) * (1.0 - g);
+    const double lim = w / 2.0 - ell;
+    const bool strictOk = (lim > 0.0) & ((num * num) < ((lim * lim) * sqL) * (1.0 - g));
     // the moving endpoint this step will see: the previous step's projection (the piece's own endpoint for the first)
     double qx = __shfl_up(px, 1, PP_WAVE), qy = __shfl_up(py, 1, PP_WAVE);
     if (lane == first) { qx = moveEnd ? Ex : Sx; qy = moveEnd ? Ey : Sy; }
+    bool mono = true;
+    if (ell > 0.0) {                                              // wave-uniform: long runs only
+        const double cx = x - __shfl_up(x, 1, PP_WAVE), cy = y - __shfl_up(y, 1, PP_WAVE);
+        const double along = (cx * dxr + cy * dyr) * (moveEnd ? -1.0 : 1.0);
+        mono = (lane == first) | ((along > 0.0) & ((along * along) > ((cx * cx + cy * cy) * sqL) * (sinDt * sinDt) * (1.0 + 1e-6)));
+    }
     const double csx = moveEnd ? Sx : qx, csy = moveEnd ? Sy : qy;   // the piece as this step sees it
     const double cex = moveEnd ? qx : Ex, cey = moveEnd ? qy : Ey;
     const double T = PP_RIBBON_TOL - g;
@@ -762,7 +805,7 @@ __device__ inline int pp_corridor_run(const PPRibbon& r, int n, double w, int ad
     // start follows: front [start, proj] vanishes, rest kept; end follows: front kept, rest [proj, end] vanishes
     const bool halves = moveEnd ? ((frontSq > thr * (1.0 + g)) & (restSq < thr * (1.0 - g)))
                                 : ((frontSq < thr * (1.0 - g)) & (restSq > thr * (1.0 + g)));
-    bool ok = stepOk & (lane >= first) & strictOk & !(outx | outy) & halves & (((coverMask >> lane) & 1ull) != 0ull);
+    bool ok = stepOk & (lane >= first) & strictOk & !(outx | outy) & halves & mono & (((coverMask >> lane) & 1ull) != 0ull);
     // no other piece may be touched by any step of the run: either it is out of reach (farther than half its length
     // + w from its midpoint: cheap), or — for the near ones, typically the sibling the first split left behind —
     // the reference's own test must fail with the guard: projection clearly outside the piece, or clearly outside
@@ -774,17 +817,18 @@ __device__ inline int pp_corridor_run(const PPRibbon& r, int n, double w, int ad
         const double sx = pp_readlane(r.sx, q), sy = pp_readlane(r.sy, q), ex = pp_readlane(r.ex, q), ey = pp_readlane(r.ey, q);
         const double mx = 0.5 * (sx + ex), my = 0.5 * (sy + ey);
         const double ql = pp_sq_len(sx, sy, ex, ey);
-        const double reach = 0.5 * sqrt(ql) + w + 1e-3;
+        const double reach = 0.5 * sqrt(ql) + w + 1e-3 + ell;
         const bool far = pp_sq_len(mx, my, x, y) > reach * reach;
         if (__ballot(ok & !far) != 0ull) {
             const double dq = ex - sx, eq = ey - sy;
             const double dt = (x - sx) * dq + (y - sy) * eq;
             const double ppx = dq * dt / ql + sx, ppy = eq * dt / ql + sy;
-            const double T2 = PP_RIBBON_TOL + g;
+            const double T2 = PP_RIBBON_TOL + g + ell;
             const double c1 = ppx - sx, c2 = ppx - ex, d1 = ppy - sy, d2 = ppy - ey;
             const bool cpOut = (((c1 < -T2) & (c2 < -T2)) | ((c1 > T2) & (c2 > T2))) | (((d1 < -T2) & (d2 < -T2)) | ((d1 > T2) & (d2 > T2)));
             const double nq = eq * x - dq * y + ex * sy - ey * sx;
-            const bool strictOut = (nq * nq) > (((w / 2.0) * (w / 2.0)) * ql) * (1.0 + g);
+            const double lo = w / 2.0 + ell;
+            const bool strictOut = (nq * nq) > ((lo * lo) * ql) * (1.0 + g);
             ok = ok & (far | cpOut | strictOut);
         }
     }
@@ -802,8 +846,11 @@ __device__ inline int pp_corridor_run(const PPRibbon& r, int n, double w, int ad
 // so minDistanceFrom is 0 and the next step is an event again) but change nothing — no piece is strictly contained,
 // or cover() is not enabled at that step (Edge.cpp:159).  Same guarded, lanes-as-steps evaluation as the corridor run:
 // a step joins the run only if "inside" is certain and "nothing splits" is certain.  Returns the run length.
+// Long runs (ell > 0, see pp_corridor_run): a sample vouches for the steps between the previous sample and itself when it lies
+// inside a piece with ell to spare and no piece could split anywhere within ell of it — or cover() is off at ALL of those steps
+// (bit i of coverMask: cover() runs at SOME step sample i vouches for).
 __device__ inline int pp_quiet_run(const PPRibbon& r, int n, double w, double x, double y, bool stepOk,
-                                   unsigned long long coverMask, int first, double span) {
+                                   unsigned long long coverMask, int first, double span, double ell = 0.0) {
     const int lane = pp_lane();
     const double g = 1e-9;
     const bool cand = stepOk & (lane >= first);
@@ -815,20 +862,27 @@ __device__ inline int pp_quiet_run(const PPRibbon& r, int n, double w, double x,
         const double sx = pp_readlane(r.sx, q), sy = pp_readlane(r.sy, q), ex = pp_readlane(r.ex, q), ey = pp_readlane(r.ey, q);
         const double mx = 0.5 * (sx + ex), my = 0.5 * (sy + ey);
         const double ql = pp_sq_len(sx, sy, ex, ey);
-        const double reach = 0.5 * sqrt(ql) + w + 1e-3;
+        const double reach = 0.5 * sqrt(ql) + w + 1e-3 + ell;
         const bool far = pp_sq_len(mx, my, x, y) > reach * reach;
         if (__ballot(cand & !far) != 0ull) {
             const double dq = ex - sx, eq = ey - sy;
             const double dt = (x - sx) * dq + (y - sy) * eq;
             const double ppx = dq * dt / ql + sx, ppy = eq * dt / ql + sy;
             const double c1 = ppx - sx, c2 = ppx - ex, d1 = ppy - sy, d2 = ppy - ey;
-            const double Ti = PP_RIBBON_TOL - g, To = PP_RIBBON_TOL + g;
-            const bool cpIn = !((((c1 < -Ti) & (c2 < -Ti)) | ((c1 > Ti) & (c2 > Ti))) | (((d1 < -Ti) & (d2 < -Ti)) | ((d1 > Ti) & (d2 > Ti))));
+            const double Ti = PP_RIBBON_TOL - g, To = PP_RIBBON_TOL + g + ell;
+            bool cpIn = !((((c1 < -Ti) & (c2 < -Ti)) | ((c1 > Ti) & (c2 > Ti))) | (((d1 < -Ti) & (d2 < -Ti)) | ((d1 > Ti) & (d2 > Ti))));
+            if (ell > 0.0) {
+                // inside the piece's extent by ell, measured along the piece (dt / |piece| = distance of the projection from the
+                // start): every pose within ell then projects inside the extent, where the reference's per-coordinate test passes
+                const double marginLen = (ell + 1e-6) * sqrt(ql);
+                cpIn = (dt > marginLen) & ((ql - dt) > marginLen);
+            }
             const bool cpOut = (((c1 < -To) & (c2 < -To)) | ((c1 > To) & (c2 > To))) | (((d1 < -To) & (d2 < -To)) | ((d1 > To) & (d2 > To)));
             const double nq = eq * x - dq * y + ex * sy - ey * sx;
             const double A = nq * nq;
-            inside = inside | (!far & cpIn & (A < ((w * w) * ql) * (1.0 - g)));
-            maySplit = maySplit | (!far & !cpOut & !(A > (((w / 2.0) * (w / 2.0)) * ql) * (1.0 + g)));
+            const double wi = w - ell, wo = w / 2.0 + ell;
+            inside = inside | (!far & cpIn & (wi > 0.0) & (A < ((wi * wi) * ql) * (1.0 - g)));
+            maySplit = maySplit | (!far & !cpOut & !(A > ((wo * wo) * ql) * (1.0 + g)));
         }
     }
     const bool coverOn = ((coverMask >> lane) & 1ull) != 0ull;

@@ -507,6 +507,7 @@ __device__ __forceinline__ PPCurveHot pp_curve_hot(const PPEdgeSetup* S) {
     h.qx = PP_SF64(qx); h.qy = PP_SF64(qy);
     return h;
 }
+template <bool TAB = false>
 __device__ __forceinline__ void pp_window_pose(const PPEdgeSetup* S, const PPCurveHot& c, int& cur, PPSeg& cs, double t, double tFirst, bool valid,
                                                double& x, double& y, double& uth, bool& dubErr) {
     // lanes past the end of the sweep redo lane 0's step (benign arithmetic, uniform control flow); the caller masks them
@@ -529,20 +530,23 @@ __device__ __forceinline__ void pp_window_pose(const PPEdgeSetup* S, const PPCur
         if (__ballot(mine != firstSeg) != 0ull) {
             // the window straddles a junction: every lane takes its own segment's constants from memory
             const PPSeg* g = &S->seg[mine];
-            pp_curve_seg(g->type, (tprime - g->o1) - g->o2, g->bx, g->by, g->bth, g->sb, g->cb, ux, uy, uth);
+            pp_curve_seg<TAB>(g->type, (tprime - g->o1) - g->o2, g->bx, g->by, g->bth, g->sb, g->cb, ux, uy, uth);
         } else {
             uniformSeg = true;
             if (cur != firstSeg) { cur = firstSeg; cs = pp_seg_load_uniform(&S->seg[cur]); }
         }
         if (cur != lastSeg && !uniformSeg) { cur = lastSeg; cs = pp_seg_load_uniform(&S->seg[cur]); }
     }
-    if (uniformSeg) pp_curve_seg(cs.type, (tprime - cs.o1) - cs.o2, cs.bx, cs.by, cs.bth, cs.sb, cs.cb, ux, uy, uth);
+    if (uniformSeg) pp_curve_seg<TAB>(cs.type, (tprime - cs.o1) - cs.o2, cs.bx, cs.by, cs.bth, cs.sb, cs.cb, ux, uy, uth);
     x = ux * c.rho + c.qx;
     y = uy * c.rho + c.qy;
 }
 
 // The cover sweep samples poses only when it loads a window: it re-reads the curve constants there (scalar loads, kept
 // inside the loop by laundering the pointer) rather than carrying 33 scalar registers of them through the event loop.
+#ifndef PP_COVER_SINCOS_TAB
+#define PP_COVER_SINCOS_TAB true    // the cover sweep takes the sine / cosine constants from memory (see pp_sincos_bounded)
+#endif
 #define PP_WINDOW_POSE(S, t, t0, valid, x, y) do {                                                         \
         const PPEdgeSetup* _S = (S);                                                                       \
         asm volatile("" : "+s"(_S));                                                                       \
@@ -550,7 +554,7 @@ __device__ __forceinline__ void pp_window_pose(const PPEdgeSetup* S, const PPCur
         int _cur = -1;                                                                                     \
         PPSeg _cs = PPSeg{0, 0, 0, 0, 0, INFINITY, -INFINITY, 0, 0, 1, 0};   /* matches nothing: the first use loads a segment */ \
         double _u; bool _e = false;                                                                        \
-        pp_window_pose(_S, _hot, _cur, _cs, t, t0, valid, x, y, _u, _e);                                   \
+        pp_window_pose<PP_COVER_SINCOS_TAB>(_S, _hot, _cur, _cs, t, t0, valid, x, y, _u, _e);              \
     } while (0)
 // Which 64-step chunks of an edge's sweep can be skipped?  One THREAD per (edge, chunk), in a kernel of its own ahead of the pose
 // sweep (inside the sweep the test's registers pushed the per-step loop into spills).  A chunk is skipped when it provably changes
@@ -1360,13 +1364,36 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
     const double inc_d = p.inc_d;
     const double runSpan = 64.0 * (p.inc_d / p.max_speed) * speed * (1.0 + 1e-9) + 1e-6;   // how far 64 steps can take the vehicle
 
+    // long runs (pp_corridor_run / pp_quiet_run with ell > 0): one sample every longStride steps — as many steps as make
+    // PP_LONG_REACH of travel (a slow edge of config 3: 5 steps of 1 cm; at full speed a step is 5 cm and nothing changes; measured 0.02 .. 0.4 m: the wider the margins, the more attempts fail) — with margins of that travel
+#ifndef PP_LONG_REACH
+#define PP_LONG_REACH 0.05
+#endif
+#ifndef PP_LONG_MAX_STRIDE
+#define PP_LONG_MAX_STRIDE 16
+#endif
+#define PP_STEP_LEN() ((p.inc_d / p.max_speed) * speed * (1.0 + 1e-9) + 1e-9)      /* arc length of one step, from above */
+#ifndef PP_NO_LONG_RUN
+    int longStride = 1;
+    {
+        const double stepLen = PP_STEP_LEN();
+        const double sd = PP_LONG_REACH / stepLen;
+        longStride = sd >= (double)PP_LONG_MAX_STRIDE ? PP_LONG_MAX_STRIDE : (sd > 1.0 ? (int)sd : 1);
+        // the half that vanishes between two samples must be shorter than the minimum length; the curve must not turn much between them
+        if (!((double)longStride * stepLen + 1e-6 < 0.5 * w) || !(((double)longStride * stepLen + 1e-6) / PP_SF64(rho) < 0.5)) longStride = 1;
+    }
+#else
+    const int longStride = 1;
+#endif
+
     // ---- phase B: coverage events among steps [0, limit)
 #ifdef PP_ABL_NO_EVENTS
     nextEvent = 1 << 30;
 #endif
     if (!throwsRef) {
         bool ended = false;
-        int cont = 0, contPiece = 0;        // 1 / 2: the last window ended inside a corridor / quiet run (of piece contPiece)
+        int cont = 0, contPiece = 0;        // 1 / 2: the last window ended inside a corridor / quiet run (of piece contPiece); + 4: it was
+                                            // one run from end to end (a long run is worth trying)
         bool contMoveEnd = false;
         while (!ended) {
             if (nextEvent >= limit) break;
@@ -1385,9 +1412,11 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
             // a window of 64 steps of the track starting AT the next event, one step per lane (stretches without events are
             // never loaded)
             const int base = nextEvent;
-            PP_TRACE("[wave] window at %d (limit %d, lastEv %d, nrib %d)\n", base, limit, lastEv, nrib);
+            // ... or, after a window that was one run from end to end, 64 SAMPLES longStride steps apart (a long run)
+            const int stride = ((cont & 4) != 0 && longStride > 1 && base + 2 * longStride < limit) ? longStride : 1;
+            PP_TRACE("[wave] window at %d stride %d (limit %d, lastEv %d, nrib %d)\n", base, stride, limit, lastEv, nrib);
             PP_CNT(dbgWindows++);
-            const int k = base + lane;
+            const int k = base + lane * stride;
             const double t = (k < p.ng) ? tg[k] : INFINITY;
             // the poses of the window, recomputed with the pose sweep's own arithmetic (pp_window_pose)
             double2 q;
@@ -1396,14 +1425,31 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                 if (k >= limit) { q.x = 0.0; q.y = 0.0; }
             }
             // Edge.cpp:159: cover only when coverage is allowed on this edge or the heading did not change since the last step
-            unsigned long long coverMask = ~0ull;
+            unsigned long long coverMask = ~0ull, coverAny = ~0ull;
             if (!cov) {
-                const int c0 = base >> 6, sh = base & 63;
-                const unsigned long long lo = pp_const_u64(teq + c0)[0];
-                const unsigned long long hi = (sh != 0 && c0 + 1 < p.nch) ? pp_const_u64(teq + c0 + 1)[0] : 0ull;
-                coverMask = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+                if (stride == 1) {
+                    const int c0 = base >> 6, sh = base & 63;
+                    const unsigned long long lo = pp_const_u64(teq + c0)[0];
+                    const unsigned long long hi = (sh != 0 && c0 + 1 < p.nch) ? pp_const_u64(teq + c0 + 1)[0] : 0ull;
+                    coverMask = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+                    coverAny = coverMask;
+                } else {
+                    // a sample vouches for the steps (previous sample, itself]: cover() enabled at all of them / at any of them
+                    const int lo = (lane == 0) ? base : (k - stride + 1);
+                    const int cnt = (lane == 0) ? 1 : stride;
+                    unsigned long long bits = 0ull;
+                    if (k < limit) {
+                        const int w0 = lo >> 6, sh = lo & 63;
+                        bits = teq[w0] >> sh;
+                        if (sh + cnt > 64 && w0 + 1 < p.nch) bits |= teq[w0 + 1] << (64 - sh);
+                    }
+                    const unsigned long long mask = (1ull << cnt) - 1ull;
+                    bits &= mask;
+                    coverMask = __ballot(bits == mask);
+                    coverAny = __ballot(bits != 0ull);
+                }
             }
-            const int climit = (limit - base) < PP_WAVE ? (limit - base) : PP_WAVE;
+            const int climit = (stride == 1) ? ((limit - base) < PP_WAVE ? (limit - base) : PP_WAVE) : __popcll(__ballot(k < limit));
             bool runFailed = false, quietFailed = false;
             while (true) {
                 const int j = nextEvent - base;
@@ -1411,27 +1457,39 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                 const double tj = pp_readlane(t, j);
                 if (!(tj < endTime)) { ended = true; break; }         // `while (intermediate.time() < endTime)`
 #ifndef PP_NO_CORRIDOR_RUN
-                if (j == 0 && cont != 0) {
+                if (j == 0 && (cont & 3) != 0) {
                     // the previous window ended inside a run: this step is an event of the same kind, very likely the whole
                     // window is.  The run's own guarded checks decide; if its first step does not pass, the step goes
                     // through the one-at-a-time code below like any other.
                     int L = 0;
                     double nsx = 0, nsy = 0;
                     const bool stepOk = (lane < climit) & (t < endTime);
-                    PP_CNT(if (cont == 1) dbgCorr++; else dbgQuiet++);
-                    if (cont == 1) L = pp_corridor_run(rib, nrib, w, contPiece, contMoveEnd, q.x, q.y, stepOk, coverMask, 0, runSpan, nsx, nsy);
+                    const int kind = cont & 3;
+                    PP_CNT(if (kind == 1) dbgCorr++; else dbgQuiet++);
+                    // a long run: margins of the travel between two samples
+                    const double ell = (stride > 1) ? ((double)stride * PP_STEP_LEN() + 1e-6) : 0.0;
+                    const double span = (stride > 1) ? 64.0 * ell : runSpan;
+                    if (kind == 1) L = pp_corridor_run(rib, nrib, w, contPiece, contMoveEnd, q.x, q.y, stepOk, coverMask, 0, span, nsx, nsy, ell, ell / PP_SF64(rho));
 #ifndef PP_NO_QUIET_RUN
-                    else L = pp_quiet_run(rib, nrib, w, q.x, q.y, stepOk, coverMask, 0, runSpan);
+                    else L = pp_quiet_run(rib, nrib, w, q.x, q.y, stepOk, coverAny, 0, span, ell);
 #endif
-                    PP_TRACE("[wave]   continued run (kind %d) from %d: L %d\n", cont, base, L);
+                    PP_TRACE("[wave]   continued run (kind %d, stride %d) from %d: L %d\n", kind, stride, base, L);
                     if (L > 0) {
-                        if (cont == 1 && lane == contPiece) {
+                        if (kind == 1 && lane == contPiece) {
                             if (contMoveEnd) { rib.ex = nsx; rib.ey = nsy; } else { rib.sx = nsx; rib.sy = nsy; }
                         }
-                        PP_CNT(if (cont == 1) dbgCorrLen += L; else dbgQuietLen += L);
-                        lastEv = base + L - 1;
-                        nextEvent = base + L;
-                        if (L < climit) cont = 0;              // the run ended inside the window: something else happens next
+                        PP_CNT(if (kind == 1) dbgCorrLen += (L - 1) * stride + 1; else dbgQuietLen += (L - 1) * stride + 1);
+                        lastEv = base + (L - 1) * stride;
+                        nextEvent = lastEv + 1;
+                    }
+                    if (stride > 1) {
+                        // a window of samples is only ever this one attempt: whatever it absorbed, ordinary windows (or, if every
+                        // sample held, another long run) go on from there
+                        cont = kind | ((L == PP_WAVE) ? 4 : 0);
+                        break;
+                    }
+                    if (L > 0) {
+                        cont = (L < climit) ? 0 : (kind | 4);  // ended inside the window: something else happens next / filled it: a long run next
                         continue;
                     }
                     cont = 0;
@@ -1462,7 +1520,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                         }
                         lastEv = base + j + L;
                         nextEvent = base + j + L + 1;      // inside the corridor minDistanceFrom is 0: the next step is an event too
-                        if (j + L + 1 >= climit) { cont = 1; contPiece = piece; contMoveEnd = moveEnd; }   // cut by the window, not by a guard
+                        if (j + L + 1 >= climit) { cont = 1 | 4; contPiece = piece; contMoveEnd = moveEnd; }   // cut by the window, not by a guard
                         continue;
                     }
                 }
@@ -1476,7 +1534,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                     if (L > 0) {
                         lastEv = base + j + L;
                         nextEvent = base + j + L + 1;
-                        if (j + L + 1 >= climit) cont = 2;
+                        if (j + L + 1 >= climit) cont = 2 | 4;
                         continue;
                     }
                 }
@@ -1560,7 +1618,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
             PPSeg cs = PPSeg{0, 0, 0, 0, 0, INFINITY, -INFINITY, 0, 0, 1, 0};
             double px, py, puth;
             bool perr = false;
-            pp_window_pose(S2, hot, cur, cs, lane == 1 ? endTime : tl, tl, true, px, py, puth, perr);
+            pp_window_pose<PP_COVER_SINCOS_TAB>(S2, hot, cur, cs, lane == 1 ? endTime : tl, tl, true, px, py, puth, perr);
             if (lastIdx >= 0) { ix = pp_readlane(px, 0); iy = pp_readlane(py, 0); }
             endX = pp_readlane(px, 1);
             endY = pp_readlane(py, 1);

@@ -5,6 +5,7 @@
 // runs unchanged around GpuAStarPlanner.  PotentialFieldPlanner and GeoTiffMap are not on this path.
 #pragma once
 #include <condition_variable>
+#include <functional>
 #include <future>
 #include <mutex>
 #include <string>
@@ -49,6 +50,23 @@ public:
     // this build's knobs
     void setPlanningTimeSeconds(double s) { m_PlanningTimeSeconds = s; }   // reference: c_PlanningTimeSeconds = 0.85 (executive.h:183)
     void setSpeculation(int n) { m_PlannerConfig.setSpeculation(n); }
+    // PlannerConfig::setDeadlineGuard: off for a clock that does not advance while the device works (a scripted, counting clock)
+    void setDeadlineGuard(bool on) { m_PlannerConfig.setDeadlineGuard(on); }
+    // What the loop decided for a cycle, handed to an observer right before that cycle's plan() call (called on the planning
+    // thread): the state it plans from (executive.cpp:114-118,217-268), how much of the last plan it hands back (:144-146), the
+    // horizon after any back-off (:270-287), the time budget (:189-190), the ribbons left.  tests/test_gpu_mission.py compares these
+    // with the oracle's restatement of the loop, cycle by cycle.
+    struct CycleRecord {
+        unsigned long cycle = 0;
+        State from;
+        size_t previousPlanLegs = 0;
+        double timeHorizon = 0, timeRemaining = 0;
+        size_t ribbons = 0;
+        double uncoveredLength = 0;
+        int emptyInARow = 0;
+        bool lastPlanAchievable = false;
+    };
+    void setCycleObserver(std::function<void(const CycleRecord&)> f) { m_CycleObserver = std::move(f); }
     // the devices every cycle's planner works on (default: device 0).  The contexts are process-level (GpuContext::shared) and
     // are held here for the life of the executive, so no cycle pays for device allocations an earlier cycle already made.
     void setDevices(const std::vector<int>& devices) { m_Contexts = GpuContext::shared(devices); }
@@ -80,6 +98,7 @@ private:
     double m_LastHeading = 0, m_LastUpdateTime = 1;
     double m_PlanningTimeSeconds = 0.85;
     unsigned long m_Cycles = 0, m_EmptyPlans = 0;
+    std::function<void(const CycleRecord&)> m_CycleObserver;
 };
 
 }  // namespace ppamd

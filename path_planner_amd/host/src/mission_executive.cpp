@@ -222,7 +222,16 @@ void Executive::planLoop() {
                 else m_PlannerConfig.setObstaclesManager(contacts);
                 ribbons.coverBetween(m_LastState.x(), m_LastState.y(), cyc.from.x(), cyc.from.y(), false);   // up to where we plan from (:186)
                 GpuAStarPlanner planner(m_Contexts);                              // stateless: a new one every cycle (:85-90); the device contexts persist
-                cyc.last = planner.plan(ribbons, cyc.from, m_PlannerConfig, cyc.last.Plan, cycleStart + m_PlanningTimeSeconds - out.getTime());
+                const double budget = cycleStart + m_PlanningTimeSeconds - out.getTime();
+                if (m_CycleObserver) {
+                    CycleRecord rec;
+                    rec.cycle = m_Cycles - 1; rec.from = cyc.from; rec.previousPlanLegs = cyc.last.Plan.get().size();
+                    rec.timeHorizon = m_PlannerConfig.timeHorizon(); rec.timeRemaining = budget;
+                    rec.ribbons = (size_t)ribbons.count(); rec.uncoveredLength = ribbons.getTotalUncoveredLength();
+                    rec.emptyInARow = cyc.emptyInARow; rec.lastPlanAchievable = cyc.lastPlanAchievable;
+                    m_CycleObserver(rec);
+                }
+                cyc.last = planner.plan(ribbons, cyc.from, m_PlannerConfig, cyc.last.Plan, budget);
             } catch (const std::exception& e) {                                   // logged, plan dropped, loop continues (:191-195)
                 std::cerr << "Exception thrown while planning: " << e.what() << " - proceeding without a plan." << std::endl;
                 cyc.last.Plan = DubinsPlan();

@@ -4,7 +4,8 @@ quiet run attempts and the steps they absorbed), from a -DPP_DBG_COUNTS build th
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = os.path.join(ROOT, "gpurun_out", "libppgpu_counts.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-DPP_DBG_COUNTS",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-DPP_DBG_COUNTS"] +
+                      os.environ.get("RUN_COUNTS_FLAGS", "").split() + [
                        os.path.join(ROOT, "path_planner_amd", "csrc", "ppgpu.hip"), "-o", lib, "-ldl"])
 os.environ["PPGPU_LIB_OVERRIDE"] = lib
 os.environ["PPGPU_QUIET_FINISH"] = "0"      # the counters travel in record slots that only the wave writes
