@@ -123,3 +123,51 @@ def test_skipping_the_heuristic_value_leaves_everything_else_alone():
             assert np.array_equal(a[f], b[f], equal_nan=True) if a[f].dtype.kind == "f" else np.array_equal(a[f], b[f]), f
     feas = (a["flags"] & 1) == 0
     assert np.all(b["h"][feas] == 0) and np.any(a["h"][feas] > 0) and np.array_equal(b["f"][feas], b["g"][feas])
+
+
+def test_oracle_executive_back_off_and_plan_reuse_rules():
+    """oracle/mission_oracle (Executive::planLoop restated, executive.cpp:43-305) on the scripted mission of tests/test_gpu_mission.py,
+    CPU only: three empty plans in a row halve the horizon and reset the count (:270-287); an exception inside plan() gives an empty
+    plan and the loop goes on from dead reckoning (:191-195, :114-118); a controller answer off the plan drops the plan (:245-257);
+    otherwise the remainder of the last plan is handed back (:144-146)."""
+    import json, os, subprocess, tempfile
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_mission import ORACLE, write_scripted_mission, read_trace
+    if not os.path.exists(ORACLE):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(ORACLE), "mission_oracle"])
+    with tempfile.TemporaryDirectory() as d:
+        sc = write_scripted_mission(d)
+        out = subprocess.run([ORACLE, sc], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+    tr = read_trace(out.stdout)
+    cyc = [r for r in tr if r["k"] == "cycle"]
+    st = [r for r in tr if r["k"] == "stats"]
+    pub = {r["cycle"]: r for r in tr if r["k"] == "publish"}
+    assert len(cyc) == len(st) == 40
+    fails = 0
+    horizon = 30.0
+    for c, s in zip(cyc, st):
+        assert c["empty_in_a_row"] == fails and c["time_horizon"] == horizon, (c, fails, horizon)
+        if s["plan_legs"] == 0:
+            assert c["cycle"] not in pub
+            fails += 1
+            if fails > 2:
+                horizon = max(horizon / 2, 5.0)
+                if horizon > 5.0:
+                    fails = 0
+        else:
+            fails = 0
+            assert c["cycle"] in pub
+        if c["cycle"] == 26:
+            horizon = 30.0                      # the scripted reconfiguration arrives after this cycle's plan()
+    # plan reuse: the next cycle plans from the controller's answer and gets the last plan back, unless the answer was off the plan
+    for c in cyc[1:]:
+        prev = c["cycle"] - 1
+        if prev in pub and prev not in (10, 20):
+            assert c["from"] == pub[prev]["next"] and c["previous_plan_legs"] >= 1 and c["last_plan_achievable"] == 1
+        elif prev in (10, 20):
+            assert c["from"][:2] == pub[prev]["next"][:2] and c["previous_plan_legs"] == 0 and c["last_plan_achievable"] == 0
+        else:
+            assert c["previous_plan_legs"] == 0          # after an empty plan: dead reckoning, nothing to hand back
+    assert st[6]["plan_legs"] == 0                       # the scripted clock fault
