@@ -457,6 +457,52 @@ __device__ __forceinline__ bool pp_is_blocked(const PPGrid& g, double x, double 
     uint32_t w = g.bits[(size_t)r * g.wpr + (c >> 5)];
     return (w >> (c & 31)) & 1u;
 }
+// The same lookup with the chunk's occupancy words staged in LDS first (BASELINE's north_star: "occupancy grid tiled into LDS").
+// MEASUREMENT VARIANT, -DPP_GRID_LDS (tools/variant_stats.sh; DESIGN.md 4.2 has the number): the wave finds the bounding box of
+// its 64 cells (rows x 32-cell words), copies those words from the L2-resident bit grid into its LDS tile with coalesced loads
+// (a chunk moves at most 3.2 m: some 35 rows x 2 words at 0.1 m cells), and every lane reads its word there.  Chunks whose box
+// does not fit the tile take the direct lookup.  `tile` = PP_GRID_TILE_WORDS dwords private to the wave.
+#define PP_GRID_TILE_WORDS 256
+__device__ __forceinline__ bool pp_is_blocked_lds(const PPGrid& g, double x, double y, bool valid, uint32_t* tile) {
+    if (g.rows == 0) return false;
+    const double cx = x * g.inv_res, cy = y * g.inv_res;
+    const unsigned cxl = (unsigned)(cx * (1.0 - 4e-9)), cxh = (unsigned)(cx * (1.0 + 4e-9));
+    const unsigned cyl = (unsigned)(cy * (1.0 - 4e-9)), cyh = (unsigned)(cy * (1.0 + 4e-9));
+    unsigned r = cyl, c = cxl;
+    bool outside = (x < 0) | (cxl >= (unsigned)g.cols) | (y < 0) | (cyl >= (unsigned)g.rows);
+    if (__ballot((cxl != cxh) | (cyl != cyh)) != 0ull) {
+        const double qx = x / g.res, qy = y / g.res;
+        outside = (x < 0) | (qx >= (double)g.cols) | (y < 0) | (qy >= (double)g.rows);
+        r = (unsigned)qy;
+        c = (unsigned)qx;
+    }
+    const bool in = valid & !outside;
+    const unsigned wd = c >> 5;
+    // bounding box of the in-grid cells, over the wave
+    unsigned rmin = in ? r : 0xffffffffu, rmax = in ? r : 0u, wmin = in ? wd : 0xffffffffu, wmax = in ? wd : 0u;
+    for (int o = 32; o > 0; o >>= 1) {
+        rmin = min(rmin, (unsigned)__shfl_xor((int)rmin, o, PP_WAVE)); rmax = max(rmax, (unsigned)__shfl_xor((int)rmax, o, PP_WAVE));
+        wmin = min(wmin, (unsigned)__shfl_xor((int)wmin, o, PP_WAVE)); wmax = max(wmax, (unsigned)__shfl_xor((int)wmax, o, PP_WAVE));
+    }
+    uint32_t w = 0u;
+    if (__ballot(in) == 0ull) return valid & outside;
+    const unsigned nrows = rmax - rmin + 1u, nw = wmax - wmin + 1u, total = nrows * nw;
+    if (total <= (unsigned)PP_GRID_TILE_WORDS) {
+        const int lane = pp_lane();
+        for (unsigned i = (unsigned)lane; i < total; i += PP_WAVE) {
+            const unsigned rr = (nw == 1u) ? i : ((nw == 2u) ? (i >> 1) : (i / nw));
+            const unsigned ww = i - rr * nw;
+            tile[i] = g.bits[(size_t)(rmin + rr) * g.wpr + (wmin + ww)];
+        }
+        pp_wave_lds_fence();
+        if (in) w = tile[(r - rmin) * nw + (wd - wmin)];
+        pp_wave_lds_fence();
+    } else if (in) {
+        w = g.bits[(size_t)r * g.wpr + wd];
+    }
+    if (outside) return valid;
+    return valid & (((w >> (c & 31)) & 1u) != 0u);
+}
 
 // ----------------------------------------------------------------------------- dynamic obstacles
 // BinaryDynamicObstaclesManager::Obstacle with the per-call constants hoisted on the HOST with

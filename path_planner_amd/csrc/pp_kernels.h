@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) void pp_k_plan_skips_gaussian_many(PPParams p,
 // e = the edge's slot in the workspace.  GAUSSIAN: the dynamic obstacles are GaussianDynamicObstaclesManager's (its own
 // instantiation: exp() and the density bookkeeping would otherwise cost the common kernel registers).
 template <bool GAUSSIAN>
-__device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long long e) {
+__device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long long e, uint32_t* gridTile = nullptr) {
     const int lane = pp_lane();
     const PPEdgeSetup* S = p.setup + e;
     PPTrackSummary* sum = p.track_summary + e;
@@ -920,7 +920,11 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
                 // on edges that may not cover while turning
                 heading = cov ? 0.0 : pp_heading_from_yaw(pp_mod2pi(uth));
     #ifndef PP_ABL_NO_GRID
+#ifdef PP_GRID_LDS
+                if (!gridClear) blk = pp_is_blocked_lds(p.grid, x, y, valid, gridTile);
+#else
                 if (!gridClear) blk = valid & pp_is_blocked(p.grid, x, y);   // Edge.cpp:144 (pp_k_plan_skips may have ruled it out for the whole chunk)
+#endif
     #endif
             }
             double dens = 0;
@@ -1778,13 +1782,25 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
 // n_edges = slice size (ppgpu.hip: launch_cost)
 __global__ __launch_bounds__(PP_WPB * 64, PP_POSE_MIN_WAVES) void pp_k_pose_sweep(PPParams p) {
     PPQueue qs = pp_queue_init();
+#ifdef PP_GRID_LDS
+    __shared__ uint32_t s_tile[PP_WPB * PP_GRID_TILE_WORDS];
+    uint32_t* tile = s_tile + (threadIdx.x >> 6) * PP_GRID_TILE_WORDS;
+#else
+    uint32_t* tile = nullptr;
+#endif
     for (PP_EACH_EDGE(idx, 1, PP_Q_POSE, p.n_edges, 1))
-        pp_pose_sweep_edge<false>(p, p.ws_base + idx);
+        pp_pose_sweep_edge<false>(p, p.ws_base + idx, tile);
 }
 __global__ __launch_bounds__(PP_WPB * 64, 4) void pp_k_pose_sweep_gaussian(PPParams p) {
     PPQueue qs = pp_queue_init();
+#ifdef PP_GRID_LDS
+    __shared__ uint32_t s_tile[PP_WPB * PP_GRID_TILE_WORDS];
+    uint32_t* tile = s_tile + (threadIdx.x >> 6) * PP_GRID_TILE_WORDS;
+#else
+    uint32_t* tile = nullptr;
+#endif
     for (PP_EACH_EDGE(idx, 1, PP_Q_POSE, p.n_edges, 1))
-        pp_pose_sweep_edge<true>(p, p.ws_base + idx);
+        pp_pose_sweep_edge<true>(p, p.ws_base + idx, tile);
 }
 // The wave that finished an edge's cover sweep goes straight on to the edge's heuristic (point heuristics, binary-obstacle
 // sweep; the Dubins heuristics and the 12-ribbon pass keep their own kernels): the child ribbons and the record it needs were
