@@ -191,6 +191,13 @@ int ppgpu_past_timing(ppgpu_ctx* ctx, int32_t back, double* ms_solve, double* ms
  * small launches it is every edge.  (Sliced launches: exact with timing on, the last slice's share otherwise.)  Waits for the launch. */
 int ppgpu_last_cover_edges(ppgpu_ctx* ctx, int64_t* n_edges);
 
+/* Device memory for callers that have no HIP toolchain of their own (the C++ host library is built with g++ against this header
+ * only): buffers for the `d_` parameters below, on the handle's device, and a blocking copy back to the host that first waits
+ * for the handle's stream. */
+int ppgpu_device_alloc(ppgpu_ctx* ctx, uint64_t bytes, void** d_out);
+int ppgpu_device_free(ppgpu_ctx* ctx, void* d_ptr);
+int ppgpu_device_read(ppgpu_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes);
+
 /* ---------------------------------------------------------------- world state */
 
 /* PlannerConfig setters + Ribbon::RibbonWidth + RibbonManager heuristic. */

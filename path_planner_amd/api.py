@@ -31,6 +31,9 @@ def _load():
         "ppgpu_set_stream": (C.c_int, [vp, vp]),
         "ppgpu_synchronize": (C.c_int, [vp]),
         "ppgpu_reserve_samples": (C.c_int, [vp, i64, i32]),
+        "ppgpu_device_alloc": (C.c_int, [vp, u64, C.POINTER(vp)]),
+        "ppgpu_device_free": (C.c_int, [vp, vp]),
+        "ppgpu_device_read": (C.c_int, [vp, vp, vp, u64]),
         "ppgpu_heuristic_host": (C.c_int, [vp, i32, vp, vp, vp, vp, vp]),
         "ppgpu_expand_capacity": (C.c_int64, [i32, i32]),
         "ppgpu_expand_host": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, C.POINTER(C.c_int64), vp, vp, vp, i32]),

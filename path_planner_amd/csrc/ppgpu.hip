@@ -272,6 +272,28 @@ int ppgpu_synchronize(ppgpu_ctx* c) {
     return PPGPU_OK;
 }
 
+int ppgpu_device_alloc(ppgpu_ctx* c, uint64_t bytes, void** d_out) {
+    if (!c || !d_out || bytes == 0) return fail(PPGPU_EINVAL, "device_alloc: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(d_out, (size_t)bytes));
+    return PPGPU_OK;
+}
+int ppgpu_device_free(ppgpu_ctx* c, void* d_ptr) {
+    if (!c) return fail(PPGPU_EINVAL, "null context");
+    if (!d_ptr) return PPGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(d_ptr));
+    return PPGPU_OK;
+}
+int ppgpu_device_read(ppgpu_ctx* c, void* h_dst, const void* d_src, uint64_t bytes) {
+    if (!c || !h_dst || !d_src) return fail(PPGPU_EINVAL, "device_read: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PPGPU_OK;
+}
+
 int ppgpu_set_config(ppgpu_ctx* c, const ppgpu_config* cfg) {
     if (!c || !cfg) return fail(PPGPU_EINVAL, "null argument");
     if (!(cfg->max_speed > 0) || !(cfg->collision_checking_increment > 0) || !(cfg->turning_radius > 0) ||

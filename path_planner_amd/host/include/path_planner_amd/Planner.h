@@ -176,4 +176,38 @@ private:
                        const std::vector<long>& sampleIndex);
 };
 
+// One planner iteration in its BATCH form, sample-sharded over the GPUs of a node (SURVEY.md 8 e; BASELINE's north_star: "the
+// sample batch shards naturally across the 8 GPUs of one node with a single RCCL all-reduce of the per-shard best cost/vertex
+// each iteration").  The iteration's batch of `attempts` draws from the StateGenerator stream is cut into contiguous slices, one
+// per device context; every device skips the slices below its own (ppgpu_sampler_skip), draws and filters its slice, costs the
+// edges from the open vertex to its samples under the four (radius, speed) configurations and reduces its best (f, edge); then
+// ONE collective — ppgpu_allreduce_best on the communicator ppgpu_comm_init_all made of the contexts — leaves the global
+// incumbent on every device.  No sample, edge or record crosses between devices.  Each context's work runs on its own host
+// thread (GpuContext::run), which is also what the collective needs: every rank must have joined before any returns.
+// The reference has no counterpart (its incumbent update is AStarPlanner.cpp:109-117 on one thread); GpuAStarPlanner's anytime
+// search keeps dealing open VERTICES to the devices (the host pops goals in f order, no collective needed there).
+class ShardedIteration {
+public:
+    struct Result {
+        double f = 0;                          // the global incumbent: smallest f over every shard's feasible edges ...
+        uint64_t fBits = ~0ull, edge = ~0ull;  // ... its bit pattern and global edge id (shard * edgesPerShard + local index); ~0: none
+        int shard = -1;                        // which device found it
+        std::vector<int64_t> kept;             // samples each shard kept (map filter)
+        int64_t edges = 0;                     // edges costed over all shards
+        int rcclRanks = 0;                     // ncclCommCount of the communicator (0: host combine, see below)
+        bool agreed = false;                   // every device ended with the same key
+    };
+    // One context per device: the communicator is RCCL's.  Two contexts on ONE device (a one-GPU box rehearsing the split) cannot
+    // form one — RCCL takes one rank per device — and the keys are then combined on the host instead; Result::rcclRanks says which.
+    explicit ShardedIteration(std::vector<std::shared_ptr<GpuContext>> ctxs);
+    ~ShardedIteration();
+    Result run(const RibbonManager& ribbonManager, const State& start, const PlannerConfig& config, unsigned long seed, int64_t attempts);
+
+private:
+    std::vector<std::shared_ptr<GpuContext>> m_Ctxs;
+    std::vector<void*> m_Keys, m_Records;      // per device: the 16-byte key and the record buffer (device memory)
+    std::vector<size_t> m_RecordCap;
+    bool m_Rccl = false;
+};
+
 }  // namespace ppamd

@@ -189,32 +189,35 @@ int GpuAStarPlanner::depth(int v) const {
 }
 
 // ------------------------------------------------------------------------------------------------ world upload
-void GpuAStarPlanner::uploadWorld(const State& start) {
+// The snapshot every device of a planner works from: configuration, occupancy grid, obstacle table (SURVEY 8 e: replicated on
+// every device once per replan).
+static void uploadSnapshot(const std::vector<std::shared_ptr<GpuContext>>& ctxs, const PlannerConfig& config, const RibbonManager& ribbonManager,
+                           double startStateTime) {
     ppgpu_config c{};
-    c.max_speed = m_Config.maxSpeed();
-    c.slow_speed = m_Config.slowSpeed();
-    c.turning_radius = m_Config.turningRadius();
-    c.coverage_turning_radius = m_Config.coverageTurningRadius();
-    c.time_horizon = m_Config.timeHorizon();
-    c.time_minimum = m_Config.timeMinimum();
-    c.collision_checking_increment = m_Config.collisionCheckingIncrement();
-    c.start_state_time = start.time();
+    c.max_speed = config.maxSpeed();
+    c.slow_speed = config.slowSpeed();
+    c.turning_radius = config.turningRadius();
+    c.coverage_turning_radius = config.coverageTurningRadius();
+    c.time_horizon = config.timeHorizon();
+    c.time_minimum = config.timeMinimum();
+    c.collision_checking_increment = config.collisionCheckingIncrement();
+    c.start_state_time = startStateTime;
     c.ribbon_width = Ribbon::RibbonWidth;
     c.collision_penalty_factor = kCollisionPenaltyFactor;
     c.time_penalty_factor = kTimePenaltyFactor;
-    c.heuristic_turning_radius = m_RibbonManager.turningRadius();
-    c.heuristic = (int32_t)m_RibbonManager.heuristic();
-    c.tsp_k = m_RibbonManager.k();
-    c.branching_factor = m_Config.branchingFactor();
+    c.heuristic_turning_radius = ribbonManager.turningRadius();
+    c.heuristic = (int32_t)ribbonManager.heuristic();
+    c.tsp_k = ribbonManager.k();
+    c.branching_factor = config.branchingFactor();
     std::vector<uint8_t> cells;
     int rows = 0, cols = 0;
     double res = 0;
-    if (m_Config.map()) m_Config.map()->rasterize(cells, rows, cols, res);
+    if (config.map()) config.map()->rasterize(cells, rows, cols, res);
     std::vector<double> orows;
-    const DynamicObstaclesManager& om = m_Config.obstaclesManager();
+    const DynamicObstaclesManager& om = config.obstaclesManager();
     om.deviceRows(orows);
-    // the snapshot is replicated on every device of the planner (SURVEY 8 e: grid, obstacles and config are broadcast once per replan)
-    for (const auto& ctx : m_Ctxs) {
+    auto check = [](int rc, const char* what) { if (rc != PPGPU_OK) throw std::runtime_error(std::string(what) + ": " + ppgpu_last_error()); };
+    for (const auto& ctx : ctxs) {
         ppgpu_ctx* h = ctx->handle();
         check(ppgpu_set_config(h, &c), "ppgpu_set_config");
         check(ppgpu_set_grid(h, rows ? cells.data() : nullptr, rows, cols, res), "ppgpu_set_grid");
@@ -224,6 +227,8 @@ void GpuAStarPlanner::uploadWorld(const State& start) {
             check(ppgpu_set_obstacles(h, om.deviceModel(), (int32_t)(orows.size() / 7), orows.empty() ? nullptr : orows.data()), "ppgpu_set_obstacles");
     }
 }
+
+void GpuAStarPlanner::uploadWorld(const State& start) { uploadSnapshot(m_Ctxs, m_Config, m_RibbonManager, start.time()); }
 
 // ------------------------------------------------------------------------------------------------ open list
 void GpuAStarPlanner::pushVertexQueue(int vi) {   // SamplingBasedPlanner.cpp:7-19
@@ -832,6 +837,106 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
     m_Stats.OrderFallbacks -= orderFallbacksBefore;
     g_prof.report("plan()");
     return m_Stats;
+}
+
+// ------------------------------------------------------------------------------------------------ ShardedIteration
+ShardedIteration::ShardedIteration(std::vector<std::shared_ptr<GpuContext>> ctxs) : m_Ctxs(std::move(ctxs)) {
+    if (m_Ctxs.empty()) m_Ctxs.push_back(GpuContext::shared(0));
+    const size_t D = m_Ctxs.size();
+    m_Keys.assign(D, nullptr); m_Records.assign(D, nullptr); m_RecordCap.assign(D, 0);
+    bool distinct = true;
+    for (size_t i = 0; i < D; i++)
+        for (size_t j = 0; j < i; j++) distinct = distinct && m_Ctxs[i]->device() != m_Ctxs[j]->device();
+    for (size_t i = 0; i < D; i++)
+        if (ppgpu_device_alloc(m_Ctxs[i]->handle(), 16, &m_Keys[i]) != PPGPU_OK) throw std::runtime_error(std::string("ppgpu_device_alloc: ") + ppgpu_last_error());
+    if (distinct) {
+        std::vector<ppgpu_ctx*> hs;
+        for (auto& c : m_Ctxs) { ppgpu_comm_destroy(c->handle()); hs.push_back(c->handle()); }
+        if (ppgpu_comm_init_all(hs.data(), (int32_t)D) != PPGPU_OK) throw std::runtime_error(std::string("ppgpu_comm_init_all: ") + ppgpu_last_error());
+        m_Rccl = true;
+    }
+}
+
+ShardedIteration::~ShardedIteration() {
+    for (size_t i = 0; i < m_Ctxs.size(); i++) {
+        if (m_Rccl) ppgpu_comm_destroy(m_Ctxs[i]->handle());
+        ppgpu_device_free(m_Ctxs[i]->handle(), m_Keys[i]);
+        ppgpu_device_free(m_Ctxs[i]->handle(), m_Records[i]);
+    }
+}
+
+ShardedIteration::Result ShardedIteration::run(const RibbonManager& ribbonManager, const State& start, const PlannerConfig& config, unsigned long seed,
+                                               int64_t attempts) {
+    const size_t D = m_Ctxs.size();
+    RibbonManager rm = ribbonManager;
+    rm.changeHeuristicIfTooManyRibbons();                                  // AStarPlanner.cpp:18
+    uploadSnapshot(m_Ctxs, config, rm, start.time());
+    // the sampling box and the root vertex of AStarPlanner::plan (:27-37)
+    const double magnitude = config.maxSpeed() * config.timeHorizon();
+    const double* ext = config.map() ? config.map()->extremes() : Map().extremes();
+    const double bounds[6] = {std::fmax(start.x() - magnitude, ext[0]), std::fmin(start.x() + magnitude, ext[1]), std::fmax(start.y() - magnitude, ext[2]),
+                              std::fmin(start.y() + magnitude, ext[3]), config.maxSpeed(), config.maxSpeed()};
+    std::vector<double> rib(rm.rows(), rm.rows() + 4 * (size_t)rm.count());
+    ppgpu_vertex root{};
+    root.x = start.x(); root.y = start.y(); root.heading = start.heading(); root.speed = config.maxSpeed(); root.time = start.time();
+    root.g = 0; root.coverage_completed_time = rm.done() ? start.time() : rm.coverageCompletedTime();
+    root.ribbon_offset = 0; root.ribbon_count = (int32_t)rm.count();
+    // contiguous slices of the batch, sizes differing by at most one (path_planner_amd/sharding.py: shard_attempts)
+    const int64_t base = attempts / (int64_t)D, extra = attempts % (int64_t)D;
+    const int64_t edgesPerShard = 4 * (base + (extra ? 1 : 0));            // global edge ids: shard * edgesPerShard + local index
+    Result out;
+    out.kept.assign(D, 0);
+    std::vector<uint64_t> keys(2 * D, ~0ull);
+    auto shard = [&](size_t d) {
+        ppgpu_ctx* h = m_Ctxs[d]->handle();
+        auto check = [](int rc, const char* what) { if (rc != PPGPU_OK) throw std::runtime_error(std::string(what) + ": " + ppgpu_last_error()); };
+        const int64_t lo = (int64_t)d * base + std::min<int64_t>((int64_t)d, extra), n = base + ((int64_t)d < extra ? 1 : 0);
+        check(ppgpu_set_vertices(h, 1, &root, root.ribbon_count, rib.empty() ? nullptr : rib.data()), "ppgpu_set_vertices");
+        check(ppgpu_sampler_init(h, bounds, seed, (int32_t)(rib.size() / 4), rib.empty() ? nullptr : rib.data()), "ppgpu_sampler_init");
+        if (lo > 0) check(ppgpu_sampler_skip(h, lo), "ppgpu_sampler_skip");   // the slices of the lower ranks
+        int64_t kept = 0;
+        for (int64_t left = n; left > 0; left -= 524288) check(ppgpu_sampler_add(h, std::min<int64_t>(left, 524288), &kept), "ppgpu_sampler_add");
+        out.kept[d] = kept;
+        const size_t need = (size_t)std::max<int64_t>(4 * kept, 1) * sizeof(ppgpu_edge_result);
+        if (need > m_RecordCap[d]) {
+            check(ppgpu_device_free(h, m_Records[d]), "ppgpu_device_free");
+            m_Records[d] = nullptr; m_RecordCap[d] = 0;
+            check(ppgpu_device_alloc(h, need, &m_Records[d]), "ppgpu_device_alloc");
+            m_RecordCap[d] = need;
+        }
+        if (kept > 0) check(ppgpu_cost_edges_dense(h, 0, 1, 0, kept, 0xF, (ppgpu_edge_result*)m_Records[d], nullptr, 0), "ppgpu_cost_edges_dense");
+        check(ppgpu_best_edge(h, 4 * kept, (const ppgpu_edge_result*)m_Records[d], 0, (uint64_t)d * (uint64_t)edgesPerShard, (uint64_t*)m_Keys[d]), "ppgpu_best_edge");
+        if (m_Rccl) check(ppgpu_allreduce_best(h, nullptr, (uint64_t*)m_Keys[d]), "ppgpu_allreduce_best");   // the one collective of the iteration
+        check(ppgpu_device_read(h, &keys[2 * d], m_Keys[d], 16), "ppgpu_device_read");
+    };
+    if (D == 1) {
+        shard(0);
+    } else {
+        for (size_t d = 0; d < D; d++) m_Ctxs[d]->run([&, d] { shard(d); });
+        std::exception_ptr first;
+        for (size_t d = 0; d < D; d++) {
+            try { m_Ctxs[d]->wait(); } catch (...) { if (!first) first = std::current_exception(); }
+        }
+        if (first) std::rethrow_exception(first);
+    }
+    for (size_t d = 0; d < D; d++) out.edges += 4 * out.kept[d];
+    if (m_Rccl) {
+        int32_t world = 0, rank = 0;
+        if (ppgpu_comm_info(m_Ctxs[0]->handle(), &world, &rank) == PPGPU_OK) out.rcclRanks = world;
+        out.agreed = true;
+        for (size_t d = 1; d < D; d++) out.agreed = out.agreed && keys[2 * d] == keys[0] && keys[2 * d + 1] == keys[1];
+        out.fBits = keys[0]; out.edge = keys[1];
+    } else {
+        // contexts that share a device: the lexicographic min ppgpu_key_min computes, on the host
+        out.agreed = true;
+        for (size_t d = 0; d < D; d++)
+            if (keys[2 * d] < out.fBits || (keys[2 * d] == out.fBits && keys[2 * d + 1] < out.edge)) { out.fBits = keys[2 * d]; out.edge = keys[2 * d + 1]; }
+    }
+    if (out.edge != ~0ull) {
+        std::memcpy(&out.f, &out.fBits, sizeof(double));
+        out.shard = (int)(out.edge / (uint64_t)edgesPerShard);
+    }
+    return out;
 }
 
 }  // namespace ppamd

@@ -4,7 +4,8 @@
 //
 // Scenario lines:  cfg <key> <value> | start x y heading speed time | ribbon x1 y1 x2 y2 | heuristic H K radius |
 //                  ribbon_width w | obstacle x y heading speed time width length | gaussian x y heading speed time [c00 c01 c10 c11] | map_file path | clock t0 dt |
-//                  time_remaining T | prev qi0 qi1 qi2 p0 p1 p2 rho type speed start end | repeat n
+//                  time_remaining T | prev qi0 qi1 qi2 p0 p1 p2 rho type speed start end | repeat n |
+//                  sharded_batch attempts seed   (instead of plan(): one iteration's batch, sample-sharded over `devices`: ShardedIteration)
 #include <algorithm>
 #include <array>
 #include <chrono>
@@ -38,6 +39,8 @@ int main(int argc, char** argv) {
     double replanStep = 0.1;
     uint32_t mmsi = 1;
     std::vector<int> devices;
+    long long shardedAttempts = 0;
+    unsigned long shardedSeed = 7;
     std::string line;
     while (std::getline(in, line)) {
         std::istringstream s(line);
@@ -78,6 +81,7 @@ int main(int argc, char** argv) {
         } else if (k == "time_remaining") { s >> timeRemaining;
         } else if (k == "devices") {          // device ids of the planner; an id that repeats gets its own second context on that device
             int d; while (s >> d) devices.push_back(d);
+        } else if (k == "sharded_batch") { s >> shardedAttempts >> shardedSeed;
         } else if (k == "repeat") { s >> repeat;
         } else if (k == "replan") { s >> replans >> replanStep;   // N consecutive cycles, start moved replanStep seconds along the plan
         } else if (k == "real_clock") { int v; s >> v; realClock = v != 0;   // now() = t0 + wall seconds since plan() began
@@ -106,6 +110,29 @@ int main(int argc, char** argv) {
     } catch (const std::exception& e) {
         std::printf("{\"exception\": \"%s\"}\n", e.what());
         return 1;
+    }
+    if (shardedAttempts > 0) {
+        try {
+            ShardedIteration it(contexts);
+            ShardedIteration::Result r;
+            std::vector<double> wall;
+            for (int rep = 0; rep < repeat; rep++) {
+                const auto w0 = std::chrono::steady_clock::now();
+                r = it.run(rm, start, config, shardedSeed, shardedAttempts);
+                wall.push_back(1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count());
+            }
+            std::sort(wall.begin(), wall.end());
+            std::printf("{\"sharded_batch\": %lld, \"shards\": %zu, \"rccl_ranks\": %d, \"agreed\": %s, \"best_f\": %.17g, \"best_f_bits\": %llu, \"best_edge\": %llu, "
+                        "\"best_shard\": %d, \"edges\": %lld, \"wall_ms_median\": %.4f, \"kept\": [",
+                        shardedAttempts, contexts.size(), r.rcclRanks, r.agreed ? "true" : "false", r.f, (unsigned long long)r.fBits, (unsigned long long)r.edge, r.shard,
+                        (long long)r.edges, wall[wall.size() / 2]);
+            for (size_t i = 0; i < r.kept.size(); i++) std::printf("%s%lld", i ? ", " : "", (long long)r.kept[i]);
+            std::printf("]}\n");
+            return 0;
+        } catch (const std::exception& e) {
+            std::printf("{\"exception\": \"%s\"}\n", e.what());
+            return 1;
+        }
     }
     try {
         Planner::Stats st;

@@ -456,3 +456,47 @@ def test_ten_hertz_replan_loop_with_32_moving_obstacles(monkeypatch):
     # "Guaranteed to return before timeRemaining has elapsed" (Planner.h:42): the deadline guard does not start a round trip or a
     # sample doubling that cannot end in time, so what is left above the budget is one mispredicted round trip and OS jitter
     assert r["wall_ms_p50"] <= 100.5 and r["wall_ms_p99"] <= 105.0, r
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_sample_sharded_iteration_in_the_cpp_product(devices):
+    """ShardedIteration (SURVEY 8 e in the C++ host library): the iteration's batch split over the device contexts by sample index —
+    ppgpu_sampler_skip, draw, cost, ppgpu_best_edge with the shard's index base — and combined with ONE collective,
+    ppgpu_allreduce_best on the communicator ppgpu_comm_init_all made (one context: a 1-rank RCCL communicator, all a one-GPU box
+    can form; three contexts on the one device: RCCL takes one rank per device, so the keys are combined on the host, and the
+    split itself is what is checked).  Either way the incumbent is the unsharded launch's: same f bits, same sample, same
+    configuration."""
+    from path_planner_amd import api, sharding, workloads
+    from path_planner_amd.types import RESULT_DTYPE, F_INFEASIBLE
+    import torch
+    w = workloads.config2()
+    attempts, seed = 3001, 7
+    with tempfile.TemporaryDirectory() as d:
+        mp = os.path.join(d, "grid.map")
+        _write_map(w.grid, w.res, mp)
+        sc = os.path.join(d, "s.txt")
+        _scenario(w, sc, mp, 1000.0, 1e-3, 10, 64, devices=devices)
+        with open(sc, "a") as f:
+            f.write(f"sharded_batch {attempts} {seed}\n")
+        r = _run_cli(sc)
+    print(r)
+    assert r["shards"] == len(devices) and r["agreed"]
+    assert r["rccl_ranks"] == (1 if len(devices) == 1 else 0)
+    # the unsharded launch through the C ABI
+    ctx = api.Context(0)
+    ctx.set_config(w.cfg); ctx.set_grid(w.grid, w.res); ctx.set_obstacles(w.obst)
+    ctx.set_vertices(w.root(), w.ribbons4)
+    ctx.sampler_init(w.bounds6, seed, w.ribbons4)
+    n = ctx.sampler_add(attempts)
+    assert sum(r["kept"]) == n and r["edges"] == 4 * n
+    d_res = torch.zeros(4 * n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    ctx.cost_edges_dense(0, 1, 0, n, 0xF, d_res.data_ptr())
+    ctx.synchronize()
+    res = d_res.cpu().numpy().view(RESULT_DTYPE)
+    key = sharding.local_best_key(res["f"], (res["flags"] & F_INFEASIBLE) == 0)
+    assert int(key[0]) == r["best_f_bits"]
+    # global edge id -> (shard, local edge) -> position in the unsharded list
+    per = 4 * -(-attempts // len(devices))
+    shard, local = r["best_edge"] // per, r["best_edge"] % per
+    assert shard == r["best_shard"] and 4 * sum(r["kept"][:shard]) + local == int(key[1])
