@@ -18,6 +18,13 @@ class PpgpuError(RuntimeError):
 
 
 def _load():
+    # The PyTorch wheel carries its own ROCm runtime; whichever libamdhip64 a process loads first serves every later user.  Loaded
+    # after this library's, torch reports "No HIP GPUs are available".  tests/ and bench.py pair the two, so torch goes first
+    # whenever it is installed (importing it does not touch the device).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

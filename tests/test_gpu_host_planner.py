@@ -466,9 +466,9 @@ def test_sample_sharded_iteration_in_the_cpp_product(devices):
     can form; three contexts on the one device: RCCL takes one rank per device, so the keys are combined on the host, and the
     split itself is what is checked).  Either way the incumbent is the unsharded launch's: same f bits, same sample, same
     configuration."""
+    import torch                                     # before the HIP library: whichever libamdhip64 loads first serves both
     from path_planner_amd import api, sharding, workloads
     from path_planner_amd.types import RESULT_DTYPE, F_INFEASIBLE
-    import torch
     w = workloads.config2()
     attempts, seed = 3001, 7
     with tempfile.TemporaryDirectory() as d:
