@@ -740,14 +740,10 @@ __device__ __forceinline__ void pp_plan_skips_chunk(const PPParams& p, const PPE
     const bool ok = okGeom && okHead && gridClear && decided;
     *skipb = ok ? PP_SKIP_ALL : (unsigned char)((gridClear ? PP_SKIP_GRID : 0) | (obstClear ? PP_SKIP_OBST : 0));
     if (ok) {
+        // (the per-step counts of a skipped chunk are not stored: every step is inside the same nInside boxes, and the one reader
+        // that can stop inside a skipped chunk — the cover sweep, when coverage completes there — divides the chunk's sum by 64;
+        // round 2 wrote them, 128 bytes per such chunk: half of this kernel's 205 MB of writes)
         p.track_chunk_hits[(size_t)e * p.nch + chunk] = (unsigned)(PP_WAVE * nInside);
-        if (nInside > 0) {
-            // the per-step counts (read only if the edge ends inside this chunk): every step is inside the same nInside boxes
-            const unsigned w2 = (unsigned)nInside | ((unsigned)nInside << 16);
-            uint4 v; v.x = v.y = v.z = v.w = w2;
-            uint4* th = reinterpret_cast<uint4*>(p.track_hits + (size_t)e * p.ngp + k0);
-            for (int i = 0; i < PP_WAVE / 8; i++) th[i] = v;
-        }
         if (!cov) p.track_eq[(size_t)e * p.nch + chunk] = eqWord;
         if (GAUSSIAN) p.track_chunk_pen[(size_t)e * p.nch + chunk] = 0.0;
     } else if (!cov && k0 > 0 && dP >= 0.0 && dP <= length) {
@@ -1112,8 +1108,12 @@ __device__ __forceinline__ bool pp_finish_quiet_edge(const PPParams& p, const PP
         const int cfull = hexec >> 6;
         for (int c = 0; c < cfull; c++) hitsTotal += (int)tch[c];
         if ((hexec & 63) != 0 && tch[cfull] != 0u) {
-            const unsigned short* thits = p.track_hits + (size_t)e * p.ngp;
-            for (int i = cfull << 6; i < hexec; i++) hitsTotal += (int)thits[i];
+            if (p.track_skip && (p.track_skip[(size_t)e * p.nch + cfull] & PP_SKIP_ALL) != 0) {
+                hitsTotal += (hexec & 63) * (int)(tch[cfull] >> 6);           // a skipped chunk: the same boxes at every step (no per-step counts)
+            } else {
+                const unsigned short* thits = p.track_hits + (size_t)e * p.ngp;
+                for (int i = cfull << 6; i < hexec; i++) hitsTotal += (int)thits[i];
+            }
         }
     }
     const double penalty = (double)hitsTotal * p.cpf;
@@ -1648,7 +1648,11 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
         int acc = 0;
         if (p.n_obst > 0) {
             for (int c = lane; c < cfull; c += PP_WAVE) acc += (int)tch[c];
-            if ((hexec & 63) != 0 && tch[cfull] != 0u && (cfull << 6) + lane < hexec) acc += (int)thits[(cfull << 6) + lane];
+            if ((hexec & 63) != 0 && tch[cfull] != 0u && (cfull << 6) + lane < hexec) {
+                // a chunk the pose sweep skipped has no per-step counts: all of its 64 steps are inside the same boxes
+                const bool skipped = p.track_skip && (p.track_skip[(size_t)e * p.nch + cfull] & PP_SKIP_ALL) != 0;
+                acc += skipped ? (int)(tch[cfull] >> 6) : (int)thits[(cfull << 6) + lane];
+            }
             hitsTotal = pp_wave_sum_i(acc);
         }
     }
