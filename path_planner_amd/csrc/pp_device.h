@@ -92,7 +92,7 @@ __device__ __forceinline__ double pp_heading_to(double x, double y, double x1, d
 // minimax polynomials for sin and cos on [-pi/4, pi/4] with a correction term for the low part of the reduced
 // argument; error below 1 ulp).  It replaces the general-purpose device sincos, whose huge-argument path and extra
 // selects cost about twice as many instructions; arguments outside the fast range take the library call.
-// Like any libm pair, results can differ from the host libm's in the last bit: see DESIGN.md "Numerics".
+// Like any libm pair, results can differ from the host libm's in the last bit: see DESIGN.md Appendix C.
 template <bool TAB = false>
 __device__ __forceinline__ void pp_sincos_bounded(double x, double* sn, double* cs);
 __device__ __forceinline__ void pp_sincos(double x, double* sn, double* cs) {
@@ -458,7 +458,7 @@ __device__ __forceinline__ bool pp_is_blocked(const PPGrid& g, double x, double 
     return (w >> (c & 31)) & 1u;
 }
 // The same lookup with the chunk's occupancy words staged in LDS first (BASELINE's north_star: "occupancy grid tiled into LDS").
-// MEASUREMENT VARIANT, -DPP_GRID_LDS (tools/variant_stats.sh; DESIGN.md 4.2 has the number): the wave finds the bounding box of
+// MEASUREMENT VARIANT, -DPP_GRID_LDS (tools/variant_stats.sh; DESIGN.md Appendix B has the number): the wave finds the bounding box of
 // its 64 cells (rows x 32-cell words), copies those words from the L2-resident bit grid into its LDS tile with coalesced loads
 // (a chunk moves at most 3.2 m: some 35 rows x 2 words at 0.1 m cells), and every lane reads its word there.  Chunks whose box
 // does not fit the tile take the direct lookup.  `tile` = PP_GRID_TILE_WORDS dwords private to the wave.

@@ -25,7 +25,7 @@ def compare_results(gpu, cpu, gpu_child=None, cpu_child=None, allow_word_ties=Fa
     mirror-image curves when source and target are symmetric about the line joining them; which of them `cost < best`
     keeps is decided by the last bit of the libm in use, on the reference as well.  With this option an edge whose word
     differs but whose path length agrees to 1e-12 is counted (n_word_ties) and excluded from the comparison.  skip_heuristic: do not compare h and f (the Dubins-TSP heuristics on collinear split pieces sit on
-    the Dubins mod-2pi discontinuity, see DESIGN.md "Numerics").  Both are used by the randomized test's second generation
+    the Dubins mod-2pi discontinuity).  Both are used by the randomized test's second generation
     only; every other test runs with the strict defaults."""
     rep = {"n": int(len(gpu))}
     # Dubins word, child ribbon count, executed steps

@@ -4,7 +4,7 @@ hands the first plan back.  Every call must agree in every statistic — samples
 FIRST-GOAL ITERATION, depth — and in cost to 1e-5.  Where another plan of the same cost comes back, the two edge dumps must
 show why (tools/fuzz_plan.py: classify_tie): the searches consume the same edges in the same order with the same feasibility, and
 upstream of the divergence a curve differs in its last digits — the reference's one-sided `distance - 1e-5` retry
-(DubinsWrapper.cpp:39-42) or two Dubins words of exactly equal length — which no device libm can rule out (DESIGN.md 4.2).  A
+(DubinsWrapper.cpp:39-42) or two Dubins words of exactly equal length — which no device libm can rule out (DESIGN.md Appendix C).  A
 difference in the push / pop order itself is a failure."""
 import os
 import sys

@@ -107,11 +107,11 @@ def _compare(host, st, plan, allow_order_fallbacks=False):
         # equal f, which std::pop_heap surfaces in an order that depends on the order expand() pushed them in (the device
         # replays the reference's heap-array order: ppgpu_expand_order).  One thing may differ in name only: a curve with a
         # zero-length arc is the same curve under two words (RSL / RSR with no final turn ...), their lengths tie exactly, and
-        # which of them `cost < best` keeps hangs on the last bit of libm's atan2 (DESIGN.md 4.2 (i)); such a segment is
+        # which of them `cost < best` keeps hangs on the last bit of libm's atan2 (DESIGN.md Appendix C (i)); such a segment is
         # compared as geometry.
         # The same goes for a straight line (both arcs of length zero) solved at the two turning radii of a vertex's edge
         # configurations: one trajectory, two descriptions of exactly equal cost; which of the two equal-f children is popped first
-        # then hangs on an ulp of h (the child ribbons carry corridor-run rounding, DESIGN.md 4.2).
+        # then hangs on an ulp of h (the child ribbons carry corridor-run rounding, DESIGN.md Appendix C).
         for a, b in zip(hp, plan):
             if a[7] == b[7] and np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)) <= 1e-5:
                 continue

@@ -218,7 +218,7 @@ def one_round(rng, rid, side=None):
     gpu, gchild = ctx.dense(root, rib, sx, sy, sh)
     e = edge_pack(np.zeros(ne, dtype=np.uint64), np.repeat(np.arange(n), 4), np.tile(np.arange(4), n))
     cpu, cchild = world.cost_edges(root, rib, sx, sy, sh, e, stride=20)
-    dub_h = heur in (H_TSP_DUBINS_ALL, H_TSP_DUBINS_K)     # see DESIGN.md "Numerics": compared by the dedicated tests, not here
+    dub_h = heur in (H_TSP_DUBINS_ALL, H_TSP_DUBINS_K)     # see DESIGN.md Appendix C: compared by the dedicated tests, not here
     rep = compare_results(gpu, cpu, gchild, cchild, allow_word_ties=True, skip_heuristic=dub_h)
     if os.environ.get("FUZZ_DUMP") == str(rid):
         import pickle
@@ -255,7 +255,7 @@ def one_round(rng, rid, side=None):
         ok2 = rep2["ok"]
         ndeg = 0
         if not ok2:
-            # a Dubins problem whose answer hangs on the last bits of its input (DESIGN.md 4.2, kinds i and ii: a word on the edge of
+            # a Dubins problem whose answer hangs on the last bits of its input (DESIGN.md Appendix C, kinds i and ii: a word on the edge of
             # existing, collinear poses): the device's word differs from the oracle's, and the oracle's own solver returns the
             # device's curve once source or target are moved by <= 1e-11.  Such edges are counted and left out; anything else fails.
             relap = np.abs(gpu2["approx_cost"] - cpu2["approx_cost"]) / np.maximum(1.0, np.abs(cpu2["approx_cost"]))
@@ -268,7 +268,7 @@ def one_round(rng, rid, side=None):
                 ok2, ndeg = rep2["ok"], len(deg)
         nkeys = 0
         if not ok2 and not dub_h and cfg.heuristic == H_TSP_POINT_K:
-            # DESIGN.md 4.2 kind (iv): pieces of a split ribbon share an endpoint that differs in the last bit between the two sides;
+            # DESIGN.md Appendix C kind (iv): pieces of a split ribbon share an endpoint that differs in the last bit between the two sides;
             # their nearest-endpoint keys tie on one side only, the stable sort of the K-limited heuristic orders them differently,
             # another ribbon is branched on and h moves by percents.  Explained exactly when the ORACLE's heuristic on the DEVICE's own
             # child ribbons and end pose is the device's h bit for bit; such edges are counted and their h, f left out.

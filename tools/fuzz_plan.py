@@ -12,7 +12,7 @@ Verdict per plan() call:
             differs, and somewhere upstream the two sides disagree in the last digits of a curve — the reference's own
             `distance - 1e-5` retry (DubinsWrapper.cpp:39-42) fired on one side only, or two Dubins words of exactly equal length
             were told apart by the last bit of libm, or the Dubins problem itself is degenerate (collinear poses, a word on the
-            edge of existing: the glibc solver returns the host's curve when its input is moved by 1e-11; DESIGN.md 4.2) — after
+            edge of existing: the glibc solver returns the host's curve when its input is moved by 1e-11; DESIGN.md Appendix C) — after
             which vertices of (near-)equal f pop in another order;
   MISMATCH  anything else (a failed check is named).
 usage: tools/fuzz_plan.py [rounds] [seed] [round ...]     (tests/test_gpu_fuzz_plan.py runs the same rounds inside the suite)"""
@@ -71,7 +71,7 @@ def degenerate_dubins(h, o):
     The target is read off the oracle's curve (its end pose); the problem is solved again (oracle's solver, glibc) with source
     and target moved by 1e-13 .. 1e-11 in heading and position.  If some such perturbation returns the HOST's curve (same word,
     length within 1e-6) the choice between the two is decided below the accuracy of any libm: two words on the edge of
-    existing, or angles of +-1e-16 that `mod2pi` turns into 0 or a full turn (DESIGN.md 4.2, kinds i and ii)."""
+    existing, or angles of +-1e-16 that `mod2pi` turns into 0 or a full turn (DESIGN.md Appendix C, kinds i and ii)."""
     rho = float(o[9])
     if float(h[9]) != rho:
         return False
@@ -88,7 +88,7 @@ def degenerate_dubins(h, o):
 
 def full_turns_apart(h, o):
     """The same word with the same parameters up to whole turns of an arc: an angle of +-1e-16 that `mod2pi` made 0 on one side
-    and 2 pi on the other (collinear poses; DESIGN.md 4.2 kind ii)."""
+    and 2 pi on the other (collinear poses; DESIGN.md Appendix C kind ii)."""
     if h[8] != o[8] or h[9] != o[9]:
         return False
     for i in range(3):
@@ -152,7 +152,7 @@ def classify_tie(H, O, same_length=True):
             retry = True                                    # same edge, last digits differ: a parent's end pose moved by <= 1e-5 m
         elif np.any(h != o):
             lastbit = True                                  # same edge to the last bit or two: h from child ribbons that carry the
-                                                            # sweeps' own rounding (corridor runs, per-step sincos: DESIGN.md 4.2)
+                                                            # sweeps' own rounding (corridor runs, per-step sincos: DESIGN.md Appendix C)
     if not (word_tie or retry or degenerate or lastbit):
         return False, "no upstream difference explains the other plan: the push / pop order itself differs"
     return True, " + ".join(x for x, on in (("equal-length Dubins words", word_tie), ("one-sided 1e-5 retry upstream", retry),
