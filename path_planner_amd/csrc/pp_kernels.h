@@ -493,7 +493,7 @@ struct PPTrackSummary {
     int limit;      // steps [0, limit) can execute: the first blocked step, or the first step at/after the edge's end time
     int blocked;    // 1: step `limit` exists and is blocked (Edge.cpp:144-147); 2: sampling step 0 threw (limit = 0, :126-133)
     int dub_err;    // some sampled arc length fell outside the curve even after the reference's 1e-5 retry
-    int pad;
+    int hits;       // -DPP_SUMMARY_HITS only (measured, not taken: DESIGN.md Appendix B): boxes hit, summed over steps [0, limit); else 0
 };
 
 // DubinsWrapper::sample (DubinsWrapper.cpp:29-49) -> dubins_path_sample for the 64 steps of one window, one step per lane:
@@ -595,6 +595,7 @@ __device__ __forceinline__ bool pp_chunk_clear_of(const PPObst& o, double x, dou
 #define PP_SKIP_ALL 1     // track_skip bits: the chunk is not sampled at all
 #define PP_SKIP_GRID 2    // sampled, but no pose of it can lie on a blocked cell
 #define PP_SKIP_OBST 4    // sampled, but no pose of it can lie inside an obstacle
+#define PP_SKIP_HITS 8    // with PP_SKIP_ALL: every pose of the chunk lies inside some obstacle box (the chunk's hit count is not zero)
 #define PP_PLAN_EDGES_MAX 32          // edges a workgroup of the skip planner stages at most (12.3 KB of LDS)
 template <bool GAUSSIAN, bool OBST_LDS>
 __device__ __forceinline__ void pp_plan_skips_chunk(const PPParams& p, const PPEdgeSetupBody* S, const PPObst* OB, const long long e, const int chunk) {
@@ -738,7 +739,7 @@ __device__ __forceinline__ void pp_plan_skips_chunk(const PPParams& p, const PPE
 #endif
     }
     const bool ok = okGeom && okHead && gridClear && decided;
-    *skipb = ok ? PP_SKIP_ALL : (unsigned char)((gridClear ? PP_SKIP_GRID : 0) | (obstClear ? PP_SKIP_OBST : 0));
+    *skipb = ok ? (unsigned char)(PP_SKIP_ALL | (nInside > 0 ? PP_SKIP_HITS : 0)) : (unsigned char)((gridClear ? PP_SKIP_GRID : 0) | (obstClear ? PP_SKIP_OBST : 0));
     if (ok) {
         // (the per-step counts of a skipped chunk are not stored: every step is inside the same nInside boxes, and the one reader
         // that can stop inside a skipped chunk — the cover sweep, when coverage completes there — divides the chunk's sum by 64;
@@ -808,7 +809,7 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
     const unsigned sflags = (unsigned)PP_SI32(sflags);
     const int dubType = PP_SI32(type);
     if ((sflags & (PP_SETUP_MALFORMED | PP_SETUP_COLOCATED)) || dubType < 0) {
-        if (lane == 0) { sum->limit = 0; sum->blocked = 0; sum->dub_err = 0; sum->pad = 0; }
+        if (lane == 0) { sum->limit = 0; sum->blocked = 0; sum->dub_err = 0; sum->hits = 0; }
         return;
     }
     const unsigned vi = (unsigned)PP_SI32(vi);
@@ -824,7 +825,7 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
         // catches it, marks the edge infeasible and stops without counting the step (Edge.cpp:126-133)
         const double t0 = pp_const_f64(tg)[0];
         if (t0 < endTime && t0 < wStart) {
-            if (lane == 0) { sum->limit = 0; sum->blocked = 2; sum->dub_err = 0; sum->pad = 0; }
+            if (lane == 0) { sum->limit = 0; sum->blocked = 2; sum->dub_err = 0; sum->hits = 0; }
             return;
         }
     }
@@ -842,6 +843,8 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
     double carryHeading = srcH;                                       // `lastHeading`, Edge.cpp:96
     bool dubErr = false;
     int limit = 0, blocked = 0;
+    int totalHits;                                                    // wave-uniform, but kept in a VECTOR register: the loop below has no scalar
+    asm volatile("v_mov_b32 %0, 0" : "=v"(totalHits));                // register to spare (every one more is a v_readlane / v_writelane pair per use)
     // Can any obstacle come near this edge at all?  Every sampled pose lies within `travel` (arc length from the start of
     // the curve) of the curve's first point, and an obstacle moves at most |Speed| * duration during the sweep: the same
     // kind of exact bound as the per-chunk culling, applied once.
@@ -890,7 +893,8 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
 #else
         const unsigned long long gclear = 0ull, oclear = 0ull;
 #endif
-        for (int ci = 0; ci < PP_WAVE; ci++) {
+        int ci = 0;
+        for (; ci < PP_WAVE; ci++) {
             const int base = (g0 + ci) * PP_WAVE;
 #ifdef PP_DBG_TRACE
             if (pp_edge_position(p, p.e_base + (e - p.ws_base)) == (long long)(PP_DBG_TRACE) && lane == 0 && base < 400)
@@ -969,6 +973,9 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
                 // per-step counts are only ever read for a chunk whose sum is not zero
                 chunkHits = pp_wave_sum_i(lane < nlim ? hits : 0);
                 thits[k] = (unsigned short)(hits > 65535 ? 65535 : hits);
+#ifdef PP_SUMMARY_HITS
+                totalHits += chunkHits;
+#endif
             }
             if (gaussian) {
                 double chunkPen = 0;
@@ -987,9 +994,21 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
             if (nvalid < PP_WAVE) { limit = base + nvalid; stop = true; break; }
             limit = base + PP_WAVE;
         }
+        // skipped chunks the sweep passed whose every pose lies inside some box: the planner's count, 64 per box (rare; kept out of
+        // the per-chunk path above, which runs 3.5 million times per launch)
+#ifdef PP_SUMMARY_HITS
+        // (the skip bytes are read again rather than kept across the loop: the loop has no scalar register to spare)
+        const unsigned sb2 = (skipb && g0 + lane < p.nch) ? (unsigned)skipb[g0 + lane] : 0u;
+        unsigned long long hm = __ballot((sb2 & (PP_SKIP_ALL | PP_SKIP_HITS)) == (PP_SKIP_ALL | PP_SKIP_HITS)) & ((ci >= PP_WAVE) ? ~0ull : ((1ull << ci) - 1ull));
+        while (hm) {
+            const int cj = __ffsll((long long)hm) - 1;
+            hm &= hm - 1;
+            totalHits += (int)pp_const_i32(tch + (g0 + cj))[0];
+        }
+#endif
     }
     const int anyErr = (__ballot(dubErr) != 0ull) ? 1 : 0;
-    if (lane == 0) { sum->limit = limit; sum->blocked = blocked; sum->dub_err = anyErr; sum->pad = 0; }
+    if (lane == 0) { sum->limit = limit; sum->blocked = blocked; sum->dub_err = anyErr; sum->hits = totalHits; }
 }
 
 // How many steps pass before the next coverage event: the loop of Edge.cpp:153-154 subtracts the increment from toCoverDistance
@@ -1047,8 +1066,11 @@ __device__ __forceinline__ void pp_lane_pose(const PPEdgeSetupBody* S, double t,
     y = uy * rho + qy;
 }
 // -> true: the edge's record and child ribbons are written.  false: nothing was written, the wave does the edge.
+// `stage` = this lane's 16 doubles of LDS (stride PP_REC_STRIDE): the record goes there, and the wave then stores the records of its
+// lanes together, 4 records of 128 contiguous bytes per store instruction instead of 64 different lines per field.
+#define PP_REC_STRIDE 17
 __device__ __forceinline__ bool pp_finish_quiet_edge(const PPParams& p, const PPEdgeSetupBody* S, const ppgpu_vertex* V, long long e, long long eg,
-                                                     int limit, int lastEv, const double* rp, const double* tg) {
+                                                     int limit, int lastEv, const double* rp, const double* tg, double* stage) {
     const int nrib = V->ribbon_count;                                       // > 0, no piece short enough to be erased
     const PPTrackSummary* sum = p.track_summary + e;
     if (sum->dub_err) return false;
@@ -1103,6 +1125,11 @@ __device__ __forceinline__ bool pp_finish_quiet_edge(const PPParams& p, const PP
         if (inBox) return false;
     }
     int hitsTotal = 0;
+#ifdef PP_SUMMARY_HITS
+    if (p.n_obst > 0 && hexec == limit) {
+        hitsTotal = sum->hits;                                              // every step below `limit` ran: the pose sweep's own total
+    } else
+#endif
     if (p.n_obst > 0) {
         const unsigned* tch = p.track_chunk_hits + (size_t)e * p.nch;
         const int cfull = hexec >> 6;
@@ -1137,8 +1164,7 @@ __device__ __forceinline__ bool pp_finish_quiet_edge(const PPParams& p, const PP
         }
         h = fmax(sumLength + mn, mx) / p.max_speed * p.tpf;
     }
-    ppgpu_edge_result* rec = p.out + eg;
-    double* r = reinterpret_cast<double*>(rec);
+    double* r = stage;
     const unsigned info = (unsigned)(S->type & 0xff) | ((unsigned)(nrib & 0xff) << 8) | ((unsigned)(steps & 0xffff) << 16);
     r[0] = __hiloint2double((int)info, (int)flags);
     r[1] = trueCost; r[2] = penalty; r[3] = S->approx;
@@ -1162,6 +1188,7 @@ __device__ __forceinline__ bool pp_finish_quiet_edge(const PPParams& p, const PP
 #define PP_APPROACH_MAX_EVENTS 0     // > 0: a lane hands its edge to the wave after this many approach events (bounds the kernel's tail)
 #endif
 __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp_k_approach_events(PPParams p) {
+    __shared__ double s_rec[PP_APPROACH_THREADS * PP_REC_STRIDE];      // quiet edges' records, transposed through LDS (34 KB: four workgroups per CU still fit)
     const long long e0 = (long long)blockIdx.x * PP_APPROACH_THREADS;
     const long long e = e0 + threadIdx.x;
     const bool valid = e < p.n_edges;
@@ -1247,7 +1274,7 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
             out.x = k; out.y = lastEv;
 #ifndef PP_NO_QUIET_FINISH
             if (!handOver && k >= limit && p.quiet_finish &&
-                pp_finish_quiet_edge(p, S, V, p.ws_base + e, pp_edge_position(p, p.e_base + e), limit, lastEv, rp, tg))
+                pp_finish_quiet_edge(p, S, V, p.ws_base + e, pp_edge_position(p, p.e_base + e), limit, lastEv, rp, tg, s_rec + (size_t)threadIdx.x * PP_REC_STRIDE))
                 out.x = PP_FAR_DONE;
 #endif
 #ifdef PP_DBG_QUIET
@@ -1256,6 +1283,23 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
         }
     }
     if (valid) p.track_far[p.ws_base + e] = out;
+#ifndef PP_NO_QUIET_FINISH
+    {
+        // the records of this wave's quiet edges, from LDS: lanes 16g .. 16g+15 store the 16 doubles of record 4 it + g
+        const int lane = threadIdx.x & 63, wbase = (int)threadIdx.x - lane;
+        const unsigned long long doneMask = __ballot(valid && out.x == PP_FAR_DONE);
+        if (doneMask) {
+            pp_wave_lds_fence();
+            const long long myEg = valid ? pp_edge_position(p, p.e_base + e) : 0;
+            const int g = lane >> 4, slot = lane & 15;
+            for (int it = 0; it < 16; it++) {
+                const int src = 4 * it + g;
+                const long long egs = __shfl(myEg, src, PP_WAVE);
+                if ((doneMask >> src) & 1ull) reinterpret_cast<double*>(p.out + egs)[slot] = s_rec[(size_t)(wbase + src) * PP_REC_STRIDE + slot];
+            }
+        }
+    }
+#endif
     // the edges the cover sweep's waves still have to visit, packed (one atomic per workgroup; the order of the launch — long
     // edges first — survives up to the order in which workgroups get here)
     if (p.live_list) {
@@ -1646,6 +1690,11 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
         const unsigned short* thits = p.track_hits + (size_t)e * p.ngp;
         const int cfull = hexec >> 6;
         int acc = 0;
+#ifdef PP_SUMMARY_HITS
+        if (!GAUSSIAN && p.n_obst > 0 && hexec == limit) {
+            hitsTotal = pp_const_i32(&sum->hits)[0];                        // every step below `limit` ran: the pose sweep's own total
+        } else
+#endif
         if (p.n_obst > 0) {
             for (int c = lane; c < cfull; c += PP_WAVE) acc += (int)tch[c];
             if ((hexec & 63) != 0 && tch[cfull] != 0u && (cfull << 6) + lane < hexec) {
