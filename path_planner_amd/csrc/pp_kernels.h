@@ -1604,6 +1604,10 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
         }
     }
 
+#ifdef PP_ABL_ONLY_EVENTS
+    if (lane == 0) p.out[eg].flags = (unsigned)(nrib + lastEv + rdt + (int)cct);     // (timing experiment: keep phase B's results alive, skip the rest)
+    return;
+#endif
     // ---- where the loop of Edge.cpp:143-175 stopped
     int steps = 0;
     double ix = srcX, iy = srcY;        // `intermediate` position
