@@ -689,6 +689,16 @@ __device__ __forceinline__ void pp_plan_skips_chunk(const PPParams& p, const PPE
                 if (!pp_chunk_clear_of<true>(o, 0.5 * (xF + xL), 0.5 * (yF + yL), tM, 0.5 * Lc + dev, ht)) decided = false;
                 return;
             }
+#ifndef PP_PLAN_NO_PRETEST
+            {
+                // most boxes on an edge's list are nowhere near this chunk: every pose lies within Lc/2 + dev of the chord's midpoint,
+                // the box within its own reach of its centre, which moves at most |Speed| ht around where it is at the middle step
+                const double dtM = tM - o.Time;
+                const double ddx = 0.5 * (xF + xL) - (o.X + o.Speed * dtM * o.cosYaw), ddy = 0.5 * (yF + yL) - (o.Y + o.Speed * dtM * o.sinYaw);
+                const double R = o.reach + 0.5 * Lc + dev + fabs(o.Speed) * ht + 1e-3;
+                if (ddx * ddx + ddy * ddy > R * R) return;
+            }
+#endif
             const double dtF = tF - o.Time, dtL = tL - o.Time;
             const double txF = xF - (o.X + o.Speed * dtF * o.cosYaw), tyF = yF - (o.Y + o.Speed * dtF * o.sinYaw);
             const double txL = xL - (o.X + o.Speed * dtL * o.cosYaw), tyL = yL - (o.Y + o.Speed * dtL * o.sinYaw);
