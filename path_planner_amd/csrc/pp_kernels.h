@@ -1080,7 +1080,7 @@ __device__ __forceinline__ void pp_lane_pose(const PPEdgeSetupBody* S, double t,
 // lanes together, 4 records of 128 contiguous bytes per store instruction instead of 64 different lines per field.
 #define PP_REC_STRIDE 17
 __device__ __forceinline__ bool pp_finish_quiet_edge(const PPParams& p, const PPEdgeSetupBody* S, const ppgpu_vertex* V, long long e, long long eg,
-                                                     int limit, int lastEv, const double* rp, const double* tg, double* stage) {
+                                                     int limit, int lastEv, const double* rp, const double* tg, double* stage, bool rpUniform) {
     const int nrib = V->ribbon_count;                                       // > 0, no piece short enough to be erased
     const PPTrackSummary* sum = p.track_summary + e;
     if (sum->dub_err) return false;
@@ -1128,6 +1128,13 @@ __device__ __forceinline__ bool pp_finish_quiet_edge(const PPParams& p, const PP
     if (cov || coverFinal) {                                                // the last cover (:182-191): only if it cannot touch a ribbon
         const double grow = p.ribw + 1e-3;
         bool inBox = false;
+        if (rpUniform) {                                                    // one vertex for the whole wave: its ribbons through scalar loads
+            const PP_AS4 double* ru = pp_const_f64(rp);
+            for (int i = 0; i < nrib; i++) {
+                const double sx = ru[4 * i], sy = ru[4 * i + 1], ex = ru[4 * i + 2], ey = ru[4 * i + 3];
+                inBox |= (ix >= fmin(sx, ex) - grow) & (ix <= fmax(sx, ex) + grow) & (iy >= fmin(sy, ey) - grow) & (iy <= fmax(sy, ey) + grow);
+            }
+        } else
         for (int i = 0; i < nrib; i++) {
             const double sx = rp[4 * i], sy = rp[4 * i + 1], ex = rp[4 * i + 2], ey = rp[4 * i + 3];
             inBox |= (ix >= fmin(sx, ex) - grow) & (ix <= fmax(sx, ex) + grow) & (iy >= fmin(sy, ey) - grow) & (iy <= fmax(sy, ey) + grow);
@@ -1182,7 +1189,12 @@ __device__ __forceinline__ bool pp_finish_quiet_edge(const PPParams& p, const PP
     r[9] = g; r[10] = h; r[11] = (h == PP_H_DEFERRED) ? g : g + h;
     r[12] = V->coverage_completed_time; r[13] = S->p0; r[14] = S->p1; r[15] = S->p2;
     double* c = p.child + (size_t)eg * p.stride * 4;
-    for (int i = 0; i < 4 * nrib; i++) c[i] = rp[i];
+    if (rpUniform) {
+        const PP_AS4 double* ru = pp_const_f64(rp);
+        for (int i = 0; i < 4 * nrib; i++) c[i] = ru[i];
+    } else {
+        for (int i = 0; i < 4 * nrib; i++) c[i] = rp[i];
+    }
     return true;
 }
 #ifndef PP_APPROACH_MIN_WAVES
@@ -1229,6 +1241,12 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
     int2 out; out.x = 0; out.y = -1;
     const unsigned sflags = S->sflags;
     const int dubType = S->type;
+    // do all lanes of this wave start from the same open vertex?
+    const unsigned viMine = S->vi;
+    const unsigned viFirst = (unsigned)__builtin_amdgcn_readfirstlane((int)viMine);
+    const bool oneVertex = viFirst < (unsigned)p.nverts && __ballot(valid && viMine != viFirst) == 0ull;
+    const double* rpU = p.ribbons + 4 * (size_t)pp_const_i32(&p.verts[oneVertex ? viFirst : 0].ribbon_offset)[0];
+    const int nribU = pp_const_i32(&p.verts[oneVertex ? viFirst : 0].ribbon_count)[0];
     if (valid && !(sflags & (PP_SETUP_MALFORMED | PP_SETUP_COLOCATED)) && dubType >= 0) {
         const ppgpu_vertex* V = p.verts + S->vi;
         const int nrib = V->ribbon_count;
@@ -1241,6 +1259,10 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
             const double endTime0 = fmin(p.horizon + 1e-12 + p.sst, S->wEnd);
             const double w = p.ribw, grow = w + 1e-3, minLength0 = 2 * w;
             bool tiny = false;
+            if (oneVertex) {
+                const PP_AS4 double* ru = pp_const_f64(rpU);
+                for (int i = 0; i < nribU; i++) tiny |= pp_sq_len(ru[4 * i], ru[4 * i + 1], ru[4 * i + 2], ru[4 * i + 3]) < minLength0 * minLength0 / (2.0 * 2.0);
+            } else
             for (int i = 0; i < nrib; i++) tiny |= pp_sq_len(rp[4 * i], rp[4 * i + 1], rp[4 * i + 2], rp[4 * i + 3]) < minLength0 * minLength0 / (2.0 * 2.0);
             int k = 0, lastEv = -1;
             bool handOver = tiny;               // the wave has events to visit (or an error to flag)
@@ -1266,6 +1288,20 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
                 const double x = ux * rho + qx, y = uy * rho + qy;
                 bool inBox = false;
                 double q = PP_DBL_MAX;
+#ifndef PP_APPROACH_NO_UNIFORM_RIBBONS
+                if (oneVertex) {
+                    // every lane of the wave starts from the same vertex (a dense launch from one open vertex): its ribbons come through
+                    // scalar loads instead of twenty vector loads per event
+                    const PP_AS4 double* ru = pp_const_f64(rpU);
+                    for (int i = 0; i < nribU; i++) {
+                        const double sx = ru[4 * i], sy = ru[4 * i + 1], ex = ru[4 * i + 2], ey = ru[4 * i + 3];
+                        inBox |= (x >= fmin(sx, ex) - grow) & (x <= fmax(sx, ex) + grow) & (y >= fmin(sy, ey) - grow) & (y <= fmax(sy, ey) + grow);
+                        const double qS = (sx - x) * (sx - x) + (sy - y) * (sy - y);
+                        const double qE = (ex - x) * (ex - x) + (ey - y) * (ey - y);
+                        q = fmin(q, fmin(qE, qS));
+                    }
+                } else
+#endif
                 for (int i = 0; i < nrib; i++) {
                     const double sx = rp[4 * i], sy = rp[4 * i + 1], ex = rp[4 * i + 2], ey = rp[4 * i + 3];
                     inBox |= (x >= fmin(sx, ex) - grow) & (x <= fmax(sx, ex) + grow) & (y >= fmin(sy, ey) - grow) & (y <= fmax(sy, ey) + grow);
@@ -1284,7 +1320,7 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
             out.x = k; out.y = lastEv;
 #ifndef PP_NO_QUIET_FINISH
             if (!handOver && k >= limit && p.quiet_finish &&
-                pp_finish_quiet_edge(p, S, V, p.ws_base + e, pp_edge_position(p, p.e_base + e), limit, lastEv, rp, tg, s_rec + (size_t)threadIdx.x * PP_REC_STRIDE))
+                pp_finish_quiet_edge(p, S, V, p.ws_base + e, pp_edge_position(p, p.e_base + e), limit, lastEv, oneVertex ? rpU : rp, tg, s_rec + (size_t)threadIdx.x * PP_REC_STRIDE, oneVertex))
                 out.x = PP_FAR_DONE;
 #endif
 #ifdef PP_DBG_QUIET
