@@ -86,6 +86,8 @@ struct ppgpu_ctx {
     // sampler (StateGenerator) state
     PPSamplerState sampler{};
     DevBuf<double> samp_ribbons;
+    unsigned long long* pinned_counts = nullptr;   // 64 bytes of pinned host memory for the sampler's count read-backs
+    std::vector<double> samp_ribbons_host;   // what samp_ribbons holds (ppgpu_sampler_init skips the upload of an unchanged table)
     DevBuf<unsigned char> s_bytes;      // scan / compaction scratch
     DevBuf<unsigned long long> s_u64;
     DevBuf<unsigned> s_u32a, s_u32b;
@@ -165,6 +167,7 @@ int ppgpu_create(int device, ppgpu_ctx** out) {
     c->n_cu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    HIP_TRY(hipHostMalloc((void**)&c->pinned_counts, 64, hipHostMallocDefault));
     if (const char* pm = std::getenv("PPGPU_PREPASS_MIN_EDGES")) c->prepass_min_edges = std::atoll(pm);
     if (const char* lh = std::getenv("PPGPU_LANE_HEURISTIC")) c->lane_heuristic = std::atoi(lh) != 0;
     if (const char* qf = std::getenv("PPGPU_QUIET_FINISH")) c->quiet_finish = std::atoi(qf) != 0;
@@ -190,6 +193,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     c->setup.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
     c->track_summary.release(); c->track_far.release(); c->track_skip.release(); c->track_carry.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->defer_list.release(); c->live_list.release(); c->work.release(); c->dstage_in.release(); c->dstage_out.release();
+    if (c->pinned_counts) (void)hipHostFree(c->pinned_counts);
     if (c->stage_in) (void)hipHostFree(c->stage_in);
     if (c->stage_out) (void)hipHostFree(c->stage_out);
     for (int r = 0; r < PP_TIMING_RING; r++) for (int i = 0; i < 6; i++) if (c->ev_ring[r][i]) (void)hipEventDestroy(c->ev_ring[r][i]);
@@ -523,9 +527,16 @@ int ppgpu_sampler_init(ppgpu_ctx* c, const double* b6, uint64_t seed, int32_t n_
     s.pos = 0;
     s.initialised = 1;
     if (n_ribbons > 0) {
-        if ((rc = c->samp_ribbons.reserve((size_t)n_ribbons * 4, false, c->stream))) return rc;
-        HIP_TRY(hipMemcpyAsync(c->samp_ribbons.p, hr, (size_t)n_ribbons * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        // the generator of every iteration of a plan() call is built from the same ribbon manager (AStarPlanner.cpp:34): the table is
+        // uploaded (one host round trip) only when it differs from the one already on the device
+        const size_t nd = (size_t)n_ribbons * 4;
+        if (c->samp_ribbons_host.size() != nd || std::memcmp(c->samp_ribbons_host.data(), hr, nd * sizeof(double)) != 0) {
+            if ((rc = c->samp_ribbons.reserve(nd, false, c->stream))) return rc;
+            c->samp_ribbons_host.clear();             // not valid until the copy below is known to have happened
+            HIP_TRY(hipMemcpyAsync(c->samp_ribbons.p, hr, nd * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->samp_ribbons_host.assign(hr, hr + nd);
+        }
     }
     c->n_samples = 0;
     c->n_extra = 0;
@@ -622,9 +633,11 @@ int ppgpu_sampler_add(ppgpu_ctx* c, int64_t n_attempts, int64_t* n_total_out) {
     hipLaunchKernelGGL(pp_k_compact_samples, dim3(nblk_n), dim3(256), 0, st, keep, n, blk32, c->s_cand.p, c->sx.p, c->sy.p,
                        c->sh.p, c->n_samples, d_total);
     HIP_TRY(hipGetLastError());
-    unsigned long long h2[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(&h2[0], d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&h2[1], d_end, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    // the two counts come back through pinned memory (a copy to pageable memory waits for the stream by itself, once per copy)
+    volatile unsigned long long* h2 = c->pinned_counts;
+    h2[0] = 0; h2[1] = 0;
+    HIP_TRY(hipMemcpyAsync((void*)&h2[0], d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync((void*)&h2[1], d_end, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (s.on_ribbons && h2[1] == 0) return fail(PPGPU_EHIP, "sampler: chain scan did not reach the end of the batch");
     s.pos = s.on_ribbons ? (s.pos + h2[1]) : (s.pos + 4ull * (unsigned long long)n);   // slots consumed so far
