@@ -131,9 +131,17 @@ def run_rank(args):
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     rccl_ranks = None
+    # PP_BENCH_FORCE_COMM=1 (developer aid): take the N > 1 path — torch's NCCL group, the unique-id broadcast, the library's own
+    # communicator and one ppgpu_allreduce_best per step — with a world of one, which is all a one-GPU box can form
+    use_comm = (world > 1 or os.environ.get("PP_BENCH_FORCE_COMM") == "1") and not rehearsal
+    if use_comm and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if rehearsal:
         dist.init_process_group("gloo")
-    elif world > 1:
+    elif use_comm:
         # torch's process group carries the barrier and the max-over-ranks of the timing contract; the data path's one
         # collective per step goes through the product's own communicator (ppgpu_comm_* / ppgpu_allreduce_best)
         dist.init_process_group("nccl", device_id=dev)
@@ -181,12 +189,12 @@ def run_rank(args):
             d_all = torch.cat(allk).to(dev)
             ctx.key_min(world, d_all.data_ptr(), d_key2.data_ptr())
             ctx.synchronize()
-        elif world > 1:
+        elif use_comm:
             ctx.allreduce_best(d_key2.data_ptr())     # the one collective of the iteration: 16 B per rank over xGMI + local min
         return ne
 
     def fence():
-        if world > 1:
+        if world > 1 or use_comm:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -209,7 +217,7 @@ def run_rank(args):
         kernel_events.append(ctx.past_timing(back))
 
     tot = torch.tensor([float(edges), elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
-    if world > 1:
+    if world > 1 or use_comm:
         e_sum = tot[0:1].clone()
         t_max = tot[1:2].clone()
         dist.all_reduce(e_sum, op=dist.ReduceOp.SUM)
@@ -339,10 +347,10 @@ def run_rank(args):
         if world == 1 and args.open_vertex_run:
             out.update(open_vertex_run(ctx, w, torch, dev))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or use_comm:
         dist.barrier()
         torch.cuda.synchronize(dev)
-        if not rehearsal:
+        if use_comm:
             ctx.comm_destroy()
         dist.destroy_process_group()
 

@@ -85,3 +85,15 @@ def test_handle_owned_communicator_one_rank():
     with pytest.raises(api.PpgpuError):
         ctx.allreduce_best(key.data_ptr())                  # no communicator any more
     ctx.close()
+
+
+def test_the_multi_rank_path_with_a_world_of_one():
+    """PP_BENCH_FORCE_COMM=1: everything `--gpus N` does beyond one rank — torch's NCCL process group, the unique id made by rank 0 and
+    broadcast through it, ppgpu_comm_init_rank, one ppgpu_allreduce_best per step on the step's stream, the max-over-ranks of
+    the timing, the teardown — with the only world a one-GPU box can form.  rccl_ranks comes back from ncclCommCount."""
+    out = subprocess.run([sys.executable, BENCH, "--steps", "4", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                         env=dict(_env(), PP_BENCH_FORCE_COMM="1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1
+    assert line["value"] > 1e7 and line["workload_stats"]["best_edge"] >= 0
