@@ -918,3 +918,56 @@ def test_expand_order_with_more_candidates_than_the_list_holds(torch_cuda):
         for r in range(2):
             want = np.lexsort((np.arange(n), ln[:, r]))[:k]
             assert idx[0, r].tolist() == want.tolist(), (attempt, r)
+
+
+def test_slow_edges_crawling_along_ribbons(torch_cuda):
+    """The cover sweep's long runs (one sample every few steps once a corridor / quiet run has filled a window): slow coverage edges
+    (0.5 m/s: one centimetre per collision-check step) from a vertex standing at the start of a ribbon, heading along it, to
+    targets further along the ribbons — hundreds of consecutive steps inside one corridor, the case the long runs exist for — and the
+    same at full speed (stride 1: no long runs) from a second vertex beside a ribbon (quiet stretches).  Launched large enough to take
+    the prepass route; flags, step counts and child ribbon counts identical to the oracle, child ribbons within 1e-5."""
+    from path_planner_amd import api, workloads
+    from path_planner_amd.types import RESULT_DTYPE, VERTEX_DTYPE, edge_pack
+    from parity import compare_results
+    import oracle as orc
+    torch = torch_cuda
+    w = workloads.config3(n_samples=64)
+    rib = np.asarray(w.ribbons4, dtype=np.float64).reshape(-1, 4)
+    world = orc.World(w.cfg, w.grid, w.res, w.obst)
+    # vertex 0 at the start of ribbon 0 heading along it (+x: heading pi/2); vertex 1 one metre beside ribbon 2, same heading
+    v = np.zeros(2, dtype=VERTEX_DTYPE)
+    t0 = float(w.start5[4])
+    v[0] = (rib[0, 0] - 1.0, rib[0, 1], np.pi / 2, 2.5, t0, 0.0, -1.0, 0, len(rib))
+    v[1] = (rib[2, 0] - 1.0, rib[2, 1] + 1.0, np.pi / 2, 2.5, t0, 0.0, -1.0, 0, len(rib))
+    rng = np.random.default_rng(31)
+    n = 1500
+    which = rng.integers(0, len(rib), n)
+    u = rng.uniform(0.1, 1.0, n)
+    sx = rib[which, 0] + u * (rib[which, 2] - rib[which, 0]) + rng.normal(0, 0.05, n)
+    sy = rib[which, 1] + rng.normal(0, 0.4, n)
+    sh = np.where(rng.random(n) < 0.7, np.pi / 2, rng.uniform(0, 2 * np.pi, n)) + rng.normal(0, 0.02, n)
+    ctx = api.Context(0)
+    ctx.set_config(w.cfg); ctx.set_grid(w.grid, w.res); ctx.set_obstacles(w.obst)
+    ctx.set_vertices(v, rib); ctx.set_samples(sx, sy, sh)
+    vi = np.repeat(np.arange(2), n * 4)
+    ti = np.tile(np.repeat(np.arange(n), 4), 2)
+    cb = np.tile(np.tile(np.arange(4), n), 2)
+    edges = edge_pack(vi, ti, cb)
+    ne = len(edges)
+    assert ne >= 8192                                         # the prepass route (chunk skipping, approach events, lane heuristic)
+    d_e = torch.from_numpy(edges.view(np.int64)).to("cuda:0")
+    d_res = torch.zeros(ne * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
+    d_child = torch.zeros(ne * 12 * 4, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    ctx.cost_edges_list(ne, d_e.data_ptr(), d_res.data_ptr(), d_child.data_ptr(), 12)
+    ctx.synchronize()
+    gpu = d_res.cpu().numpy().view(RESULT_DTYPE)
+    cpu, cchild = world.cost_edges(v, rib, sx, sy, sh, edges, stride=12, threads=8)
+    rep = compare_results(gpu, cpu, d_child.cpu().numpy().reshape(ne, 12, 4), cchild)
+    print(rep)
+    assert rep["ok"], rep
+    # the case is what it claims to be: many slow coverage edges swept for hundreds of steps whose ribbons changed
+    slow_cov = (cb == 3) & ((cpu["flags"] & 1) == 0)
+    steps = cpu["info"] >> 16
+    changed = np.any(np.abs(cchild[:, :len(rib)] - rib[None, :, :]) > 1e-9, axis=(1, 2)) | (((cpu["info"] >> 8) & 0xFF) != len(rib))
+    assert np.count_nonzero(slow_cov & (steps > 600) & changed) > 200
