@@ -748,6 +748,9 @@ __device__ inline int pp_ribbons_event(PPRibbon& r, int n, double w, double x, d
         }
         return n;
     }
+    // exactly one piece split, both halves kept, nothing erased: told to the caller (adv = -4 - index of the front half; the rest
+    // follows it), which can then guess the corridor run that very likely starts at the next step
+    if (mS != 0ull && (mS & (mS - 1ull)) == 0ull && mF == mS && mR == actMask && n < 64) adv = -4 - (__ffsll((long long)mS) - 1);
     const unsigned long long below = (1ull << lane) - 1ull;
     const int posF = __popcll(mF & below) + __popcll(mR & below);
     const int posR = posF + (keepF ? 1 : 0);

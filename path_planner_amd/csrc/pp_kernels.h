@@ -1489,6 +1489,12 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
         int cont = 0, contPiece = 0;        // 1 / 2: the last window ended inside a corridor / quiet run (of piece contPiece); + 4: it was
                                             // one run from end to end (a long run is worth trying)
         bool contMoveEnd = false;
+#if !defined(PP_NO_APPROACH) && defined(PP_HANDOVER_QUIET)      // measured in round 3: 1056 -> 1063 us (the attempts that fail cost more than the events saved): off
+        // the approach kernel handed over at an event inside some ribbon's grown bounding box: nearly always inside that ribbon's
+        // corridor, where this event and the following ones change nothing until the strict corridor is reached — a quiet run is tried
+        // from the window's first step (its guarded checks decide; if the first step does not pass, the one-at-a-time code takes it)
+        if (p.track_far && nextEvent > 0) cont = 2;
+#endif
         while (!ended) {
             if (nextEvent >= limit) break;
 #ifndef PP_NO_TFAR
@@ -1545,11 +1551,31 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
             }
             const int climit = (stride == 1) ? ((limit - base) < PP_WAVE ? (limit - base) : PP_WAVE) : __popcll(__ballot(k < limit));
             bool runFailed = false, quietFailed = false;
+            bool tryQuiet = false;              // a corridor run has just ended inside this window
             while (true) {
                 const int j = nextEvent - base;
                 if (j >= climit) break;
                 const double tj = pp_readlane(t, j);
                 if (!(tj < endTime)) { ended = true; break; }         // `while (intermediate.time() < endTime)`
+#if !defined(PP_NO_CORRIDOR_RUN) && !defined(PP_NO_QUIET_RUN) && defined(PP_RUN_THEN_QUIET)   // measured in round 3: 1057 -> 1123 us (one more inlined run in a kernel whose code already fills the instruction cache): off
+                if (tryQuiet) {
+                    // the step a corridor run stopped at: very often the vehicle has left the piece's strict corridor sideways and
+                    // travels on inside its outer corridor — events that change nothing.  The quiet run's guarded checks decide from
+                    // this very step on; if it does not pass them, the one-at-a-time code below takes it as before.
+                    tryQuiet = false;
+                    if (stride == 1 && nrib > 0 && j + 1 < climit && !quietFailed) {
+                        const int L = pp_quiet_run(rib, nrib, w, q.x, q.y, (lane < climit) & (t < endTime), coverMask, j, runSpan);
+                        PP_CNT(dbgQuiet++; dbgQuietLen += L);
+                        PP_TRACE("[wave]   quiet run tried where the corridor run ended, from %d: L %d\n", base + j, L);
+                        if (L > 0) {
+                            lastEv = base + j + L - 1;
+                            nextEvent = lastEv + 1;
+                            if (j + L >= climit) cont = 2 | 4;
+                            continue;
+                        }
+                    }
+                }
+#endif
 #ifndef PP_NO_CORRIDOR_RUN
                 if (j == 0 && (cont & 3) != 0) {
                     // the previous window ended inside a run: this step is an event of the same kind, very likely the whole
@@ -1584,6 +1610,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                     }
                     if (L > 0) {
                         cont = (L < climit) ? 0 : (kind | 4);  // ended inside the window: something else happens next / filled it: a long run next
+                        tryQuiet = (kind == 1) && (L < climit);
                         continue;
                     }
                     cont = 0;
@@ -1599,6 +1626,20 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                 if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF | PPGPU_F_RIBBON_LOST; }
 
 #ifndef PP_NO_CORRIDOR_RUN
+                bool guessed = false;
+#ifndef PP_NO_SPLIT_GUESS
+                if (adv <= -4 && j + 1 < climit && !runFailed && nrib <= PP_WAVE) {
+                    // this event split one piece in two (the vehicle has just entered its strict corridor): the next step will move the
+                    // inner endpoint of the half the vehicle travels into — guess which from the direction of travel and try the run
+                    // at once instead of learning it from one more one-at-a-time event (the run's own checks decide: a wrong guess
+                    // gives L = 0 and costs one attempt)
+                    const int front = -4 - adv;
+                    const double dxp = pp_readlane(rib.ex, front + 1) - pp_readlane(rib.sx, front), dyp = pp_readlane(rib.ey, front + 1) - pp_readlane(rib.sy, front);
+                    const bool towardsEnd = ((pp_readlane(q.x, j + 1) - xj) * dxp + (pp_readlane(q.y, j + 1) - yj) * dyp) > 0.0;
+                    adv = towardsEnd ? (front + 1) : (front | 0x100);
+                    guessed = true;
+                }
+#endif
                 if (adv >= 0 && j + 1 < climit && !runFailed) {
                     // this event only moved one piece's endpoint: the following steps very likely do the same
                     double nsx, nsy;
@@ -1606,7 +1647,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                     const int piece = adv & 0xff;
                     const int L = pp_corridor_run(rib, nrib, w, piece, moveEnd, q.x, q.y, (lane < climit) & (t < endTime), coverMask, j + 1, runSpan, nsx, nsy);
                     PP_CNT(dbgCorr++; dbgCorrLen += L);
-                    runFailed = (L == 0);                  // do not keep paying for attempts that do not start
+                    runFailed = (L == 0) && !guessed;      // do not keep paying for attempts that do not start
                     PP_TRACE("[wave]   corridor run from %d: L %d\n", base + j + 1, L);
                     if (L > 0) {
                         if (lane == piece) {
@@ -1615,6 +1656,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                         lastEv = base + j + L;
                         nextEvent = base + j + L + 1;      // inside the corridor minDistanceFrom is 0: the next step is an event too
                         if (j + L + 1 >= climit) { cont = 1 | 4; contPiece = piece; contMoveEnd = moveEnd; }   // cut by the window, not by a guard
+                        else tryQuiet = true;
                         continue;
                     }
                 }
@@ -2087,7 +2129,44 @@ __global__ __launch_bounds__(PP_H_WPB * 64) void pp_k_heuristic_big(PPParams p) 
 #endif
 #define PP_HL_TRI (PP_HL_MAX_N * (2 * PP_HL_MAX_N - 1) + 1)     // doubles per edge: pairs of 2n endpoints (+1: odd stride)
 #define PP_HL_PTS (4 * PP_HL_MAX_N + 1)
-struct PPLaneTsp { const double* T; double twoW; int K; bool sortK; };
+struct PPLaneTsp { const double* T; const double* CB; double twoW; int K; bool sortK; unsigned* cnt; };
+// Branch and bound (round 3), exact.  Whatever order the remaining ribbons are visited in, the tour still has to add, for every
+// one of them, its length - 2w and a transition INTO one of its endpoints from an endpoint of another ribbon, which is at least
+// mind[r] = the smallest such distance in the edge's triangle; the fmax(., 0) clamps only raise a sum.  So every leaf below a node
+// is at least sf + rb with rb = the sum of CB[r] = len[r] - 2w + mind[r] over the node's remaining ribbons (real arithmetic; the
+// rounding of at most 3 x 6 additions of values below 1e6 is below 1e-8).  A subtree whose bound exceeds the best tour the edge
+// has seen so far (`gbest`, shared by the edge's lanes) by more than PP_HL_MARGIN cannot hold the minimum and is not walked —
+// when that is so for EVERY lane of the wave (control flow stays uniform: one ballot per node).  The minimum over the leaves that
+// are visited is the minimum over all leaves: the same bits.  The K ribbons branched on are taken last-first (the nearer of the K
+// farthest first: finds short tours, hence a tight gbest, earlier; a minimum does not depend on the order).
+#ifndef PP_HL_MARGIN
+#define PP_HL_MARGIN 1e-6
+#endif
+#ifndef PP_HL_PRUNE_MIN_REM
+#define PP_HL_PRUNE_MIN_REM 2        // nodes with at least this many ribbons left are tested
+#endif
+#ifndef PP_HL_NO_PRUNE
+#define PP_HL_PRUNE 1
+#else
+#define PP_HL_PRUNE 0
+#endif
+__device__ __forceinline__ double pp_quad_min(double v) {           // over the PP_HL_SPLIT adjacent lanes of an edge
+#pragma unroll
+    for (int m = 1; m < PP_HL_SPLIT; m <<= 1) v = fmin(v, __shfl_xor(v, m));
+    return v;
+}
+#ifndef PP_HL_SHARE_MIN_REM
+#define PP_HL_SHARE_MIN_REM 3        // nodes with at least this many ribbons left first take the best tour of the edge's other lanes (2: 160 us, 3: 153)
+#endif
+template <int REM>
+__device__ __forceinline__ bool pp_lane_tsp_pruned(double sf, double rb, double& gbest) {
+#if PP_HL_PRUNE
+    if constexpr (REM >= PP_HL_SHARE_MIN_REM) gbest = pp_quad_min(gbest);
+    return __ballot(!(sf + rb > gbest + PP_HL_MARGIN)) == 0ull;
+#else
+    return false;
+#endif
+}
 __device__ __forceinline__ int pp_tri(int a, int b) {            // endpoints 0 .. 2n-1 (start / end of ribbon i = 2i / 2i + 1), a != b
     const int lo = a < b ? a : b, hi = a < b ? b : a;
     return ((hi * (hi - 1)) >> 1) + lo;
@@ -2145,12 +2224,18 @@ __device__ __forceinline__ double pp_lane_tsp_last2(const PPLaneTsp& c, double s
     return fmin(fmin(m0, m1), fmin(m2, m3));
 }
 template <int REM>
-__device__ __forceinline__ double pp_lane_tsp(const PPLaneTsp& c, double sf, unsigned ord, int pt) {
+__device__ __forceinline__ double pp_lane_tsp(const PPLaneTsp& c, double sf, unsigned ord, int pt, double rb, double& gbest) {
     if constexpr (REM == 0) {
         return sf;
     } else {
+        if constexpr (REM >= PP_HL_PRUNE_MIN_REM) {
+            if (pp_lane_tsp_pruned<REM>(sf, rb, gbest)) return PP_DBL_MAX;
+        }
         if constexpr (REM == 2) {
-            if (c.K >= 2) return pp_lane_tsp_last2(c, sf, ord, pt);
+#ifdef PP_HL_COUNT
+            if (pp_lane() == 0) atomicAdd(c.cnt, 1u);
+#endif
+            if (c.K >= 2) { const double v = pp_lane_tsp_last2(c, sf, ord, pt); gbest = fmin(gbest, v); return v; }
         }
         unsigned srt = ord;
         if (REM > 1 && c.sortK && REM > c.K) {               // with K >= REM every ribbon is branched on: their order is immaterial
@@ -2166,7 +2251,7 @@ __device__ __forceinline__ double pp_lane_tsp(const PPLaneTsp& c, double sf, uns
         }
         const int nb = REM < c.K ? REM : c.K;                 // ribbons branched on, each entered from both ends
         double best = PP_DBL_MAX;
-        for (int cc = 0; cc < nb; cc++) {
+        for (int cc = nb - 1; cc >= 0; cc--) {
             const int rid = (int)((srt >> (4 * cc)) & 0xfu);
             const double len = c.T[rid * (2 * rid + 1) + 2 * rid];         // = pp_tri(2 rid, 2 rid + 1)
             const double base = sf + len - c.twoW;
@@ -2178,11 +2263,13 @@ __device__ __forceinline__ double pp_lane_tsp(const PPLaneTsp& c, double sf, uns
                 best = fmin(best, fmin(fromStart, fromEnd));
             } else {
                 const unsigned nord = pp_lane_tsp_drop(srt, cc);
+                const double nrb = PP_HL_PRUNE ? rb - c.CB[rid] : 0.0;
 #pragma unroll 1
                 for (int dir = 0; dir < 2; dir++)
-                    best = fmin(best, pp_lane_tsp<REM - 1>(c, dir == 0 ? fromStart : fromEnd, nord, 2 * rid + 1 - dir));
+                    best = fmin(best, pp_lane_tsp<REM - 1>(c, dir == 0 ? fromStart : fromEnd, nord, 2 * rid + 1 - dir, nrb, gbest));
             }
         }
+        if constexpr (REM == 1) gbest = fmin(gbest, best);
         return best;
     }
 }
@@ -2200,7 +2287,9 @@ __device__ __forceinline__ double pp_lane_tsp_root(const PPLaneTsp& c, const dou
         srt = pp_lane_tsp_order<N>(key, srt);
     }
     const int b = 2 * (N < c.K ? N : c.K);
-    double best = PP_DBL_MAX;
+    double best = PP_DBL_MAX, gbest = PP_DBL_MAX, rbAll = 0;
+#pragma unroll
+    for (int r = 0; r < N; r++) rbAll += PP_HL_PRUNE ? c.CB[r] : 0.0;
     for (int u0 = 0; u0 < b; u0 += PP_HL_SPLIT) {
         const bool act = u0 + sub < b;
         const int u = act ? u0 + sub : 0;
@@ -2213,7 +2302,8 @@ __device__ __forceinline__ double pp_lane_tsp_root(const PPLaneTsp& c, const dou
         for (int j = 1; j < 2 * N; j++) dd = (qi == j) ? d0[j] : dd;
         const double nsf = fmax(0.0 + len - c.twoW + dd, 0);
         double v = nsf;
-        if constexpr (N > 1) v = pp_lane_tsp<N - 1>(c, nsf, pp_lane_tsp_drop(srt, cc), 2 * rid + 1 - dir);
+        // (a lane past the last branch repeats branch 0: its gbest is a tour of this edge too)
+        if constexpr (N > 1) v = pp_lane_tsp<N - 1>(c, nsf, pp_lane_tsp_drop(srt, cc), 2 * rid + 1 - dir, PP_HL_PRUNE ? rbAll - c.CB[rid] : 0.0, gbest);
         if (act) best = fmin(best, v);
     }
 #pragma unroll
@@ -2265,21 +2355,27 @@ __global__ __launch_bounds__(256) void pp_k_deferred_list(PPParams p) {
 #define PP_HL_THREADS 64
 #endif
 // (occupancy is set by LDS: 11.8 KB per 16 edges, 13 waves per CU)
-__global__ __launch_bounds__(PP_HL_THREADS) void pp_k_heuristic_lanes(PPParams p) {
+#ifndef PP_HL_MIN_WAVES
+#define PP_HL_MIN_WAVES 3
+#endif
+__global__ __launch_bounds__(PP_HL_THREADS, PP_HL_MIN_WAVES) void pp_k_heuristic_lanes(PPParams p) {
     constexpr int PER = PP_HL_THREADS / PP_HL_SPLIT;              // edges per workgroup
     __shared__ double Tall[PER * PP_HL_TRI];
     __shared__ double Pall[PER * PP_HL_PTS];
+    __shared__ double CBall[PER * PP_HL_MAX_N];
     const int tid = threadIdx.x;
     // which list this workgroup serves: the lists follow one another in whole workgroups
+    // (longest lists first: an edge with 6 ribbons takes four times as long as one with 5, and the workgroups dispatched last
+    // decide how the kernel drains)
     unsigned blk = blockIdx.x, count = 0;
-    int n = 1;
-    for (; n <= PP_HL_MAX_N; n++) {
+    int n = PP_HL_MAX_N;
+    for (; n >= 1; n--) {
         count = (unsigned)pp_const_i32(p.defer_count + n)[0];
         const unsigned nblk = (count + (unsigned)PER - 1u) / (unsigned)PER;
         if (blk < nblk) break;
         blk -= nblk;
     }
-    if (n > PP_HL_MAX_N) return;                                  // the grid is sized for "every edge deferred"
+    if (n < 1) return;                                            // the grid is sized for "every edge deferred"
     const unsigned slot = blk * (unsigned)PER + (unsigned)tid / PP_HL_SPLIT;
     const int sub = tid & (PP_HL_SPLIT - 1);
     const bool have = slot < count;
@@ -2299,9 +2395,23 @@ __global__ __launch_bounds__(PP_HL_THREADS) void pp_k_heuristic_lanes(PPParams p
             for (int lo = 0; lo < hi; lo++)
                 T[((hi * (hi - 1)) >> 1) + lo] = pp_dist(P[2 * lo], P[2 * lo + 1], P[2 * hi], P[2 * hi + 1]);
     __syncthreads();
+    double* CB = CBall + (tid / PP_HL_SPLIT) * PP_HL_MAX_N;
+#if PP_HL_PRUNE
+    if (have)
+        for (int r = sub; r < n; r += PP_HL_SPLIT) {              // CB[r] = len[r] - 2w + the shortest way into ribbon r from another ribbon
+            double m = (n > 1) ? PP_DBL_MAX : 0.0;
+            for (int q = 0; q < 2 * n; q++)
+                if ((q >> 1) != r) m = fmin(m, fmin(T[pp_tri(q, 2 * r)], T[pp_tri(q, 2 * r + 1)]));
+            CB[r] = T[r * (2 * r + 1) + 2 * r] - 2 * p.ribw + m;
+        }
+    __syncthreads();
+#endif
     if (!have) return;
     PPLaneTsp c;
-    c.T = T; c.twoW = 2 * p.ribw;
+    c.T = T; c.CB = CB; c.twoW = 2 * p.ribw; c.cnt = p.need_big + 14;
+#ifdef PP_HL_COUNT
+    if ((threadIdx.x & 63) == 0) atomicAdd(p.need_big + 15, n == 6 ? 64u : (n == 5 ? 16u : (n == 4 ? 4u : 1u)));   // last-two-level calls per lane without pruning (K = 2)
+#endif
     c.sortK = p.heuristic != PPGPU_H_TSP_POINT_ALL;
     c.K = c.sortK ? p.tsp_k : PP_TSP_MAX;
     double hdist = 0;

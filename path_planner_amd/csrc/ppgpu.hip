@@ -939,6 +939,15 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     // 8-byte read each)
     if (p.heuristic == PPGPU_H_TSP_POINT_K)
         hipLaunchKernelGGL(pp_k_heuristic_big, dim3(resident_grid(c, 6, pp_k_heuristic_big, total)), dim3(PP_H_WPB * 64), 0, c->stream, p);
+#ifdef PP_HL_COUNT
+    if (p.defer_h) {   // developer aid: how much of the lane heuristic's enumeration the bound cut away
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        unsigned cnt[2];
+        HIP_TRY(hipMemcpy(cnt, c->need_big.p + 14, sizeof(cnt), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[lane tsp] last-two-level calls per wave: %u of %u without pruning\n", cnt[0], cnt[1]);
+        HIP_TRY(hipMemset(c->need_big.p + 14, 0, 2 * sizeof(unsigned)));
+    }
+#endif
     c->last_launch_edges = total; c->last_launch_packed = p.live_list != nullptr;
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], c->stream)); c->ev_launches++; }
     HIP_TRY(hipGetLastError());
