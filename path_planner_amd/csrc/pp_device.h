@@ -819,7 +819,12 @@ __device__ __forceinline__ bool pp_any_erasable_piece(const PPRibbon& r, int n, 
 // The run covers samples first .. first + L - 1; the endpoint moves to the projection of the last of them, the same expression the
 // step-by-step run applies at its last step.  A sample that does not clear its margins ends the long run there and ordinary
 // windows take over: flags cannot differ.  With ell = 0 (and sinDt = 0) every expression below is the step-by-step one.
-__device__ inline int pp_corridor_run(const PPRibbon& r, int n, double w, int adv, bool moveEnd, double x, double y, bool stepOk,
+#ifdef PP_RUN_NOINLINE
+#define PP_RUN_INLINE __noinline__
+#else
+#define PP_RUN_INLINE inline
+#endif
+__device__ PP_RUN_INLINE int pp_corridor_run(const PPRibbon& r, int n, double w, int adv, bool moveEnd, double x, double y, bool stepOk,
                                       unsigned long long coverMask, int first, double span, double& newX, double& newY,
                                       double ell = 0.0, double sinDt = 0.0) {
     const int lane = pp_lane();
@@ -898,7 +903,7 @@ __device__ inline int pp_corridor_run(const PPRibbon& r, int n, double w, int ad
 // Long runs (ell > 0, see pp_corridor_run): a sample vouches for the steps between the previous sample and itself when it lies
 // inside a piece with ell to spare and no piece could split anywhere within ell of it — or cover() is off at ALL of those steps
 // (bit i of coverMask: cover() runs at SOME step sample i vouches for).
-__device__ inline int pp_quiet_run(const PPRibbon& r, int n, double w, double x, double y, bool stepOk,
+__device__ PP_RUN_INLINE int pp_quiet_run(const PPRibbon& r, int n, double w, double x, double y, bool stepOk,
                                    unsigned long long coverMask, int first, double span, double ell = 0.0) {
     const int lane = pp_lane();
     const double g = 1e-9;

@@ -202,6 +202,13 @@ __device__ __forceinline__ void pp_edge_decode(const PPParams& p, long long e, u
     }
 }
 
+// PPEdgeSetup::tfar (pp_curve_clear_after below): built only with -DPP_TFAR since round 3.  Measured on config 3: computing it costs
+// pp_k_solve_edges 38 us (148 -> 110) and saves the event walkers nothing any more (cover sweep 1057 -> 1050 us WITHOUT it, approach
+// kernel 68 -> 71): the events it spares are the sparse far ones, which the lane-per-edge approach kernel walks at ~60 instructions
+// each.  Without it tfar = +inf and both walkers' tests never fire; records are the same either way.
+#if !defined(PP_TFAR) && !defined(PP_NO_TFAR)
+#define PP_NO_TFAR
+#endif
 // Phase 0 for every edge of a launch, one lane per edge (Vertex::connect -> Edge::computeApproxCost ->
 // DubinsWrapper::set, Edge.cpp:14-18,73-76; Edge::setEnd(wrapper), Edge.cpp:208-216 for wrapper edges).
 // From which curve parameter on does a solved curve stay clear of every ribbon of its source vertex?  "Clear" is what
@@ -1255,7 +1262,10 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
             const double* rp = p.ribbons + 4 * (size_t)V->ribbon_offset;
             const double* tg = p.tgrid + (size_t)S->vi * p.ng;
             const double wStart = S->wStart, speed = S->speed, length = S->length, rho = S->rho, rho_inv = S->rho_inv, qx = S->qx, qy = S->qy;
-            const double tfar = S->tfar, hi0 = S->seg[0].hi, hi1 = S->seg[1].hi;
+            const double hi0 = S->seg[0].hi, hi1 = S->seg[1].hi;
+#ifndef PP_NO_TFAR
+            const double tfar = S->tfar;
+#endif
             const double endTime0 = fmin(p.horizon + 1e-12 + p.sst, S->wEnd);
             const double w = p.ribw, grow = w + 1e-3, minLength0 = 2 * w;
             bool tiny = false;
@@ -1274,7 +1284,9 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
                 if (k >= limit) break;
                 const double t = tg[k];
                 if (!(t < endTime0)) break;
+#ifndef PP_NO_TFAR
                 if ((t - wStart) * speed / rho > tfar) { k = 0x3fffffff; break; }       // the rest of the curve is clear: no event is visited
+#endif
 #if PP_APPROACH_MAX_EVENTS > 0
                 if (--budget < 0) { handOver = true; break; }                           // a long chain: the wave goes on from event k
 #endif
@@ -2106,12 +2118,14 @@ __global__ __launch_bounds__(PP_H_WPB * 64) void pp_k_heuristic_dubins(PPParams 
         pp_heuristic_edge<true, PP_TSP_MAX>(p, e, lds_all[wave]);
 }
 // TspPointRobotNoSplitKRibbons on child lists of 9..12 ribbons (rare: a vertex whose ribbons were split many times)
+#define PP_BIG_GRID 1024
 __global__ __launch_bounds__(PP_H_WPB * 64) void pp_k_heuristic_big(PPParams p) {
     __shared__ double lds_all[PP_H_WPB][PPTsp<PP_TSP_MAX_BIG>::LDS];
     if (pp_const_i32(p.need_big)[0] == 0) return;            // almost always: no child list beyond 8 ribbons in this launch
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    PPQueue qs = pp_queue_init();
-    for (PP_EACH_EDGE(e, 4, PP_Q_BIG, p.n_edges, PP_Q_CHUNK_HEUR))
+    // a modest grid whose waves stride over the edges (ppgpu.hip: at most PP_BIG_GRID workgroups): the launch that finds nothing to do —
+    // nearly every one — used to start a workgroup per four edges to learn it, 14 us at config 3
+    for (long long e = (long long)blockIdx.x * PP_H_WPB + wave; e < p.n_edges; e += (long long)gridDim.x * PP_H_WPB)
         pp_heuristic_edge<false, PP_TSP_MAX_BIG>(p, e, lds_all[wave]);
 }
 

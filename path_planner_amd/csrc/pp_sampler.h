@@ -64,15 +64,7 @@ __device__ __forceinline__ double pp_canonical(unsigned& x) {
 }
 __device__ __forceinline__ double pp_uniform(unsigned& x, double a, double b) { return pp_canonical(x) * (b - a) + a; }
 
-// ------------------------------------------------------------------------------ 1. proj bits
-// proj[qi] bit 0 = (5th draw of a sample starting at slot pos + qi) < pi/50   (StateGenerator.cpp:22)
-__global__ __launch_bounds__(256) void pp_k_proj_bits(unsigned seed, unsigned long long pos, long long nq, unsigned char* proj) {
-    long long qi = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (qi >= nq) return;
-    unsigned x = pp_lcg_jump(seed, 2ull * (pos + (unsigned long long)qi + 4ull));
-    double u = pp_uniform(x, 0, PP_TWO_PI);
-    proj[qi] = (u < PP_PI / 50) ? 1 : 0;
-}
+// Step 1, proj bits: proj[qi] bit 0 = (5th draw of a sample starting at slot pos + qi) < pi/50   (StateGenerator.cpp:22)
 
 // ------------------------------------------------------------------------------ 2. chain scan
 // 6x6 boolean matrix, row i in bits [6i, 6i+6); C = A after B.
@@ -114,60 +106,7 @@ __device__ inline unsigned long long pp_bm_block_scan(unsigned long long agg, un
     __syncthreads();
     return excl;
 }
-__global__ __launch_bounds__(256) void pp_k_chain_reduce(const unsigned char* proj, long long nq, unsigned long long* blk) {
-    __shared__ unsigned long long sh[256];
-    long long q0 = (long long)blockIdx.x * PP_SCAN_TILE + (long long)threadIdx.x * 8;
-    unsigned long long agg = PP_BM_IDENTITY;
-    for (int i = 0; i < 8; i++) {
-        long long q = q0 + i;
-        if (q < nq) agg = pp_bm_compose(pp_bm_step(proj, q), agg);
-    }
-    unsigned long long total;
-    pp_bm_block_scan(agg, sh, total);
-    if (threadIdx.x == 0) blk[blockIdx.x] = total;
-}
-// exclusive scan of the workgroup aggregates, in place (at most PP_SCAN_TILE of them)
-__global__ __launch_bounds__(256) void pp_k_chain_scan_blocks(unsigned long long* blk, int nblk) {
-    __shared__ unsigned long long sh[256];
-    int b0 = threadIdx.x * 8;
-    unsigned long long loc[8];
-    unsigned long long agg = PP_BM_IDENTITY;
-    for (int i = 0; i < 8; i++) {
-        loc[i] = (b0 + i < nblk) ? blk[b0 + i] : PP_BM_IDENTITY;
-        agg = pp_bm_compose(loc[i], agg);
-    }
-    unsigned long long total;
-    unsigned long long pre = pp_bm_block_scan(agg, sh, total);
-    for (int i = 0; i < 8; i++) {
-        if (b0 + i < nblk) blk[b0 + i] = pre;
-        pre = pp_bm_compose(loc[i], pre);
-    }
-}
 // vis[q] = (P_q e_0)[0] = P_q[0][0]; stored as bit 1 of proj[q]
-__global__ __launch_bounds__(256) void pp_k_chain_apply(unsigned char* proj, long long nq, const unsigned long long* blk) {
-    __shared__ unsigned long long sh[256];
-    long long q0 = (long long)blockIdx.x * PP_SCAN_TILE + (long long)threadIdx.x * 8;
-    unsigned long long m[8];
-    unsigned long long agg = PP_BM_IDENTITY;
-    for (int i = 0; i < 8; i++) {
-        long long q = q0 + i;
-        m[i] = (q < nq) ? pp_bm_step(proj, q) : PP_BM_IDENTITY;
-        agg = pp_bm_compose(m[i], agg);
-    }
-    unsigned long long total;
-    unsigned long long pre = pp_bm_block_scan(agg, sh, total);
-    pre = pp_bm_compose(pre, blk[blockIdx.x]);
-    unsigned vis[8];
-    for (int i = 0; i < 8; i++) {
-        vis[i] = (unsigned)(pre & 1ull);
-        pre = pp_bm_compose(m[i], pre);
-    }
-    __syncthreads();   // every thread has read its proj[q-4], proj[q-5] neighbours (bit 0 only is read; bit 1 written)
-    for (int i = 0; i < 8; i++) {
-        long long q = q0 + i;
-        if (q < nq) proj[q] = (unsigned char)((proj[q] & 1u) | (vis[i] << 1));
-    }
-}
 
 // ------------------------------------------------------------------------------ 3. integer scans
 __device__ inline unsigned pp_u32_block_scan(unsigned agg, unsigned* sh, unsigned& total) {
@@ -185,33 +124,122 @@ __device__ inline unsigned pp_u32_block_scan(unsigned agg, unsigned* sh, unsigne
     __syncthreads();
     return excl;
 }
-__global__ __launch_bounds__(256) void pp_k_count_reduce(const unsigned char* flags, long long n, unsigned mask, unsigned* blk) {
-    __shared__ unsigned sh[256];
-    long long i0 = (long long)blockIdx.x * PP_SCAN_TILE + (long long)threadIdx.x * 8;
-    unsigned cnt = 0;
-    for (int i = 0; i < 8; i++) if (i0 + i < n && (flags[i0 + i] & mask)) cnt++;
+
+
+// ------------------------------------------------------------------------------ fused launches (round 3)
+// The sampler's kernels are tiny (65 536 attempts = 393 k stream slots) and each launch waits for the one before it: twelve launches
+// took ~80 us of which the work is a few.  The same steps in five launches: every workgroup works out the prefix of the workgroup
+// aggregates before it for itself (a few hundred 8-byte values: cheaper than a launch that does it once), and neighbouring
+// steps share a kernel where one only consumes what the other's own workgroup produced.  Same arithmetic, same bits.
+//
+// prefix of the matrices blk[0 .. upto): composed in order (later on the left), by the whole workgroup
+__device__ inline unsigned long long pp_bm_prefix_of(const unsigned long long* blk, int upto, unsigned long long* sh) {
+    unsigned long long agg = PP_BM_IDENTITY;
+    const int per = (upto + 255) / 256;                       // consecutive entries per thread
+    const int b0 = (int)threadIdx.x * per;
+    for (int i = 0; i < per; i++)
+        if (b0 + i < upto) agg = pp_bm_compose(blk[b0 + i], agg);
+    unsigned long long total;
+    pp_bm_block_scan(agg, sh, total);
+    return total;
+}
+__device__ inline unsigned pp_u32_prefix_of(const unsigned* blk, int upto, unsigned* sh) {
+    unsigned agg = 0;
+    for (int i = (int)threadIdx.x; i < upto; i += 256) agg += blk[i];
     unsigned total;
-    pp_u32_block_scan(cnt, sh, total);
+    pp_u32_block_scan(agg, sh, total);
+    return total;
+}
+// 1 + 2a: proj bits of a tile (and of the five slots before it, which its first transitions read) and the tile's transition product
+__global__ __launch_bounds__(256) void pp_k_proj_reduce(unsigned seed, unsigned long long pos, long long nq, unsigned char* proj,
+                                                        unsigned long long* blk, unsigned long long* zero16) {
+    __shared__ unsigned long long sh[256];
+    __shared__ unsigned char sp[PP_SCAN_TILE + 8];             // sp[5 + i] = proj of the tile's slot i; sp[0 .. 4] = the five slots before the tile
+    if (blockIdx.x == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0ull;   // end slot / total of this call (written by later launches)
+    const long long tile0 = (long long)blockIdx.x * PP_SCAN_TILE;
+    {
+        // a thread's eight slots are consecutive: the draw that decides slot q ends where the one of slot q + 1 begins (two engine calls
+        // each), so one jump-ahead per thread and then the engine's own steps
+        const int l0 = (int)threadIdx.x * 8;
+        const long long q0 = tile0 + l0;
+        unsigned x = (q0 < nq) ? pp_lcg_jump(seed, 2ull * (pos + (unsigned long long)q0 + 4ull)) : 1u;
+        for (int i = 0; i < 8; i++) {
+            unsigned char b = 0;
+            if (q0 + i < nq) {
+                const double u = pp_uniform(x, 0, PP_TWO_PI);
+                b = (u < PP_PI / 50) ? 1 : 0;
+                proj[q0 + i] = b;
+            }
+            sp[5 + l0 + i] = b;
+        }
+        if (threadIdx.x < 5) {                                 // the five slots before the tile
+            const long long q = tile0 - 5 + (long long)threadIdx.x;
+            unsigned char b = 0;
+            if (q >= 0 && q < nq) {
+                unsigned xh = pp_lcg_jump(seed, 2ull * (pos + (unsigned long long)q + 4ull));
+                const double u = pp_uniform(xh, 0, PP_TWO_PI);
+                b = (u < PP_PI / 50) ? 1 : 0;
+            }
+            sp[threadIdx.x] = b;
+        }
+    }
+    __syncthreads();
+    const int l0 = (int)threadIdx.x * 8;
+    unsigned long long agg = PP_BM_IDENTITY;
+    for (int i = 0; i < 8; i++) {
+        const long long q = tile0 + l0 + i;
+        if (q < nq) {
+            const unsigned p4 = q >= 4 ? (unsigned)sp[5 + l0 + i - 4] : 0u, p5 = q >= 5 ? (unsigned)sp[5 + l0 + i - 5] : 0u;
+            const unsigned row0 = ((p4 ^ 1u) << 4) | (p5 << 5);
+            const unsigned long long m = (unsigned long long)row0 | (1ull << 6) | (2ull << 12) | (4ull << 18) | (8ull << 24) | (16ull << 30);
+            agg = pp_bm_compose(m, agg);
+        }
+    }
+    unsigned long long total;
+    pp_bm_block_scan(agg, sh, total);
     if (threadIdx.x == 0) blk[blockIdx.x] = total;
 }
-__global__ __launch_bounds__(256) void pp_k_count_scan_blocks(unsigned* blk, int nblk) {
-    __shared__ unsigned sh[256];
-    int b0 = threadIdx.x * 8;
-    unsigned loc[8], agg = 0;
-    for (int i = 0; i < 8; i++) { loc[i] = (b0 + i < nblk) ? blk[b0 + i] : 0u; agg += loc[i]; }
-    unsigned total;
-    unsigned pre = pp_u32_block_scan(agg, sh, total);
-    for (int i = 0; i < 8; i++) { if (b0 + i < nblk) blk[b0 + i] = pre; pre += loc[i]; }
-}
-// slot of sample i for i < n, and the absolute slot of sample n (= where the next call resumes)
-__global__ __launch_bounds__(256) void pp_k_chain_positions(const unsigned char* proj, long long nq, const unsigned* blk,
-                                                            long long n, unsigned* qpos, unsigned long long* end_slot) {
-    __shared__ unsigned sh[256];
+// 2b + 3a: the tile's visited bits (prefix of the tiles before it worked out here) and how many of its slots are visited
+__global__ __launch_bounds__(256) void pp_k_chain_apply_count(unsigned char* proj, long long nq, const unsigned long long* blk, unsigned* cnt) {
+    __shared__ unsigned long long sh[256];
+    __shared__ unsigned shc[256];
+    const unsigned long long before = pp_bm_prefix_of(blk, (int)blockIdx.x, sh);
     long long q0 = (long long)blockIdx.x * PP_SCAN_TILE + (long long)threadIdx.x * 8;
-    unsigned cnt = 0;
-    for (int i = 0; i < 8; i++) if (q0 + i < nq && (proj[q0 + i] & 2u)) cnt++;
+    unsigned long long m[8];
+    unsigned long long agg = PP_BM_IDENTITY;
+    for (int i = 0; i < 8; i++) {
+        long long q = q0 + i;
+        m[i] = (q < nq) ? pp_bm_step(proj, q) : PP_BM_IDENTITY;
+        agg = pp_bm_compose(m[i], agg);
+    }
+    unsigned long long total;
+    unsigned long long pre = pp_bm_block_scan(agg, sh, total);
+    pre = pp_bm_compose(pre, before);
+    unsigned vis[8], c = 0;
+    for (int i = 0; i < 8; i++) {
+        vis[i] = (unsigned)(pre & 1ull);
+        pre = pp_bm_compose(m[i], pre);
+        if (q0 + i < nq) c += vis[i];
+    }
+    __syncthreads();   // every thread has read its proj[q-4], proj[q-5] neighbours (bit 0 only is read; bit 1 written)
+    for (int i = 0; i < 8; i++) {
+        long long q = q0 + i;
+        if (q < nq) proj[q] = (unsigned char)((proj[q] & 1u) | (vis[i] << 1));
+    }
+    unsigned tot;
+    pp_u32_block_scan(c, shc, tot);
+    if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
+}
+// 3b: slot of sample i for i < n, and the slot of sample n (= where the next call resumes); cnt = per-tile counts (not yet scanned)
+__global__ __launch_bounds__(256) void pp_k_chain_positions_scan(const unsigned char* proj, long long nq, const unsigned* cnt,
+                                                                 long long n, unsigned* qpos, unsigned long long* end_slot) {
+    __shared__ unsigned sh[256];
+    const unsigned before = pp_u32_prefix_of(cnt, (int)blockIdx.x, sh);
+    long long q0 = (long long)blockIdx.x * PP_SCAN_TILE + (long long)threadIdx.x * 8;
+    unsigned c = 0;
+    for (int i = 0; i < 8; i++) if (q0 + i < nq && (proj[q0 + i] & 2u)) c++;
     unsigned total;
-    unsigned rank = pp_u32_block_scan(cnt, sh, total) + blk[blockIdx.x];
+    unsigned rank = pp_u32_block_scan(c, sh, total) + before;
     for (int i = 0; i < 8; i++) {
         long long q = q0 + i;
         if (q < nq && (proj[q] & 2u)) {
@@ -244,49 +272,54 @@ __device__ inline void pp_project_onto_nearest(const double* rb, int n, double& 
     x = px; y = py; heading = h;
 }
 
-__global__ __launch_bounds__(256) void pp_k_generate(PPSamplerState s, const unsigned* qpos, const unsigned char* proj,
-                                                     const double* ribbons, long long n, double* cand) {
-    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    unsigned long long rel = qpos ? (unsigned long long)qpos[i] : 4ull * (unsigned long long)i;
-    unsigned x = pp_lcg_jump(s.seed, 2ull * (s.pos + rel));
-    double speed = pp_uniform(x, s.b[4], s.b[5]);   // drawn first (right-to-left argument evaluation)
-    (void)speed;                                    // expand() overwrites it (SamplingBasedPlanner.cpp:113)
-    double heading = pp_uniform(x, 0, PP_TWO_PI);
-    double yy = pp_uniform(x, s.b[2], s.b[3]);
-    double xx = pp_uniform(x, s.b[0], s.b[1]);
-    if (s.on_ribbons) {
-        double u5 = pp_uniform(x, 0, PP_TWO_PI);
-        if (u5 < PP_PI / 50) {                       // StateGenerator.cpp:22
-            pp_project_onto_nearest(ribbons, s.n_ribbons, xx, yy, heading);
-            double u6 = pp_uniform(x, 0, PP_TWO_PI);
-            if (u6 < PP_PI) heading += PP_PI;        // :24-26, no wrap
-        }
-    }
-    cand[i] = xx; cand[n + i] = yy; cand[2 * n + i] = heading;
-}
 
 // ------------------------------------------------------------------------------ 5. map filter + compaction
-__global__ __launch_bounds__(256) void pp_k_keep_flags(PPGrid g, const double* cand, long long n, unsigned char* keep) {
-    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    keep[i] = pp_is_blocked(g, cand[i], cand[n + i]) ? 0 : 1;   // SamplingBasedPlanner.cpp:161
-}
-__global__ __launch_bounds__(256) void pp_k_compact_samples(const unsigned char* keep, long long n, const unsigned* blk,
-                                                            const double* cand, double* sx, double* sy, double* sh,
-                                                            long long base, unsigned long long* total_out) {
-    __shared__ unsigned shm[256];
-    long long i0 = (long long)blockIdx.x * PP_SCAN_TILE + (long long)threadIdx.x * 8;
-    unsigned cnt = 0;
-    for (int i = 0; i < 8; i++) if (i0 + i < n && keep[i0 + i]) cnt++;
-    unsigned total;
-    unsigned rank = pp_u32_block_scan(cnt, shm, total) + blk[blockIdx.x];
-    for (int i = 0; i < 8; i++) {
-        long long j = i0 + i;
-        if (j < n && keep[j]) {
-            sx[base + rank] = cand[j]; sy[base + rank] = cand[n + j]; sh[base + rank] = cand[2 * n + j];
-            rank++;
+
+// 4 + 5a: one candidate per thread, the map filter's verdict on it, and how many of the workgroup's 256 candidates are kept
+__global__ __launch_bounds__(256) void pp_k_generate_keep(PPSamplerState s, const unsigned* qpos, const unsigned char* proj, const double* ribbons,
+                                                          long long n, double* cand, PPGrid g, unsigned char* keep, unsigned* cnt) {
+    __shared__ unsigned sc[4];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    bool kept = false;
+    if (i < n) {
+        unsigned long long rel = qpos ? (unsigned long long)qpos[i] : 4ull * (unsigned long long)i;
+        unsigned x = pp_lcg_jump(s.seed, 2ull * (s.pos + rel));
+        double speed = pp_uniform(x, s.b[4], s.b[5]);   // drawn first (right-to-left argument evaluation)
+        (void)speed;                                    // expand() overwrites it (SamplingBasedPlanner.cpp:113)
+        double heading = pp_uniform(x, 0, PP_TWO_PI);
+        double yy = pp_uniform(x, s.b[2], s.b[3]);
+        double xx = pp_uniform(x, s.b[0], s.b[1]);
+        if (s.on_ribbons) {
+            double u5 = pp_uniform(x, 0, PP_TWO_PI);
+            if (u5 < PP_PI / 50) {                       // StateGenerator.cpp:22
+                pp_project_onto_nearest(ribbons, s.n_ribbons, xx, yy, heading);
+                double u6 = pp_uniform(x, 0, PP_TWO_PI);
+                if (u6 < PP_PI) heading += PP_PI;        // :24-26, no wrap
+            }
         }
+        cand[i] = xx; cand[n + i] = yy; cand[2 * n + i] = heading;
+        kept = !pp_is_blocked(g, xx, yy);               // SamplingBasedPlanner.cpp:161
+        keep[i] = kept ? 1 : 0;
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *total_out = (unsigned long long)rank;
+    const unsigned long long m = __ballot(kept);
+    if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = sc[0] + sc[1] + sc[2] + sc[3];
+}
+// 5b: order-preserving compaction; cnt = kept candidates per 256-candidate workgroup (not yet scanned)
+__global__ __launch_bounds__(256) void pp_k_compact_scan(const unsigned char* keep, long long n, const unsigned* cnt, const double* cand,
+                                                         double* sx, double* sy, double* sh, long long base, unsigned long long* total_out) {
+    __shared__ unsigned shm[256];
+    __shared__ unsigned sc[4];
+    const unsigned before = pp_u32_prefix_of(cnt, (int)blockIdx.x, shm);
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool kept = i < n && keep[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(kept);
+    if (lane == 0) sc[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    unsigned rank = before + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; w++) rank += sc[w];
+    if (kept) { sx[base + rank] = cand[i]; sy[base + rank] = cand[n + i]; sh[base + rank] = cand[2 * n + i]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = (unsigned long long)(before + sc[0] + sc[1] + sc[2] + sc[3]);
 }

@@ -553,24 +553,24 @@ static int sampler_chain(ppgpu_ctx* c, long long n, long long& nq, int& nblk_q, 
     nq = s.on_ribbons ? (6 * n + 8) : n;   // worst case every sample is projected: 6 slots per sample
     nblk_q = (int)((nq + PP_SCAN_TILE - 1) / PP_SCAN_TILE);
     if (nblk_q > PP_SCAN_TILE) return fail(PPGPU_ECAPACITY, "sampler: batch too large for the two-level scan (max ~690k samples per call)");
-    if ((rc = c->s_bytes.reserve((size_t)nq + 64, false, st))) return rc;
+    if ((rc = c->s_bytes.reserve((size_t)nq + 64 + (size_t)n + 64, false, st))) return rc;   // projection / visited bits, then the keep flags
     if ((rc = c->s_u64.reserve((size_t)nblk_q + 64, false, st))) return rc;
     if ((rc = c->s_u32a.reserve((size_t)nq + 64, false, st))) return rc;
-    if ((rc = c->s_u32b.reserve((size_t)nblk_q + 64, false, st))) return rc;
+    {   // per-tile counts of the chain scan, later (ppgpu_sampler_add) per-workgroup counts of the compaction: sized for both now,
+        // so that nothing is re-allocated while launches that use it are in flight
+        const size_t nblk_n = (size_t)((n + 255) / 256);
+        if ((rc = c->s_u32b.reserve(((size_t)nblk_q > nblk_n ? (size_t)nblk_q : nblk_n) + 64, false, st))) return rc;
+    }
     *d_end = c->s_u64.p + nblk_q + 8;
-    HIP_TRY(hipMemsetAsync(c->s_u64.p + nblk_q + 8, 0, 16 * sizeof(unsigned long long), st));
-    if (!s.on_ribbons) return PPGPU_OK;
+    if (!s.on_ribbons) { HIP_TRY(hipMemsetAsync(c->s_u64.p + nblk_q + 8, 0, 16 * sizeof(unsigned long long), st)); return PPGPU_OK; }
     unsigned char* proj = c->s_bytes.p;
-    // 1. proj[q] for every slot in range (thread per slot, LCG jump-ahead)
-    hipLaunchKernelGGL(pp_k_proj_bits, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, s.seed, s.pos, nq, proj);
-    // 2. visited[q]: the chain q -> q + 5 + proj[q] as a scan of 6x6 boolean transition matrices
-    hipLaunchKernelGGL(pp_k_chain_reduce, dim3(nblk_q), dim3(256), 0, st, proj, nq, c->s_u64.p);
-    hipLaunchKernelGGL(pp_k_chain_scan_blocks, dim3(1), dim3(256), 0, st, c->s_u64.p, nblk_q);
-    hipLaunchKernelGGL(pp_k_chain_apply, dim3(nblk_q), dim3(256), 0, st, proj, nq, c->s_u64.p);
-    // 3. rank the visited slots: slot of each sample, and of sample n
-    hipLaunchKernelGGL(pp_k_count_reduce, dim3(nblk_q), dim3(256), 0, st, proj, nq, 2u, c->s_u32b.p);
-    hipLaunchKernelGGL(pp_k_count_scan_blocks, dim3(1), dim3(256), 0, st, c->s_u32b.p, nblk_q);
-    hipLaunchKernelGGL(pp_k_chain_positions, dim3(nblk_q), dim3(256), 0, st, proj, nq, c->s_u32b.p, n, c->s_u32a.p, *d_end);
+    // 1. proj[q] for every slot in range (LCG jump-ahead) + 2a. the transition product of every tile of PP_SCAN_TILE slots: the chain
+    //    q -> q + 5 + proj[q] as a scan of 6x6 boolean transition matrices (also zeroes the end slot / total of this call)
+    hipLaunchKernelGGL(pp_k_proj_reduce, dim3(nblk_q), dim3(256), 0, st, s.seed, s.pos, nq, proj, c->s_u64.p, c->s_u64.p + nblk_q + 8);
+    // 2b. visited[q] + 3a. visited slots per tile
+    hipLaunchKernelGGL(pp_k_chain_apply_count, dim3(nblk_q), dim3(256), 0, st, proj, nq, c->s_u64.p, c->s_u32b.p);
+    // 3b. rank the visited slots: slot of each sample, and of sample n
+    hipLaunchKernelGGL(pp_k_chain_positions_scan, dim3(nblk_q), dim3(256), 0, st, proj, nq, c->s_u32b.p, n, c->s_u32a.p, *d_end);
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;
 }
@@ -616,21 +616,18 @@ int ppgpu_sampler_add(ppgpu_ctx* c, int64_t n_attempts, int64_t* n_total_out) {
     if ((rc = c->s_cand.reserve((size_t)n * 3, false, st))) return rc;
     long long nq; int nblk_q; unsigned long long* d_end;
     if ((rc = sampler_chain(c, n, nq, nblk_q, &d_end))) return rc;
-    const int nblk_n = (int)((n + PP_SCAN_TILE - 1) / PP_SCAN_TILE);
+    const int nblk_n = (int)((n + 255) / 256);
     unsigned char* proj = c->s_bytes.p;
     unsigned* qpos = c->s_u32a.p;
     unsigned* blk32 = c->s_u32b.p;
-    // 4. generate the n candidate states (thread per sample)
-    hipLaunchKernelGGL(pp_k_generate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, s.on_ribbons ? qpos : nullptr,
-                       s.on_ribbons ? proj : nullptr, c->samp_ribbons.p, n, c->s_cand.p);
-    // 5. SamplingBasedPlanner::addSamples' map filter, order-preserving compaction into the store
+    // 4. generate the n candidate states (thread per sample) + 5a. SamplingBasedPlanner::addSamples' map filter
     PPGrid g{c->grid.p, c->rows, c->cols, c->wpr, c->res, c->res > 0 ? 1.0 / c->res : 0.0, nullptr};
-    unsigned char* keep = proj;  // the projection bits are no longer needed once the candidates exist
-    hipLaunchKernelGGL(pp_k_keep_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, c->s_cand.p, n, keep);
-    hipLaunchKernelGGL(pp_k_count_reduce, dim3(nblk_n), dim3(256), 0, st, keep, n, 1u, blk32);
-    hipLaunchKernelGGL(pp_k_count_scan_blocks, dim3(1), dim3(256), 0, st, blk32, nblk_n);
+    unsigned char* keep = c->s_bytes.p + (size_t)nq + 64;          // (the projection bits are still being read by this launch)
+    hipLaunchKernelGGL(pp_k_generate_keep, dim3((unsigned)nblk_n), dim3(256), 0, st, s, s.on_ribbons ? qpos : nullptr, s.on_ribbons ? proj : nullptr,
+                       c->samp_ribbons.p, n, c->s_cand.p, g, keep, blk32);
+    // 5b. order-preserving compaction into the store
     unsigned long long* d_total = d_end + 8;
-    hipLaunchKernelGGL(pp_k_compact_samples, dim3(nblk_n), dim3(256), 0, st, keep, n, blk32, c->s_cand.p, c->sx.p, c->sy.p,
+    hipLaunchKernelGGL(pp_k_compact_scan, dim3((unsigned)nblk_n), dim3(256), 0, st, keep, n, blk32, c->s_cand.p, c->sx.p, c->sy.p,
                        c->sh.p, c->n_samples, d_total);
     HIP_TRY(hipGetLastError());
     // the two counts come back through pinned memory (a copy to pageable memory waits for the stream by itself, once per copy)
@@ -923,6 +920,33 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         }
         std::fprintf(stderr, "[skips] edges %lld, chunks reached %llu, skipped %llu (%.1f %%), marked in all %llu\n", p.n_edges, reached, skipped,
                      reached ? 100.0 * skipped / reached : 0.0, marked);
+        // how many chunks per edge the pose sweep samples, and how often the only one is the edge's last (partial or stopping) chunk
+        unsigned long long hist[8] = {0, 0, 0, 0, 0, 0, 0, 0}, onlyLast = 0, lastPartial = 0;
+        for (long long e = 0; e < p.n_edges; e++) {
+            const int lim = sm[(size_t)e].limit, nreach = (lim + 63) / 64 + ((lim % 64 == 0) ? 1 : 0);   // the chunk the sweep stops in is reached too
+            int sampled = 0, lastSampled = 0;
+            for (int ch = 0; ch < p.nch && ch < nreach; ch++)
+                if (!(sk[(size_t)e * p.nch + ch] & 1)) { sampled++; lastSampled = (ch == nreach - 1); }
+            hist[sampled < 7 ? sampled : 7]++;
+            if (sampled == 1 && lastSampled) onlyLast++;
+            if (lim % 64 != 0) lastPartial++;
+        }
+        {
+            // which chunks are sampled, and what the planner knew about them: [position: first / middle / last reached][skip byte >> 1: neither half clear, grid clear, obstacles clear, both]
+            unsigned long long why[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            for (long long e = 0; e < p.n_edges; e++) {
+                const int lim = sm[(size_t)e].limit, nreach = (lim + 63) / 64 + ((lim % 64 == 0) ? 1 : 0);
+                for (int ch = 0; ch < p.nch && ch < nreach; ch++) {
+                    const unsigned b = sk[(size_t)e * p.nch + ch];
+                    if (!(b & 1)) why[ch == nreach - 1 ? 2 : (ch == 0 ? 0 : 1)][(b >> 1) & 3]++;
+                }
+            }
+            for (int i = 0; i < 3; i++)
+                std::fprintf(stderr, "[skips] sampled %s chunks: nothing clear %llu, grid clear %llu, obstacles clear %llu, both clear (geometry / heading bits) %llu\n",
+                             i == 0 ? "first" : (i == 1 ? "middle" : "last"), why[i][0], why[i][1], why[i][2], why[i][3]);
+        }
+        std::fprintf(stderr, "[skips] sampled chunks per edge: 0:%llu 1:%llu 2:%llu 3:%llu 4:%llu 5:%llu 6:%llu 7+:%llu; only the last one %llu; limit not a multiple of 64: %llu\n",
+                     hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], onlyLast, lastPartial);
     }
 #endif
     p.e_base = 0;
@@ -938,7 +962,10 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     // child lists of 9..12 ribbons under the K variant: a second pass that touches only those edges (the others cost it one
     // 8-byte read each)
     if (p.heuristic == PPGPU_H_TSP_POINT_K)
-        hipLaunchKernelGGL(pp_k_heuristic_big, dim3(resident_grid(c, 6, pp_k_heuristic_big, total)), dim3(PP_H_WPB * 64), 0, c->stream, p);
+        {
+        const long long need = (total + PP_H_WPB - 1) / PP_H_WPB;
+        hipLaunchKernelGGL(pp_k_heuristic_big, dim3((unsigned)(need < PP_BIG_GRID ? need : PP_BIG_GRID)), dim3(PP_H_WPB * 64), 0, c->stream, p);
+    }
 #ifdef PP_HL_COUNT
     if (p.defer_h) {   // developer aid: how much of the lane heuristic's enumeration the bound cut away
         HIP_TRY(hipStreamSynchronize(c->stream));
