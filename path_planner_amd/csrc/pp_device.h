@@ -1002,6 +1002,9 @@ __device__ __forceinline__ unsigned pp_lane_tsp_leaves(int n, int K) {
     return L > (1ull << 20) ? (1u << 20) : (unsigned)L;
 }
 // may the cover sweep leave a child list of n ribbons to pp_k_heuristic_lanes?
+// (Round 3 measured the same walk with tables for 8 ribbons on the lists of 7 and 8 — ~1 100 of config 3's 236 140 edges, a whole
+// wave's work for ~170 us each: four lanes per edge took 404 us for them, the wave-uniform cut rarely fires on such deep trees and
+// each lane walks a quarter of up to 32 768 leaves alone.  They stay with pp_k_heuristic_listed, a wave each, beside this kernel.)
 #define PP_HL_MAX_N 6
 static_assert(PP_HL_MAX_N == 6, "pp_k_heuristic_lanes dispatches on n = 1 .. 6");
 __device__ __forceinline__ bool pp_lane_tsp_ok(int heuristic, int tsp_k, int n) {
@@ -1118,7 +1121,10 @@ __device__ __forceinline__ PPTspNode<MAXN> pp_tsp_child(const double* T, const d
 }
 
 template <int MAXN>
-__device__ inline double pp_h_tsp_point(const double* T, const double* KM, int n, double w, int K, bool sortK, const double* LEN = nullptr) {
+// passFirst / passStride: this wave takes the passes (of 64 prefixes) passFirst, passFirst + passStride, ... — several waves can share one
+// list, each with its own copy of the tables, and the minimum of their results is the result (pp_k_heuristic_listed).
+__device__ inline double pp_h_tsp_point(const double* T, const double* KM, int n, double w, int K, bool sortK, const double* LEN = nullptr,
+                                        unsigned passFirst = 0u, unsigned passStride = 1u) {
     if (n == 0) return 0;
     if (K <= 0) return PP_DBL_MAX;   // the reference's loop body never runs and it returns DBL_MAX
     const int lane = pp_lane();
@@ -1129,7 +1135,7 @@ __device__ inline double pp_h_tsp_point(const double* T, const double* KM, int n
     const unsigned NP = (unsigned)pp_tsp_prefixes(n, K, Ls);     // < 2^21 by the callers' limits
     const int nsuf = n - Ls;         // 0 .. 3
     double best = PP_DBL_MAX;
-    for (unsigned pbase = 0; pbase < NP; pbase += 64u) {
+    for (unsigned pbase = 64u * passFirst; pbase < NP; pbase += 64u * passStride) {
         const unsigned pid = pbase + (unsigned)lane;
         const bool act = pid < NP;
         unsigned rest = act ? pid : 0u;

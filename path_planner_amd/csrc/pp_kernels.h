@@ -46,6 +46,8 @@ struct PPParams {
     unsigned* live_list; unsigned* live_count;     // {workspace slot, list position} of the edges the cover sweep still has to visit (pp_k_approach_events)
     unsigned* defer_list; unsigned* defer_count;   // edges whose heuristic the cover sweep left to pp_k_heuristic_lanes
     unsigned* need_big;                  // set by the cover sweep when some child has 9..12 ribbons (pp_k_heuristic_big then has work)
+    struct PPCoverState* cover_state;    // [edge] what the cover sweep's wave hands to pp_k_cover_finish (NULL: every wave finishes its own edges)
+    unsigned* hw_list; unsigned* hw_count;   // edges pp_k_cover_finish leaves to pp_k_heuristic_listed (a TSP enumeration of 7 or 8 ribbons)
     int ngp, nch;                        // steps per edge rounded up to whole 64-step chunks, and that many chunks
 };
 
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256, PP_SOLVE_MIN_WAVES) void pp_k_solve_edges(PPPa
     // the queue heads of the kernels that follow (all of them start after this kernel has ended, in stream order)
     if (e < 4 * PP_NQ) p.work[(size_t)e * PP_QSTRIDE] = 0ull;
     if (e == 0 && p.live_count) *p.live_count = 0u;
-    if (e == 0 && p.e_base == 0) { *p.need_big = 0u; if (p.defer_count) for (int i = 0; i <= PP_HL_MAX_N; i++) p.defer_count[i] = 0u; }            // raised by the cover sweeps of this launch, read by pp_k_heuristic_big
+    if (e == 0 && p.e_base == 0) { *p.need_big = 0u; if (p.defer_count) for (int i = 0; i <= PP_HL_MAX_N; i++) p.defer_count[i] = 0u; if (p.hw_count) *p.hw_count = 0u; }            // raised by the cover sweeps of this launch, read by pp_k_heuristic_big
     if (e >= p.n_edges) return;
     unsigned vi, target, cbits;
     const long long eg = pp_edge_position(p, p.e_base + e);   // position in the caller's edge list; e = position in this slice
@@ -503,6 +505,16 @@ struct PPTrackSummary {
     int hits;       // -DPP_SUMMARY_HITS only (measured, not taken: DESIGN.md Appendix B): boxes hit, summed over steps [0, limit); else 0
 };
 
+// What the cover sweep's wave knows when its event loop (Edge.cpp:153-171) is over, for pp_k_cover_finish (one LANE per edge) to go
+// on from: the rest of computeTrueCost (Edge.cpp:177-205) is scalar work per edge — where the loop stopped, two poses, the last
+// cover, the hit sums, the cost, the record — that a whole wave used to do for one edge at a time (287 of the sweep's 1 047 us at
+// config 3).  The ribbons as the loop left them travel in the edge's child-ribbon slot.  nrib < 0: the wave finished the edge itself.
+#define PP_FINISH_MAX 8              // ribbons a lane takes over at most (it keeps them in registers; longer lists stay with the wave)
+struct PPCoverState {
+    double cct, endTime;             // RibbonManager::coverageCompletedTime, the edge's (possibly shortened) end time
+    int nrib, lastEv, rdt;           // ribbons left, last event visited, `ribbonsDoneTime` (an int: Edge.cpp:92)
+    unsigned flags;                  // PPGPU_F_* collected so far
+};
 // DubinsWrapper::sample (DubinsWrapper.cpp:29-49) -> dubins_path_sample for the 64 steps of one window, one step per lane:
 // x, y and the un-normalised yaw.  Used by BOTH sweeps with the same arithmetic, so the cover sweep sees exactly the poses the
 // pose sweep tested (it recomputes them for the few windows that hold coverage events instead of reading them back from HBM).
@@ -1391,7 +1403,7 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
 #define PP_FUSE_HEUR 1
 #endif
 template <int MAXN>
-__device__ __forceinline__ double pp_h_point_from_pts(int heuristic, int tsp_k, double ribw, double* lds_wave, int nrib);   // further down, with the heuristics
+__device__ __forceinline__ double pp_h_point_from_pts(int heuristic, int tsp_k, double ribw, double* lds_wave, int nrib, unsigned passFirst = 0u, unsigned passStride = 1u);   // further down, with the heuristics
 
 template <bool GAUSSIAN>
 __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const long long e, const long long eg, double* lds) {
@@ -1405,6 +1417,12 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
     unsigned flags = 0;
     ppgpu_edge_result* rec = p.out + eg;
     const unsigned sflags = (unsigned)PP_SI32(sflags);
+#if !defined(PP_NO_LANE_FINISH) && !defined(PP_DBG_COUNTS) && !defined(PP_DBG_EVENTS) && !defined(PP_ABL_ONLY_EVENTS)
+    const bool laneFinish = !GAUSSIAN && p.cover_state != nullptr;
+#else
+    const bool laneFinish = false;
+#endif
+    if (laneFinish && lane == 0) p.cover_state[e].nrib = -1;          // until the hand-over below says otherwise: finished here
     if (sflags & PP_SETUP_MALFORMED) {
         // malformed descriptor: fail loudly in the record, touch nothing else
         if (lane == 0) { rec->flags = PPGPU_F_INFEASIBLE | PPGPU_F_THROWS | PPGPU_F_DUBINS_ERR; rec->info = 0; }
@@ -1708,6 +1726,19 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
     if (lane == 0) p.out[eg].flags = (unsigned)(nrib + lastEv + rdt + (int)cct);     // (timing experiment: keep phase B's results alive, skip the rest)
     return;
 #endif
+    // ---- the rest is scalar work per edge: pp_k_cover_finish does it with one lane per edge, from what this wave knows now
+    if (laneFinish && !throwsRef && (wStart <= endTime && wEnd >= endTime) && nrib <= PP_FINISH_MAX && nrib <= p.stride) {
+        if (lane == 0) {
+            PPCoverState* st = p.cover_state + e;
+            st->cct = cct; st->endTime = endTime; st->lastEv = lastEv; st->rdt = rdt; st->flags = flags | (infeasible ? PPGPU_F_INFEASIBLE : 0u);
+            st->nrib = nrib;                                          // (same lane, program order: after the -1 above)
+        }
+        if (lane < nrib) {
+            double* c = p.child + ((size_t)eg * p.stride + lane) * 4;
+            c[0] = rib.sx; c[1] = rib.sy; c[2] = rib.ex; c[3] = rib.ey;
+        }
+        return;
+    }
     // ---- where the loop of Edge.cpp:143-175 stopped
     int steps = 0;
     double ix = srcX, iy = srcY;        // `intermediate` position
@@ -1917,7 +1948,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                 lds[2 * (2 + 2 * lane)] = rib.ex; lds[2 * (2 + 2 * lane) + 1] = rib.ey;
             }
             pp_wave_lds_fence();
-            hdist = pp_h_point_from_pts<PP_TSP_MAX>(p.heuristic, p.tsp_k, p.ribw, lds, nrib);
+            hdist = pp_h_point_from_pts<PP_TSP_MAX>(p.heuristic, p.tsp_k, p.ribw, lds, nrib, 0u, 1u);
             pp_wave_lds_fence();
         }
         if (!leaveToBigPass) {
@@ -2001,7 +2032,7 @@ __global__ __launch_bounds__(PP_WPB * 64, PP_MIN_WAVES) void pp_k_cover_sweep_ga
 // MaxDistance / TspPointRobotNoSplit{All,K}Ribbons from the points staged in the wave's LDS (x,y of the query point, then
 // start / end of every ribbon): distance table, nearest-endpoint table, enumeration.  nrib <= MAXN for the TSP variants.
 template <int MAXN>
-__device__ __forceinline__ double pp_h_point_from_pts(int heuristic, int tsp_k, double ribw, double* lds_wave, int nrib) {
+__device__ __forceinline__ double pp_h_point_from_pts(int heuristic, int tsp_k, double ribw, double* lds_wave, int nrib, unsigned passFirst, unsigned passStride) {
     typedef PPTsp<MAXN> TS;
     const int lane = pp_lane();
     double* pts = lds_wave;
@@ -2020,8 +2051,8 @@ __device__ __forceinline__ double pp_h_point_from_pts(int heuristic, int tsp_k, 
         KM[pp * MAXN + ri] = fmin(pp_h_T<MAXN>(T, pp, 1 + 2 * ri), pp_h_T<MAXN>(T, pp, 2 + 2 * ri));
     }
     pp_wave_lds_fence();
-    if (heuristic == PPGPU_H_TSP_POINT_ALL) return pp_h_tsp_point<MAXN>(T, KM, nrib, ribw, MAXN, false);
-    return pp_h_tsp_point<MAXN>(T, KM, nrib, ribw, tsp_k, true);
+    if (heuristic == PPGPU_H_TSP_POINT_ALL) return pp_h_tsp_point<MAXN>(T, KM, nrib, ribw, MAXN, false, nullptr, passFirst, passStride);
+    return pp_h_tsp_point<MAXN>(T, KM, nrib, ribw, tsp_k, true, nullptr, passFirst, passStride);
 }
 
 
@@ -2130,6 +2161,235 @@ __global__ __launch_bounds__(PP_H_WPB * 64) void pp_k_heuristic_big(PPParams p) 
 }
 
 // ------------------------------------------------------------------------------------------
+// Phase C of the edges the cover sweep's waves handed over (PPCoverState), one LANE per edge: Edge.cpp:177-205 with the expressions
+// of pp_cover_sweep_edge's own phase C (which stays, for the edges a wave keeps: a list longer than PP_FINISH_MAX, the Gaussian
+// model, a curve the reference throws on) — pp_lane_pose for pp_window_pose, the reference's strict cover() ribbon by ribbon in list
+// order for pp_ribbons_event (Ribbon::split / covered, Ribbon.cpp:9-25,39-58: the same projection, containsProjection and distance
+// expressions; the wave decides the distance test on squares and falls back to this very quotient when it is close).
+// Heuristic: a list the lane kernel enumerates is marked PP_H_DEFERRED as the wave would; MaxDistance is computed here; the rare
+// list of 7 or 8 ribbons under a TSP heuristic goes to pp_k_heuristic_listed (a wave per such edge).
+#ifndef PP_FINISH_THREADS
+#define PP_FINISH_THREADS 64
+#endif
+__global__ __launch_bounds__(PP_FINISH_THREADS) void pp_k_cover_finish(PPParams p) {
+    const unsigned nlive = (unsigned)pp_const_i32(p.live_count)[0];
+    const unsigned li = blockIdx.x * PP_FINISH_THREADS + threadIdx.x;
+    if (li >= nlive) return;
+    const long long e = p.ws_base + (long long)p.live_list[2 * (size_t)li];
+    const long long eg = (long long)p.live_list[2 * (size_t)li + 1];
+    const PPCoverState st = p.cover_state[e];
+    if (st.nrib < 0) return;                                   // its wave finished it
+    const PPEdgeSetupBody* S = p.setup + e;
+    const unsigned vi = S->vi;
+    const ppgpu_vertex* V = p.verts + vi;
+    const bool cov = (S->cbits & PPGPU_EDGE_COVERAGE) != 0;
+    const double wStart = S->wStart, wEnd = S->wEnd, speed = S->speed, length = S->length, rho = S->rho, rho_inv = S->rho_inv, qx = S->qx, qy = S->qy;
+    const double hi0 = S->seg[0].hi, hi1 = S->seg[1].hi;
+    const double srcT = V->time;
+    const double endTime0 = fmin(p.horizon + 1e-12 + p.sst, wEnd);    // Edge.cpp:90
+    const double endTime = st.endTime;
+    double cct = st.cct;
+    int nrib = st.nrib, rdt = st.rdt;
+    const int lastEv = st.lastEv;
+    unsigned flags = st.flags;
+    bool infeasible = (flags & PPGPU_F_INFEASIBLE) != 0;
+    const bool startedDone = V->ribbon_count == 0;             // Edge.cpp:93
+    const PPTrackSummary* sum = p.track_summary + e;
+    const int limit = sum->limit, stopKind = sum->blocked;
+    const double* tg = p.tgrid + (size_t)vi * p.ng;
+    const double w = p.ribw;
+
+    // ---- where the loop of Edge.cpp:143-175 stopped
+    int cnt = limit;                                           // steps k < limit with t_k < endTime (the time grid is non-decreasing)
+    if (endTime != endTime0) {
+        int lo = 0, hi = limit;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (tg[mid] < endTime) lo = mid + 1; else hi = mid;
+        }
+        cnt = lo;
+    }
+    int nexec = cnt > lastEv + 1 ? cnt : lastEv + 1;
+    nexec = nexec < limit ? nexec : limit;
+    int steps, hexec, lastIdx;
+    double tfinal;
+    bool coverFinal = true;
+    if (stopKind == 1 && nexec == limit && tg[limit] < endTime) {   // `break` at :146
+        infeasible = true;
+        lastIdx = limit;
+        coverFinal = cov || (((p.track_eq[(size_t)e * p.nch + (limit >> 6)] >> (limit & 63)) & 1ull) != 0ull);
+        tfinal = tg[limit];
+        steps = limit + 1;
+        hexec = limit;
+    } else {
+        if (stopKind == 2 && p.ng > 0 && tg[0] < endTime) infeasible = true;
+        lastIdx = nexec - 1;
+        tfinal = (nexec < p.ng) ? tg[nexec] : INFINITY;
+        steps = nexec;
+        hexec = nexec;
+    }
+    // ---- end state (:177-178) and the pose `intermediate` stopped on
+    double ix = V->x, iy = V->y, uth;
+    bool ignored = false, perr = false;
+    if (lastIdx >= 0) pp_lane_pose(S, tg[lastIdx], wStart, speed, length, rho, rho_inv, qx, qy, hi0, hi1, ix, iy, uth, ignored);
+    double endX, endY;
+    pp_lane_pose(S, endTime, wStart, speed, length, rho, rho_inv, qx, qy, hi0, hi1, endX, endY, uth, perr);
+    if (perr) flags |= PPGPU_F_DUBINS_ERR;
+    const double endHeading = pp_heading_from_yaw(pp_mod2pi(uth));
+    // ---- cover the last little bit (:182-191): RibbonManager::cover(x, y, strict) over the list in order
+    double* c = p.child + (size_t)eg * p.stride * 4;
+    if ((cov || coverFinal) && nrib > 0) {
+        double rsx[PP_FINISH_MAX], rsy[PP_FINISH_MAX], rex[PP_FINISH_MAX], rey[PP_FINISH_MAX];
+#pragma unroll
+        for (int i = 0; i < PP_FINISH_MAX; i++) {
+            const bool have = i < nrib;
+            rsx[i] = have ? c[4 * i] : 0.0; rsy[i] = have ? c[4 * i + 1] : 0.0; rex[i] = have ? c[4 * i + 2] : 0.0; rey[i] = have ? c[4 * i + 3] : 0.0;
+        }
+        const double minLength = 2 * w;                                  // Ribbon::minLength (Ribbon.cpp:52-58)
+        const double thr = minLength * minLength / (2.0 * 2.0);          // covered(strict): c_StrictModifier^2
+        const double T = PP_RIBBON_TOL;
+        int nout = 0;
+#pragma unroll
+        for (int i = 0; i < PP_FINISH_MAX; i++) {
+            if (i < nrib) {
+                const double sx = rsx[i], sy = rsy[i], ex = rex[i], ey = rey[i];
+                const double dxr = ex - sx, dyr = ey - sy;
+                const double sqL = dxr * dxr + dyr * dyr;
+                const double dot = (ix - sx) * dxr + (iy - sy) * dyr;
+                const double px = dxr * dot / sqL + sx;                  // Ribbon::getProjection (Ribbon.cpp:72-78)
+                const double py = dyr * dot / sqL + sy;
+                const double a1 = px - sx, a2 = px - ex, b1 = py - sy, b2 = py - ey;
+                const bool outx = ((a1 < -T) & (a2 < -T)) | ((a1 > T) & (a2 > T));
+                const bool outy = ((b1 < -T) & (b2 < -T)) | ((b1 > T) & (b2 > T));
+                const bool cp = !(outx | outy);                          // Ribbon::containsProjection (:90-95)
+                const double num = dyr * ix - dxr * iy + ex * sy - ey * sx;
+                const bool stc = cp && ((fabs(num) / sqrt(sqL)) < (w / 2.0));   // Ribbon::contains(strict): distance (Ribbon.h:118-121) < w / 2
+                const bool keepF = stc && !(pp_sq_len(sx, sy, px, py) < thr);
+                const bool keepR = stc ? !(pp_sq_len(px, py, ex, ey) < thr) : !(sqL < thr);
+                if (keepF) {
+                    if (nout < p.stride) { c[4 * nout] = sx; c[4 * nout + 1] = sy; c[4 * nout + 2] = px; c[4 * nout + 3] = py; }
+                    nout++;
+                }
+                if (keepR) {
+                    if (nout < p.stride) { c[4 * nout] = stc ? px : sx; c[4 * nout + 1] = stc ? py : sy; c[4 * nout + 2] = ex; c[4 * nout + 3] = ey; }
+                    nout++;
+                }
+            }
+        }
+        // (the slots the handed-over list filled beyond the final one go back to zero: a wave that finishes its own edge never
+        // writes them, and callers hand in zeroed buffers)
+        for (int i = nout; i < nrib; i++) { c[4 * i] = 0.0; c[4 * i + 1] = 0.0; c[4 * i + 2] = 0.0; c[4 * i + 3] = 0.0; }
+        nrib = nout;
+    }
+    if (nrib == 0) {
+        if (cct == -1) cct = tfinal;
+        rdt = (int)tfinal;
+    }
+    // ---- obstacle hits of the executed steps (:150-151 summed)
+    int hitsTotal = 0;
+    if (p.n_obst > 0) {
+        const unsigned* tch = p.track_chunk_hits + (size_t)e * p.nch;
+        const int cfull = hexec >> 6;
+        for (int ch = 0; ch < cfull; ch++) hitsTotal += (int)tch[ch];
+        if ((hexec & 63) != 0 && tch[cfull] != 0u) {
+            if (p.track_skip && (p.track_skip[(size_t)e * p.nch + cfull] & PP_SKIP_ALL) != 0) {
+                hitsTotal += (hexec & 63) * (int)(tch[cfull] >> 6);       // a skipped chunk: the same boxes at every step (no per-step counts)
+            } else {
+                const unsigned short* thits = p.track_hits + (size_t)e * p.ngp;
+                for (int i = cfull << 6; i < hexec; i++) hitsTotal += (int)thits[i];
+            }
+        }
+    }
+    const double penalty = (double)hitsTotal * p.cpf;
+    const double netTime = endTime - srcT;                                        // Edge::netTime
+    double tc = fmax(netTime - ((nrib == 0) ? (endTime - (double)rdt) : 0), 0);  // :197
+    if (startedDone) tc = 0;                                                      // :198
+    const double trueCost = tc * p.tpf + penalty;                                 // :199
+    const double g = V->g + trueCost;                                             // Vertex::setCurrentCost
+    if (infeasible) flags |= PPGPU_F_INFEASIBLE;
+    if (nrib == 0) flags |= PPGPU_F_DONE;
+    {   // SamplingBasedPlanner::goalCondition (SamplingBasedPlanner.cpp:42-50)
+        const double coverageDoneTime = cct + p.tmin;
+        const double nonCoverageDoneTime = p.sst + p.horizon;
+        if (endTime >= nonCoverageDoneTime || (nrib == 0 && endTime >= coverageDoneTime)) flags |= PPGPU_F_GOAL;
+    }
+    if (nrib > PP_TSP_MAX) atomicOr(p.need_big, 1u);
+    if (nrib > p.stride) flags |= PPGPU_F_RIBBON_OVF;
+    // ---- h: Vertex::computeApproxToGo, as the wave decides it
+    double h = 0;
+    bool listed = false;
+    if (p.defer_h && nrib <= p.stride && pp_lane_tsp_ok(p.heuristic, p.tsp_k, nrib)) {
+        h = PP_H_DEFERRED;
+    } else if (p.fuse_h && nrib > 0 && nrib <= p.stride) {
+        const bool tsp = p.heuristic != PPGPU_H_MAX_DISTANCE;
+        if (tsp && nrib > PP_TSP_MAX) {
+            if (!pp_tsp_big_ok(p.heuristic, p.tsp_k, nrib)) flags |= PPGPU_F_RIBBON_OVF;      // else pp_k_heuristic_big fills it in
+        } else if (!tsp) {                                      // MaxDistance (RibbonManager.cpp:234-248), ribbon by ribbon in list order
+            double sumLength = 0, mn = PP_DBL_MAX, mx = 0;
+            for (int i = 0; i < nrib; i++) {
+                const double sx = c[4 * i], sy = c[4 * i + 1], ex = c[4 * i + 2], ey = c[4 * i + 3];
+                sumLength += sqrt(pp_sq_len(sx, sy, ex, ey)) - 2 * p.ribw;
+                const double dStart = pp_dist(sx, sy, endX, endY);
+                const double dEnd = pp_dist(ex, ey, endX, endY);
+                mn = fmin(fmin(mn, dEnd), dStart);
+                mx = fmax(fmax(mx, dEnd), dStart);
+            }
+            h = fmax(sumLength + mn, mx) / p.max_speed * p.tpf;
+        } else {
+            listed = true;                                      // a TSP enumeration the lanes do not take: a wave's work
+        }
+    }
+    ppgpu_edge_result* rec = p.out + eg;
+    double* r = reinterpret_cast<double*>(rec);
+    const unsigned info = (unsigned)(S->type & 0xff) | ((unsigned)(nrib & 0xff) << 8) | ((unsigned)(steps & 0xffff) << 16);
+    r[0] = __hiloint2double((int)info, (int)flags);
+    r[1] = trueCost; r[2] = penalty; r[3] = S->approx;
+    r[4] = endX; r[5] = endY; r[6] = endHeading; r[7] = speed; r[8] = endTime;
+    r[9] = g; r[10] = h; r[11] = (h == PP_H_DEFERRED) ? g : g + h;
+    r[12] = cct; r[13] = S->p0; r[14] = S->p1; r[15] = S->p2;
+    if (listed) p.hw_list[atomicAdd(p.hw_count, 1u)] = (unsigned)eg;
+}
+// The edges pp_k_cover_finish listed (a TSP enumeration of 7 or 8 child ribbons: up to 32 768 leaves): Vertex::computeApproxToGo from
+// the record and the child ribbons, as pp_heuristic_edge does it, by a whole WORKGROUP per edge — its four waves build the
+// same tables, take every fourth pass of 64 prefixes each, and the smallest of their four minima is the minimum (exact).  One wave per
+// edge was ~170 us of a single wave's time for each of config 3's ~1 100 such edges.  A grid as large as pp_k_heuristic keeps
+// resident, striding over the list; usually the list is short or empty.
+__global__ __launch_bounds__(PP_H_WPB * 64, PP_H_MIN_WAVES) void pp_k_heuristic_listed(PPParams p) {
+    __shared__ double lds_all[PP_H_WPB][PPTsp<PP_TSP_MAX>::LDS];
+    __shared__ double s_part[PP_H_WPB];
+    const unsigned n = (unsigned)pp_const_i32(p.hw_count)[0];
+    if (n == 0 || blockIdx.x >= n) return;
+#ifndef PP_LISTED_NO_PRIO
+    __builtin_amdgcn_s_setprio(3);           // few, long waves sharing their SIMDs with pp_k_heuristic_lanes' many short ones: issue first
+#endif
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = pp_lane();
+    double* pts = lds_all[wave];
+    for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+        const long long e = (long long)(unsigned)pp_const_i32(p.hw_list + i)[0];
+        ppgpu_edge_result* rec = p.out + e;
+        const int nrib = (int)((__builtin_amdgcn_readfirstlane((int)rec->info) >> 8) & 0xff);      // 7 or 8 (<= PP_TSP_MAX, <= p.stride)
+        const double endX = rec->end_x, endY = rec->end_y, g = rec->g;
+        if (lane == 0) { pts[0] = endX; pts[1] = endY; }
+        if (lane < nrib) {
+            const double* c = p.child + ((size_t)e * p.stride + lane) * 4;
+            pts[2 * (1 + 2 * lane)] = c[0]; pts[2 * (1 + 2 * lane) + 1] = c[1];
+            pts[2 * (2 + 2 * lane)] = c[2]; pts[2 * (2 + 2 * lane) + 1] = c[3];
+        }
+        pp_wave_lds_fence();
+        const double part = pp_h_point_from_pts<PP_TSP_MAX>(p.heuristic, p.tsp_k, p.ribw, pts, nrib, (unsigned)wave, (unsigned)PP_H_WPB);
+        if (lane == 0) s_part[wave] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double hdist = s_part[0];
+            for (int w = 1; w < PP_H_WPB; w++) hdist = fmin(hdist, s_part[w]);
+            const double h = hdist / p.max_speed * p.tpf;
+            rec->h = h; rec->f = g + h;
+        }
+        __syncthreads();
+    }
+}
+// ------------------------------------------------------------------------------------------
 // The point-robot TSP heuristics with a few LANES per edge instead of a wave (large launches: the cover sweep marks the edge by
 // h = PP_H_DEFERRED and goes on to its next edge).  The enumeration of RibbonManager.cpp:53-94 is a tree walk of lookups, adds and
 // compares; run by a whole wave for one edge (pp_h_tsp_point) most of its instructions are the bookkeeping of spreading prefixes
@@ -2141,8 +2401,8 @@ __global__ __launch_bounds__(PP_H_WPB * 64) void pp_k_heuristic_big(PPParams p) 
 #ifndef PP_HL_SPLIT
 #define PP_HL_SPLIT 4
 #endif
-#define PP_HL_TRI (PP_HL_MAX_N * (2 * PP_HL_MAX_N - 1) + 1)     // doubles per edge: pairs of 2n endpoints (+1: odd stride)
-#define PP_HL_PTS (4 * PP_HL_MAX_N + 1)
+#define PP_HL_TRI(MAXN) ((MAXN) * (2 * (MAXN) - 1) + 1)     // doubles per edge: pairs of 2n endpoints (+1: odd stride)
+#define PP_HL_PTS(MAXN) (4 * (MAXN) + 1)
 struct PPLaneTsp { const double* T; const double* CB; double twoW; int K; bool sortK; unsigned* cnt; };
 // Branch and bound (round 3), exact.  Whatever order the remaining ribbons are visited in, the tour still has to add, for every
 // one of them, its length - 2w and a transition INTO one of its endpoints from an endpoint of another ribbon, which is at least
@@ -2372,31 +2632,18 @@ __global__ __launch_bounds__(256) void pp_k_deferred_list(PPParams p) {
 #ifndef PP_HL_MIN_WAVES
 #define PP_HL_MIN_WAVES 3
 #endif
-__global__ __launch_bounds__(PP_HL_THREADS, PP_HL_MIN_WAVES) void pp_k_heuristic_lanes(PPParams p) {
-    constexpr int PER = PP_HL_THREADS / PP_HL_SPLIT;              // edges per workgroup
-    __shared__ double Tall[PER * PP_HL_TRI];
-    __shared__ double Pall[PER * PP_HL_PTS];
-    __shared__ double CBall[PER * PP_HL_MAX_N];
+// One workgroup's edges: slots [blk * PER, (blk + 1) * PER) of the list of edges with n child ribbons.  MAXN sizes the tables.
+template <int MAXN>
+__device__ __forceinline__ void pp_heuristic_lanes_block(const PPParams& p, const int n, const unsigned blk, const unsigned count,
+                                                         double* Tall, double* Pall, double* CBall) {
     const int tid = threadIdx.x;
-    // which list this workgroup serves: the lists follow one another in whole workgroups
-    // (longest lists first: an edge with 6 ribbons takes four times as long as one with 5, and the workgroups dispatched last
-    // decide how the kernel drains)
-    unsigned blk = blockIdx.x, count = 0;
-    int n = PP_HL_MAX_N;
-    for (; n >= 1; n--) {
-        count = (unsigned)pp_const_i32(p.defer_count + n)[0];
-        const unsigned nblk = (count + (unsigned)PER - 1u) / (unsigned)PER;
-        if (blk < nblk) break;
-        blk -= nblk;
-    }
-    if (n < 1) return;                                            // the grid is sized for "every edge deferred"
-    const unsigned slot = blk * (unsigned)PER + (unsigned)tid / PP_HL_SPLIT;
+    const unsigned slot = blk * (unsigned)(PP_HL_THREADS / PP_HL_SPLIT) + (unsigned)tid / PP_HL_SPLIT;
     const int sub = tid & (PP_HL_SPLIT - 1);
     const bool have = slot < count;
     const long long e = have ? (long long)p.defer_list[(size_t)(n - 1) * (size_t)p.total_edges + slot] : 0;
     ppgpu_edge_result* rec = p.out + e;
-    double* T = Tall + (tid / PP_HL_SPLIT) * PP_HL_TRI;
-    double* P = Pall + (tid / PP_HL_SPLIT) * PP_HL_PTS;
+    double* T = Tall + (tid / PP_HL_SPLIT) * PP_HL_TRI(MAXN);
+    double* P = Pall + (tid / PP_HL_SPLIT) * PP_HL_PTS(MAXN);
     double qx = 0, qy = 0, g = 0;
     if (have) {
         qx = rec->end_x; qy = rec->end_y; g = rec->g;
@@ -2409,7 +2656,7 @@ __global__ __launch_bounds__(PP_HL_THREADS, PP_HL_MIN_WAVES) void pp_k_heuristic
             for (int lo = 0; lo < hi; lo++)
                 T[((hi * (hi - 1)) >> 1) + lo] = pp_dist(P[2 * lo], P[2 * lo + 1], P[2 * hi], P[2 * hi + 1]);
     __syncthreads();
-    double* CB = CBall + (tid / PP_HL_SPLIT) * PP_HL_MAX_N;
+    double* CB = CBall + (tid / PP_HL_SPLIT) * MAXN;
 #if PP_HL_PRUNE
     if (have)
         for (int r = sub; r < n; r += PP_HL_SPLIT) {              // CB[r] = len[r] - 2w + the shortest way into ribbon r from another ribbon
@@ -2420,27 +2667,48 @@ __global__ __launch_bounds__(PP_HL_THREADS, PP_HL_MIN_WAVES) void pp_k_heuristic
         }
     __syncthreads();
 #endif
-    if (!have) return;
-    PPLaneTsp c;
-    c.T = T; c.CB = CB; c.twoW = 2 * p.ribw; c.cnt = p.need_big + 14;
+    if (have) {
+        PPLaneTsp c;
+        c.T = T; c.CB = CB; c.twoW = 2 * p.ribw; c.cnt = p.need_big + 14;
 #ifdef PP_HL_COUNT
-    if ((threadIdx.x & 63) == 0) atomicAdd(p.need_big + 15, n == 6 ? 64u : (n == 5 ? 16u : (n == 4 ? 4u : 1u)));   // last-two-level calls per lane without pruning (K = 2)
+        if ((threadIdx.x & 63) == 0) atomicAdd(p.need_big + 15, n == 6 ? 64u : (n == 5 ? 16u : (n == 4 ? 4u : 1u)));   // last-two-level calls per lane without pruning (K = 2)
 #endif
-    c.sortK = p.heuristic != PPGPU_H_TSP_POINT_ALL;
-    c.K = c.sortK ? p.tsp_k : PP_TSP_MAX;
-    double hdist = 0;
-    switch (n) {
-        case 1: hdist = pp_lane_tsp_root<1>(c, P, qx, qy, sub); break;
-        case 2: hdist = pp_lane_tsp_root<2>(c, P, qx, qy, sub); break;
-        case 3: hdist = pp_lane_tsp_root<3>(c, P, qx, qy, sub); break;
-        case 4: hdist = pp_lane_tsp_root<4>(c, P, qx, qy, sub); break;
-        case 5: hdist = pp_lane_tsp_root<5>(c, P, qx, qy, sub); break;
-        default: hdist = pp_lane_tsp_root<PP_HL_MAX_N>(c, P, qx, qy, sub); break;
+        c.sortK = p.heuristic != PPGPU_H_TSP_POINT_ALL;
+        c.K = c.sortK ? p.tsp_k : PP_TSP_MAX;
+        double hdist = 0;
+        {
+            switch (n) {
+                case 1: hdist = pp_lane_tsp_root<1>(c, P, qx, qy, sub); break;
+                case 2: hdist = pp_lane_tsp_root<2>(c, P, qx, qy, sub); break;
+                case 3: hdist = pp_lane_tsp_root<3>(c, P, qx, qy, sub); break;
+                case 4: hdist = pp_lane_tsp_root<4>(c, P, qx, qy, sub); break;
+                case 5: hdist = pp_lane_tsp_root<5>(c, P, qx, qy, sub); break;
+                default: hdist = pp_lane_tsp_root<PP_HL_MAX_N>(c, P, qx, qy, sub); break;
+            }
+        }
+        const double hh = hdist / p.max_speed * p.tpf;
+        if (sub == 0) { rec->h = hh; rec->f = g + hh; }
     }
-    const double hh = hdist / p.max_speed * p.tpf;
-    if (sub == 0) { rec->h = hh; rec->f = g + hh; }
 }
-
+__global__ __launch_bounds__(PP_HL_THREADS, PP_HL_MIN_WAVES) void pp_k_heuristic_lanes(PPParams p) {
+    constexpr int PER = PP_HL_THREADS / PP_HL_SPLIT;              // edges per workgroup
+    __shared__ double Tall[PER * PP_HL_TRI(PP_HL_MAX_N)];
+    __shared__ double Pall[PER * PP_HL_PTS(PP_HL_MAX_N)];
+    __shared__ double CBall[PER * PP_HL_MAX_N];
+    // which list this workgroup serves: the lists follow one another in whole workgroups
+    // (longest lists first: an edge with 6 ribbons takes four times as long as one with 5, and the workgroups dispatched last
+    // decide how the kernel drains)
+    unsigned blk = blockIdx.x, count = 0;
+    int n = PP_HL_MAX_N;
+    for (; n >= 1; n--) {
+        count = (unsigned)pp_const_i32(p.defer_count + n)[0];
+        const unsigned nblk = (count + (unsigned)PER - 1u) / (unsigned)PER;
+        if (blk < nblk) break;
+        blk -= nblk;
+    }
+    if (n < 1) return;                                            // the grid is sized for "every edge deferred"
+    pp_heuristic_lanes_block<PP_HL_MAX_N>(p, n, blk, count, Tall, Pall, CBall);
+}
 
 // ------------------------------------------------------------------------------------------
 // Dubins lengths from open vertices to every sample, both radii (Edge::computeApproxCost for the

@@ -64,6 +64,8 @@ struct DevBuf {
 struct ppgpu_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t side_stream = nullptr;                 // pp_k_heuristic_listed runs beside the lane heuristic (launch_cost)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool have_cfg = false;
     ppgpu_config cfg{};
     // Map
@@ -98,6 +100,7 @@ struct ppgpu_ctx {
     DevBuf<ppgpu_edge_result> tmp_results;
     DevBuf<double> tmp_child, tmp_lengths, tmp_len_out, int_child;
     bool quiet_finish = true;           // env PPGPU_QUIET_FINISH=0: every edge's phase C stays with its wave
+    bool lane_finish = true;            // env PPGPU_LANE_FINISH=0: every wave of the cover sweep finishes its own edges (tests compare the two)
     bool lane_heuristic = true;         // env PPGPU_LANE_HEURISTIC=0: large launches keep the wave-per-edge enumeration too (tests compare the two)
     long long prepass_min_edges = PP_PREPASS_MIN_EDGES;   // env PPGPU_PREPASS_MIN_EDGES overrides (tests run the prepasses on small launches too)
     size_t slice_bytes = PP_SLICE_BYTES; // workspace budget of one costing slice (env PPGPU_SLICE_BYTES overrides: tests)
@@ -110,7 +113,8 @@ struct ppgpu_ctx {
     DevBuf<unsigned char> track_skip;
     DevBuf<double> track_carry;
     DevBuf<unsigned> need_big;          // [0] need_big, [1 + n] number of deferred edges with n ribbons (pp_k_deferred_list)
-    DevBuf<unsigned> defer_list, live_list;
+    DevBuf<unsigned> defer_list, live_list, hw_list;
+    DevBuf<PPCoverState> cover_state;
     DevBuf<unsigned long long> work;    // queue heads of the resident per-edge grids (PP_Q_*)
     int n_cu = 0;
     int resident[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // workgroups of each per-edge kernel the device holds at once (0 = not asked yet)
@@ -167,10 +171,14 @@ int ppgpu_create(int device, ppgpu_ctx** out) {
     c->n_cu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&c->pinned_counts, 64, hipHostMallocDefault));
     if (const char* pm = std::getenv("PPGPU_PREPASS_MIN_EDGES")) c->prepass_min_edges = std::atoll(pm);
     if (const char* lh = std::getenv("PPGPU_LANE_HEURISTIC")) c->lane_heuristic = std::atoi(lh) != 0;
     if (const char* qf = std::getenv("PPGPU_QUIET_FINISH")) c->quiet_finish = std::atoi(qf) != 0;
+    if (const char* lf = std::getenv("PPGPU_LANE_FINISH")) c->lane_finish = std::atoi(lf) != 0;
     if (const char* sb = std::getenv("PPGPU_SLICE_BYTES")) {
         const long long v = std::atoll(sb);
         if (v > 0) c->slice_bytes = (size_t)v;
@@ -192,11 +200,14 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->ord_blockmin.release(); c->ord_blockcnt.release(); c->ord_bound.release(); c->ord_count.release();
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     c->setup.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
-    c->track_summary.release(); c->track_far.release(); c->track_skip.release(); c->track_carry.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->defer_list.release(); c->live_list.release(); c->work.release(); c->dstage_in.release(); c->dstage_out.release();
+    c->track_summary.release(); c->track_far.release(); c->track_skip.release(); c->track_carry.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->defer_list.release(); c->live_list.release(); c->hw_list.release(); c->cover_state.release(); c->work.release(); c->dstage_in.release(); c->dstage_out.release();
     if (c->pinned_counts) (void)hipHostFree(c->pinned_counts);
     if (c->stage_in) (void)hipHostFree(c->stage_in);
     if (c->stage_out) (void)hipHostFree(c->stage_out);
     for (int r = 0; r < PP_TIMING_RING; r++) for (int i = 0; i < 6; i++) if (c->ev_ring[r][i]) (void)hipEventDestroy(c->ev_ring[r][i]);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PPGPU_OK;
@@ -656,7 +667,7 @@ static void fill_params(ppgpu_ctx* c, PPParams& p) {
     p.cpf = g.collision_penalty_factor; p.tpf = g.time_penalty_factor;
     p.heuristic = g.heuristic; p.tsp_k = g.tsp_k; p.h_rho = g.heuristic_turning_radius;
     p.fuse_h = 0;
-    p.defer_h = 0; p.defer_list = nullptr; p.defer_count = nullptr; p.quiet_finish = 0; p.live_list = nullptr; p.live_count = nullptr;
+    p.defer_h = 0; p.defer_list = nullptr; p.defer_count = nullptr; p.quiet_finish = 0; p.live_list = nullptr; p.live_count = nullptr; p.cover_state = nullptr; p.hw_list = nullptr; p.hw_count = nullptr;
     p.grid = PPGrid{c->grid.p, c->rows, c->cols, c->wpr, c->res, c->res > 0 ? 1.0 / c->res : 0.0, c->rows > 0 ? c->grid_clear.p : nullptr};
     p.obst = c->obst.p; p.n_obst = c->n_obst; p.obst_model = c->obst_model;
     p.verts = c->verts.p; p.ribbons = c->ribbons.p; p.tgrid = c->tgrid.p; p.ng = c->ng; p.nverts = c->nverts;
@@ -823,7 +834,7 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     if (!big) p.track_far = nullptr;
     p.track_pen = c->track_pen.p; p.track_chunk_pen = c->track_chunk_pen.p;
     {
-        int rc = c->need_big.reserve(16, false, c->stream);
+        int rc = c->need_big.reserve(32, false, c->stream);
         if (rc) return rc;
         p.need_big = c->need_big.p;   // cleared by the first slice's pp_k_solve_edges
         if ((rc = c->work.reserve(PP_WORK_WORDS, false, c->stream))) return rc;
@@ -840,10 +851,16 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         if (rc) return rc;
         p.live_list = c->live_list.p; p.live_count = c->need_big.p + 12;
     }
+    if (p.live_list && c->lane_finish && !gaussianSweep) {
+        // phase C of the edges the cover sweep's waves visit: one lane per edge (pp_k_cover_finish)
+        int rc;
+        if ((rc = c->cover_state.reserve((size_t)slice, false, c->stream)) || (rc = c->hw_list.reserve((size_t)total, false, c->stream))) return rc;
+        p.cover_state = c->cover_state.p; p.hw_list = c->hw_list.p; p.hw_count = c->need_big.p + 13;
+    }
     if (p.defer_h) {
         int rc = c->defer_list.reserve((size_t)total * PP_HL_MAX_N, false, c->stream);
         if (rc) return rc;
-        p.defer_list = c->defer_list.p; p.defer_count = c->need_big.p + 1;      // [n] = deferred edges with n ribbons
+        p.defer_list = c->defer_list.p; p.defer_count = c->need_big.p + 16;     // [n] = deferred edges with n ribbons, n = 1 .. PP_HL_MAX_N
     }
     if (c->timing) {                                  // the next set of the ring
         c->ev_slot = (int)(c->ev_launches % PP_TIMING_RING);
@@ -892,6 +909,8 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
             hipLaunchKernelGGL(pp_k_cover_sweep_gaussian, dim3(resident_grid(c, 2, pp_k_cover_sweep_gaussian, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
         else
             hipLaunchKernelGGL(pp_k_cover_sweep, dim3(resident_grid(c, 3, pp_k_cover_sweep, p.n_edges)), dim3(PP_WPB * 64), 0, c->stream, p);
+        if (p.cover_state)       // (the list's length is on the device: a grid for "every edge of the slice is on it", whose spare workgroups leave at once)
+            hipLaunchKernelGGL(pp_k_cover_finish, dim3((unsigned)((p.n_edges + PP_FINISH_THREADS - 1) / PP_FINISH_THREADS)), dim3(PP_FINISH_THREADS), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     }
 #ifdef PP_DBG_QUIET
@@ -955,14 +974,26 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         hipLaunchKernelGGL(pp_k_heuristic_dubins, dim3(resident_grid(c, 4, pp_k_heuristic_dubins, total)), dim3(PP_H_WPB * 64), 0, c->stream, p);
     else if (!p.fuse_h)
         hipLaunchKernelGGL(pp_k_heuristic, dim3(resident_grid(c, 5, pp_k_heuristic, total)), dim3(PP_H_WPB * 64), 0, c->stream, p);
-    if (p.defer_h) {        // the edges whose sweep left their ribbons untouched: packed, then one lane each
-        hipLaunchKernelGGL(pp_k_deferred_list, dim3((unsigned)((total + 256 * PP_DL_PER - 1) / (256 * PP_DL_PER))), dim3(256), 0, c->stream, p);
-        hipLaunchKernelGGL(pp_k_heuristic_lanes, dim3((unsigned)((total * PP_HL_SPLIT + PP_HL_THREADS - 1) / PP_HL_THREADS) + PP_HL_MAX_N), dim3(PP_HL_THREADS), 0, c->stream, p);
+    // The edges whose TSP enumeration the sweeps deferred: packed into one list per ribbon count, then a few lanes each
+    // (pp_k_heuristic_lanes).  The rare edge pp_k_cover_finish left to a whole wave (pp_k_heuristic_listed: 7 or 8 child ribbons,
+    // ~1 100 of config 3's 236 140 edges, each a single wave's work for ~170 us) runs on a second stream BESIDE it: the lane kernel
+    // fills the rest of the machine meanwhile, and the two touch different records.  The main stream waits for the side stream
+    // before the launch is over.
+    const bool forked = p.cover_state && p.fuse_h && p.heuristic != PPGPU_H_MAX_DISTANCE;
+    if (forked) {
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        // (as many workgroups as pp_k_heuristic keeps resident: same footprint; all but a few leave at once)
+        hipLaunchKernelGGL(pp_k_heuristic_listed, dim3(resident_grid(c, 5, pp_k_heuristic, total)), dim3(PP_H_WPB * 64), 0, c->side_stream, p);
+        HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
     }
+    if (p.defer_h)
+        hipLaunchKernelGGL(pp_k_deferred_list, dim3((unsigned)((total + 256 * PP_DL_PER - 1) / (256 * PP_DL_PER))), dim3(256), 0, c->stream, p);
+    if (p.defer_h)
+        hipLaunchKernelGGL(pp_k_heuristic_lanes, dim3((unsigned)((total * PP_HL_SPLIT + PP_HL_THREADS - 1) / PP_HL_THREADS) + PP_HL_MAX_N), dim3(PP_HL_THREADS), 0, c->stream, p);
     // child lists of 9..12 ribbons under the K variant: a second pass that touches only those edges (the others cost it one
     // 8-byte read each)
-    if (p.heuristic == PPGPU_H_TSP_POINT_K)
-        {
+    if (p.heuristic == PPGPU_H_TSP_POINT_K) {
         const long long need = (total + PP_H_WPB - 1) / PP_H_WPB;
         hipLaunchKernelGGL(pp_k_heuristic_big, dim3((unsigned)(need < PP_BIG_GRID ? need : PP_BIG_GRID)), dim3(PP_H_WPB * 64), 0, c->stream, p);
     }
@@ -972,9 +1003,13 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         unsigned cnt[2];
         HIP_TRY(hipMemcpy(cnt, c->need_big.p + 14, sizeof(cnt), hipMemcpyDeviceToHost));
         std::fprintf(stderr, "[lane tsp] last-two-level calls per wave: %u of %u without pruning\n", cnt[0], cnt[1]);
+        unsigned hw = 0;
+        HIP_TRY(hipMemcpy(&hw, c->need_big.p + 13, sizeof(hw), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[finish] edges left to pp_k_heuristic_listed: %u\n", hw);
         HIP_TRY(hipMemset(c->need_big.p + 14, 0, 2 * sizeof(unsigned)));
     }
 #endif
+    if (forked) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     c->last_launch_edges = total; c->last_launch_packed = p.live_list != nullptr;
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], c->stream)); c->ev_launches++; }
     HIP_TRY(hipGetLastError());
@@ -1096,7 +1131,7 @@ int ppgpu_heuristic_host(ppgpu_ctx* c, int32_t n, const double* poses3, const in
         off += (size_t)counts[i];
     }
     if ((rc = c->tmp_results.reserve((size_t)n, false, c->stream)) || (rc = c->tmp_child.reserve(child.size(), false, c->stream)) ||
-        (rc = c->need_big.reserve(16, false, c->stream)) || (rc = c->work.reserve(PP_WORK_WORDS, false, c->stream)))
+        (rc = c->need_big.reserve(32, false, c->stream)) || (rc = c->work.reserve(PP_WORK_WORDS, false, c->stream)))
         return rc;
     HIP_TRY(hipMemsetAsync(c->work.p, 0, (size_t)PP_WORK_WORDS * sizeof(unsigned long long), c->stream));   // queue heads (no solve kernel runs here)
     HIP_TRY(hipMemcpyAsync(c->tmp_results.p, rec.data(), rec.size() * sizeof(ppgpu_edge_result), hipMemcpyHostToDevice, c->stream));

@@ -296,6 +296,68 @@ def test_sampler_continuation_skip_and_ribbonless(torch_cuda):
         assert np.array_equal(ctx.get_samples()[:, :3], world.add_samples(w.bounds6, seed, w.ribbons4, 0, 300)[:, :3])
 
 
+@pytest.mark.parametrize("heur", ["max", "all", "k"])
+def test_lane_finish_is_the_wave_finish(torch_cuda, monkeypatch, heur):
+    """Large launches hand the edges the cover sweep's waves visited to pp_k_cover_finish — one lane per edge for the rest of
+    computeTrueCost (Edge.cpp:177-205: where the loop stopped, the end state, the last cover, the hit sums, the cost, the record) —
+    and the few child lists of 7 or 8 ribbons to pp_k_heuristic_listed.  PPGPU_LANE_FINISH=0 keeps every edge with its wave: the
+    same bytes either way (records and child ribbons), on config 3 and on a world whose edges cross several ribbons."""
+    from path_planner_amd import api, workloads
+    from path_planner_amd.types import H_MAX_DISTANCE, H_TSP_POINT_ALL, H_TSP_POINT_K, make_config
+    from path_planner_amd.workloads import root_vertex
+    hsel = {"max": (H_MAX_DISTANCE, 2), "all": (H_TSP_POINT_ALL, 0), "k": (H_TSP_POINT_K, 2)}[heur]
+    w = workloads.config3(n_samples=4096)
+    w.cfg.heuristic, w.cfg.tsp_k = hsel
+    rng = np.random.default_rng(77)
+    cfg2 = make_config(start_state_time=2.0, heuristic=hsel[0], tsp_k=hsel[1])
+    rib2 = np.asarray([[40 + 9 * i, 50 + 5 * (i % 3), 44 + 9 * i + 3 * (i % 2), 96 - 4 * (i % 4)] for i in range(4)], dtype=np.float64)
+    root2 = root_vertex(70.0, 30.0, 0.3, 2.5, 2.0, rib2)
+    n2 = 3000
+    sx, sy, sh = rng.uniform(20, 130, n2), rng.uniform(20, 130, n2), rng.uniform(0, 2 * np.pi, n2)
+    outs = []
+    for lanes in ("1", "0"):
+        monkeypatch.setenv("PPGPU_LANE_FINISH", lanes)
+        monkeypatch.delenv("PPGPU_PREPASS_MIN_EDGES", raising=False)      # the production route of large launches
+        ctx = api.Context(0)
+        ctx.set_config(w.cfg); ctx.set_grid(w.grid, w.res); ctx.set_obstacles(w.obst); ctx.set_vertices(w.root(), w.ribbons4)
+        ctx.sampler_init(w.bounds6, w.seed, w.ribbons4)
+        n = ctx.sampler_add(w.n_samples)
+        a = _dense(torch_cuda, ctx, 1, n, 0xF, stride=10)
+        ctx2 = api.Context(0)
+        ctx2.set_config(cfg2); ctx2.set_grid(None, 0.5); ctx2.set_obstacles(None); ctx2.set_vertices(root2, rib2)
+        ctx2.set_samples(sx, sy, sh)
+        b = _dense(torch_cuda, ctx2, 1, n2, 0xF, stride=10)
+        outs.append((a, b))
+    for k in range(2):
+        assert outs[0][k][0].tobytes() == outs[1][k][0].tobytes(), "records differ"
+        assert outs[0][k][1].tobytes() == outs[1][k][1].tobytes(), "child ribbons differ"
+    nr = (outs[0][1][0]["info"] >> 8) & 255
+    print(heur, "child ribbon counts (second world)", np.bincount(nr))
+
+
+def test_sampler_largest_batch_and_tile_edges(torch_cuda):
+    """The sampler's scans work in tiles (2 048 stream slots, 256 candidates per workgroup) and every workgroup adds up the tiles
+    before it for itself: the largest batch one call takes (524 288 attempts: 1 536 slot tiles, 2 048 candidate workgroups), a batch
+    that ends exactly on tile edges and tiny ones, against the oracle's sequential generator, continuing one stream."""
+    from path_planner_amd import api, workloads
+    import oracle as orc
+    w = workloads.config2()
+    ctx = api.Context(0)
+    ctx.set_config(w.cfg)
+    ctx.set_grid(w.grid, w.res)
+    world = orc.World(w.cfg, w.grid, w.res, None)
+    ctx.sampler_init(w.bounds6, 4242, w.ribbons4)
+    done = 0
+    for n in (524288, 2048, 256, 1, 255, 257, 4097):
+        ctx.sampler_add(n)
+        done += n
+    cs = world.add_samples(w.bounds6, 4242, w.ribbons4, 0, done)
+    gs = ctx.get_samples()
+    assert len(gs) == len(cs) and np.array_equal(gs[:, :3], cs[:, :3])
+    with pytest.raises(Exception):
+        ctx.sampler_add(524289)                                   # over the documented limit: refused, not truncated
+
+
 def test_full_size_properties_config3(torch_cuda):
     """BASELINE.json's full size (65 536 attempts, 2048^2 grid, 16 obstacles): properties that need no oracle, plus
     an oracle spot check of a strided subset."""
