@@ -1081,6 +1081,25 @@ __device__ __forceinline__ int pp_event_stride(double D, double inc_d, double in
 // vertex's ribbons.  The lane does that too (pp_finish_quiet_edge: phase C of pp_cover_sweep_edge, the same expressions, for the
 // case "no event changed anything") and marks the edge PP_FAR_DONE; the cover sweep's wave then drops it at once.  Nearly half
 // the edges of config 3.
+// One ribbon's part of a coverage event at (x, y), lane form (the expressions of pp_k_cover_finish / pp_ribbons_event): does the ribbon
+// contain the point (RibbonManager::minDistanceFrom then returns 0) and does it contain it strictly (cover() would split it)?
+// Only called for a ribbon whose grown bounding box holds the point; outside it neither can be.
+__device__ __forceinline__ void pp_lane_ribbon_contains(double sx, double sy, double ex, double ey, double x, double y, double w, bool& inside, bool& strict) {
+    const double T = PP_RIBBON_TOL;
+    const double dxr = ex - sx, dyr = ey - sy;
+    const double sqL = dxr * dxr + dyr * dyr;
+    const double dot = (x - sx) * dxr + (y - sy) * dyr;
+    const double px = dxr * dot / sqL + sx;                  // Ribbon::getProjection (Ribbon.cpp:72-78)
+    const double py = dyr * dot / sqL + sy;
+    const double a1 = px - sx, a2 = px - ex, b1 = py - sy, b2 = py - ey;
+    const bool outx = ((a1 < -T) & (a2 < -T)) | ((a1 > T) & (a2 > T));
+    const bool outy = ((b1 < -T) & (b2 < -T)) | ((b1 > T) & (b2 > T));
+    const bool cp = !(outx | outy);                          // Ribbon::containsProjection (:90-95)
+    const double num = dyr * x - dxr * y + ex * sy - ey * sx;
+    const double ld = fabs(num) / sqrt(sqL);                 // Ribbon::distance (Ribbon.h:118-121)
+    inside = cp && (ld < w);
+    strict = cp && (ld < (w / 2.0));
+}
 #define PP_FAR_DONE (-2)
 __device__ __forceinline__ void pp_lane_pose(const PPEdgeSetupBody* S, double t, double wStart, double speed, double length, double rho, double rho_inv,
                                              double qx, double qy, double hi0, double hi1, double& x, double& y, double& uth, bool& err) {
@@ -1225,6 +1244,9 @@ __device__ __forceinline__ bool pp_finish_quiet_edge(const PPParams& p, const PP
 #ifndef PP_APPROACH_THREADS
 #define PP_APPROACH_THREADS 256
 #endif
+#ifndef PP_LANE_NEAR_MAX
+#define PP_LANE_NEAR_MAX 8
+#endif
 #ifndef PP_APPROACH_MAX_EVENTS
 #define PP_APPROACH_MAX_EVENTS 0     // > 0: a lane hands its edge to the wave after this many approach events (bounds the kernel's tail)
 #endif
@@ -1288,6 +1310,16 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
             for (int i = 0; i < nrib; i++) tiny |= pp_sq_len(rp[4 * i], rp[4 * i + 1], rp[4 * i + 2], rp[4 * i + 3]) < minLength0 * minLength0 / (2.0 * 2.0);
             int k = 0, lastEv = -1;
             bool handOver = tiny;               // the wave has events to visit (or an error to flag)
+#ifndef PP_NO_LANE_NEAR
+            // Round 3: an event within reach of ONE ribbon is no longer handed over at once.  The lane takes it exactly (does that
+            // ribbon contain the point, strictly or not: the reference's own expressions) and goes on while it changes nothing — the
+            // vehicle passes near a ribbon, or travels inside a corridor before it reaches the strict one, or may not cover while it
+            // turns: what the wave used to start with (one event and one quiet run, two of a slow edge's nine operations).  At most
+            // PP_LANE_NEAR_MAX such events per edge (a crawl along a corridor is the wave's, 64 steps at a time); within reach of
+            // two ribbons at once the wave takes over as before.
+            int nearBudget = PP_LANE_NEAR_MAX;
+            const bool covEdge = (S->cbits & PPGPU_EDGE_COVERAGE) != 0;
+#endif
 #if PP_APPROACH_MAX_EVENTS > 0
             int budget = PP_APPROACH_MAX_EVENTS;
 #endif
@@ -1311,6 +1343,7 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
                 pp_curve_seg(g->type, (tprime - g->o1) - g->o2, g->bx, g->by, g->bth, g->sb, g->cb, ux, uy, uth);
                 const double x = ux * rho + qx, y = uy * rho + qy;
                 bool inBox = false;
+                int boxCount = 0, boxIdx = 0;
                 double q = PP_DBL_MAX;
 #ifndef PP_APPROACH_NO_UNIFORM_RIBBONS
                 if (oneVertex) {
@@ -1319,7 +1352,8 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
                     const PP_AS4 double* ru = pp_const_f64(rpU);
                     for (int i = 0; i < nribU; i++) {
                         const double sx = ru[4 * i], sy = ru[4 * i + 1], ex = ru[4 * i + 2], ey = ru[4 * i + 3];
-                        inBox |= (x >= fmin(sx, ex) - grow) & (x <= fmax(sx, ex) + grow) & (y >= fmin(sy, ey) - grow) & (y <= fmax(sy, ey) + grow);
+                        const bool in = (x >= fmin(sx, ex) - grow) & (x <= fmax(sx, ex) + grow) & (y >= fmin(sy, ey) - grow) & (y <= fmax(sy, ey) + grow);
+                        inBox |= in; boxCount += in ? 1 : 0; boxIdx = in ? i : boxIdx;
                         const double qS = (sx - x) * (sx - x) + (sy - y) * (sy - y);
                         const double qE = (ex - x) * (ex - x) + (ey - y) * (ey - y);
                         q = fmin(q, fmin(qE, qS));
@@ -1328,7 +1362,8 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
 #endif
                 for (int i = 0; i < nrib; i++) {
                     const double sx = rp[4 * i], sy = rp[4 * i + 1], ex = rp[4 * i + 2], ey = rp[4 * i + 3];
-                    inBox |= (x >= fmin(sx, ex) - grow) & (x <= fmax(sx, ex) + grow) & (y >= fmin(sy, ey) - grow) & (y <= fmax(sy, ey) + grow);
+                    const bool in = (x >= fmin(sx, ex) - grow) & (x <= fmax(sx, ex) + grow) & (y >= fmin(sy, ey) - grow) & (y <= fmax(sy, ey) + grow);
+                    inBox |= in; boxCount += in ? 1 : 0; boxIdx = in ? i : boxIdx;
                     const double qS = (sx - x) * (sx - x) + (sy - y) * (sy - y);
                     const double qE = (ex - x) * (ex - x) + (ey - y) * (ey - y);
                     q = fmin(q, fmin(qE, qS));
@@ -1336,8 +1371,24 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
 #ifdef PP_DBG_TRACE
                 if (pp_edge_position(p, p.e_base + e) == (long long)(PP_DBG_TRACE)) printf("[lane] event %d: inBox %d q %.17g x %.17g y %.17g\n", k, (int)inBox, q, x, y);
 #endif
-                if (inBox) { handOver = true; break; }                                  // within reach of a ribbon: the wavefront takes over here
-                const double D = fmin(PP_DBL_MAX, sqrt(q));
+                double D = fmin(PP_DBL_MAX, sqrt(q));
+                if (inBox) {
+#ifndef PP_NO_LANE_NEAR
+                    if (boxCount == 1 && nearBudget-- > 0) {
+                        bool inside, strict;
+                        pp_lane_ribbon_contains(rp[4 * boxIdx], rp[4 * boxIdx + 1], rp[4 * boxIdx + 2], rp[4 * boxIdx + 3], x, y, w, inside, strict);
+                        // Edge.cpp:159: cover() runs when coverage is allowed on this edge or the heading did not change since the last step
+                        const bool coverOn = covEdge || (((p.track_eq[(size_t)(p.ws_base + e) * p.nch + (k >> 6)] >> (k & 63)) & 1ull) != 0ull);
+                        if (!(strict && coverOn)) {
+                            if (inside) D = 0;                                          // RibbonManager::minDistanceFrom: contained
+                            lastEv = k;
+                            k = k + pp_event_stride(D, p.inc_d, p.inv_inc_d, p.ng) + 1;
+                            continue;
+                        }
+                    }
+#endif
+                    handOver = true; break;                                             // a ribbon changes here (or two are in reach, or the budget is spent): the wavefront takes over
+                }
                 lastEv = k;
                 k = k + pp_event_stride(D, p.inc_d, p.inv_inc_d, p.ng) + 1;
             }
