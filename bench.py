@@ -275,7 +275,7 @@ def run_rank(args):
 
     if rank == 0:
         solve_ms, pose_ms, cover_ms, heur_ms = [float(x) for x in np.mean(np.array(kernel_events), axis=0)]
-        kern_ms = cover_ms                                               # pp_k_cover_sweep, the dominant kernel
+        kern_ms = cover_ms                                               # pp_k_cover_sweep (+ pp_k_cover_finish, its lane-per-edge second half), the dominant kernel
         launch_ms = solve_ms + pose_ms + cover_ms + heur_ms
         res = d_res.cpu().numpy().view(RESULT_DTYPE)[: edges // args.steps]
         n_edges_launch = len(res)
@@ -346,14 +346,14 @@ def run_rank(args):
                          "achieved_is": "SURVEY 8(d): algorithmic flops per edge F (model of the reference's arithmetic with the measured mean step count) "
                                         "x edges of one costing launch / the launch's kernel time, measured live with HIP events between the kernels",
                          "algorithmic_flops_per_edge": flops_per_edge,
-                         "kernel": "the costing launch (pp_k_solve_edges .. pp_k_heuristic_lanes); dominant kernel pp_k_cover_sweep",
+                         "kernel": "the costing launch (pp_k_solve_edges .. pp_k_heuristic_lanes); dominant kernel pp_k_cover_sweep (kernel_ms includes pp_k_cover_finish, which ends its edges one lane each)",
                          "launch_ms": launch_ms, "kernel_ms": kern_ms, "edges_in_kernel": cover_edges,
-                         "kernels_ms": {"pp_k_solve_edges": solve_ms, "pp_k_plan_skips+pp_k_pose_sweep": pose_ms, "pp_k_cover_sweep": cover_ms,
+                         "kernels_ms": {"pp_k_solve_edges": solve_ms, "pp_k_plan_skips+pp_k_pose_sweep": pose_ms, "pp_k_cover_sweep+pp_k_cover_finish": cover_ms,
                                         "others": heur_ms},
                          "kernels_note": "HIP events between the kernels of each costing launch of the timed region (last 8 steps); "
                                          "'others' = pp_k_approach_events (finishes the edges whose coverage state machine has nothing to do: "
-                                         "edges_in_kernel is what is left for the cover sweep) + pp_k_deferred_list + pp_k_heuristic_lanes + "
-                                         "pp_k_heuristic_big; the four add up to the launch",
+                                         "edges_in_kernel is what is left for the cover sweep) + pp_k_deferred_list + pp_k_heuristic_lanes (beside it, on a second stream, "
+                                         "pp_k_heuristic_listed) + pp_k_heuristic_big; the four add up to the launch",
                          "traffic": traffic,
                          "traffic_is": ("PMC bytes per costing launch from profiles/traffic.json, measured on these kernel sources"
                                         if traffic is not None else "null: no PMC pass on these kernel sources (tools/traffic.sh)"),

@@ -38,8 +38,8 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
 dom = out["kernels"].get("pp_k_cover_sweep", {})
 out["dominant_kernel"] = "pp_k_cover_sweep"
 out["hbm_bytes_per_launch"] = dom.get("fetch_size_bytes", 0.0) + dom.get("write_size_bytes", 0.0)
-COSTING = ("pp_k_solve_edges", "pp_k_plan_skips", "pp_k_pose_sweep", "pp_k_approach_events", "pp_k_cover_sweep", "pp_k_deferred_list", "pp_k_heuristic_lanes",
-           "pp_k_heuristic_big")
+COSTING = ("pp_k_solve_edges", "pp_k_plan_skips", "pp_k_pose_sweep", "pp_k_approach_events", "pp_k_cover_sweep", "pp_k_cover_finish", "pp_k_deferred_list",
+           "pp_k_heuristic_lanes", "pp_k_heuristic_listed", "pp_k_heuristic_big")
 out["costing_kernels"] = list(COSTING)
 out["hbm_bytes_per_costing_launch"] = sum(out["kernels"].get(k, {}).get("fetch_size_bytes", 0.0) + out["kernels"].get(k, {}).get("write_size_bytes", 0.0) for k in COSTING)
 import hashlib
