@@ -851,7 +851,12 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         if (rc) return rc;
         p.live_list = c->live_list.p; p.live_count = c->need_big.p + 12;
     }
-    if (p.live_list && c->lane_finish && !gaussianSweep) {
+#if defined(PP_DBG_COUNTS) || defined(PP_DBG_EVENTS) || defined(PP_ABL_ONLY_EVENTS) || defined(PP_NO_LANE_FINISH)
+    const bool laneFinishBuilt = false;     // (those builds keep every edge with its wave: pp_cover_sweep_edge)
+#else
+    const bool laneFinishBuilt = true;
+#endif
+    if (laneFinishBuilt && p.live_list && c->lane_finish && !gaussianSweep) {
         // phase C of the edges the cover sweep's waves visit: one lane per edge (pp_k_cover_finish)
         int rc;
         if ((rc = c->cover_state.reserve((size_t)slice, false, c->stream)) || (rc = c->hw_list.reserve((size_t)total, false, c->stream))) return rc;
