@@ -38,7 +38,14 @@ def parse_args():
     ap.add_argument("--total", type=int, default=262144, help="sample attempts per step over all GPUs with --strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--open-vertex-run", action="store_true",
-                    help="also time the 64-open-vertex x 4096-sample launch of SURVEY config 3 (extra launches: not in profiled runs)")
+                    help="(default since round 4) also time the 64-open-vertex x 4096-sample launch of SURVEY config 3; "
+                         "PP_BENCH_PROFILED=1 (set by the rocprofv3 tools) leaves it and the plan()-level legs out")
+    ap.add_argument("--no-plan-level", action="store_true", help="skip the 10 Hz replan loop (config 5) and the plan()-level CPU baseline")
+    ap.add_argument("--replan-cycles", type=int, default=100)
+    ap.add_argument("--as-rank", type=int, default=None, metavar="R",
+                    help="one GPU, no communicator: time the step exactly as rank R of --of N would run it (its slice of the batch, "
+                         "the sampler skip over the lower ranks' slices included).  A projection of the worst rank's step, not a scaling curve")
+    ap.add_argument("--of", type=int, default=8, metavar="N")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched ranks are stopped after this many seconds")
     return ap.parse_args()
 
@@ -156,9 +163,13 @@ def run_rank(args):
 
     w = workloads.config3()
     B = args.batch                                  # attempts per GPU per step (weak scaling: the default)
-    total_attempts = args.total if args.strong else B * world
+    # --as-rank R --of N: this one process plays rank R of an N-rank job (no communicator, no collective)
+    emu_rank, emu_world = (args.as_rank, args.of) if args.as_rank is not None else (rank, world)
+    if args.as_rank is not None and (world != 1 or not (0 <= emu_rank < emu_world)):
+        raise SystemExit("bench.py: --as-rank R --of N needs --gpus 1 and 0 <= R < N")
+    total_attempts = args.total if args.strong else B * emu_world
     if args.strong:
-        B = -(-total_attempts // world)             # the largest shard
+        B = -(-total_attempts // emu_world)         # the largest shard
     stream = torch.cuda.Stream(dev)          # a real (non-null) stream shared by the kernels, torch events and RCCL
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
@@ -176,13 +187,13 @@ def run_rank(args):
     def step(out=None):
         out = d_res if out is None else out
         ctx.sampler_init(w.bounds6, w.seed, w.ribbons4)
-        lo, hi = sharding.shard_attempts(total_attempts, rank, world)   # this rank's slice of the iteration's batch
+        lo, hi = sharding.shard_attempts(total_attempts, emu_rank, emu_world)   # this rank's slice of the iteration's batch
         if lo:
             ctx.sampler_skip(lo)
         n = ctx.sampler_add(hi - lo)
         ne = 4 * n
         ctx.cost_edges_dense(0, 1, 0, n, 0xF, out.data_ptr())
-        ctx.best_edge(ne, out.data_ptr(), d_key2.data_ptr(), goal_only=False, base=sharding.edge_index_base(rank, max_edges))
+        ctx.best_edge(ne, out.data_ptr(), d_key2.data_ptr(), goal_only=False, base=sharding.edge_index_base(emu_rank, max_edges))
         if rehearsal:
             mine = d_key2.cpu()
             allk = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
@@ -311,6 +322,18 @@ def run_rank(args):
                              "frac_of_peak": nbytes / (pose_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             except Exception:
                 traffic = per_kernel = sweep_hbm = None
+        # counter-anchored utilisation: profiles/valu.json from its own rocprofv3 --pmc pass (tools/valu.sh),
+        # stamped with the kernel sources it was measured on
+        valu = None
+        vp = os.path.join(ROOT, "profiles", "valu.json")
+        if os.path.exists(vp):
+            try:
+                vj = json.load(open(vp))
+                if vj.get("kernel_sources_sha256") != kernel_sources_sha256():
+                    raise ValueError("profiles/valu.json was measured on other kernel sources")
+                valu = vj
+            except Exception:
+                valu = None
         key = d_key2.cpu().numpy().view(np.uint64)
         alg_bytes_launch = bytes_per_edge * n_edges_launch
         out = {
@@ -344,7 +367,15 @@ def run_rank(args):
                        "sharding": "sample batch split by rank; one RCCL collective per iteration (ppgpu_allreduce_best: all-gather of 16 B per rank + local min)"},
             "roofline": {"bound": "fp64_valu", "achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TFLOPS,
                          "achieved_is": "SURVEY 8(d): algorithmic flops per edge F (model of the reference's arithmetic with the measured mean step count) "
-                                        "x edges of one costing launch / the launch's kernel time, measured live with HIP events between the kernels",
+                                        "x edges of one costing launch / the launch's kernel time, measured live with HIP events between the kernels.  "
+                                        "F counts what the REFERENCE does per edge; the kernels skip chunks and cull obstacles exactly, so frac is not "
+                                        "hardware utilisation and can exceed 1 - valu_issue_frac (counters) is the utilisation figure",
+                         "valu_issue_frac": (valu or {}).get("valu_issue_frac"),
+                         "executed_to_model_flops": ((valu["executed_lane_ops_per_launch"] / (flops_per_edge * n_edges_launch)) if valu else None),
+                         "valu_is": ("profiles/valu.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES ... on these kernel sources, tools/valu.sh): "
+                                     "valu_issue_frac = sum over the costing kernels of SQ_ACTIVE_INST_VALU / (4 SIMDs x SQ_BUSY_CU_CYCLES); executed = "
+                                     "SQ_INSTS_VALU x 64 lanes, an upper bound of the lanes doing arithmetic" if valu else "null: no VALU counter pass on these kernel sources (tools/valu.sh)"),
+                         "valu_per_kernel": (valu or {}).get("kernels"),
                          "algorithmic_flops_per_edge": flops_per_edge,
                          "kernel": "the costing launch (pp_k_solve_edges .. pp_k_heuristic_lanes); dominant kernel pp_k_cover_sweep (kernel_ms includes pp_k_cover_finish, which ends its edges one lane each)",
                          "launch_ms": launch_ms, "kernel_ms": kern_ms, "edges_in_kernel": cover_edges,
@@ -373,11 +404,18 @@ def run_rank(args):
                                "kernel_edges_per_s": n_edges_launch / (launch_ms * 1e-3),
                                "best_f": float(np.array([key[0]], dtype=np.uint64).view(np.float64)[0]), "best_edge": int(key[1])},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        profiled = os.environ.get("PP_BENCH_PROFILED") == "1"     # under rocprofv3 (tools/*.sh): only the headline launches
+        if args.as_rank is not None:
+            out["as_rank"] = {"rank": emu_rank, "of": emu_world, "attempts_skipped_per_step": sharding.shard_attempts(total_attempts, emu_rank, emu_world)[0],
+                              "note": "ONE GPU playing rank R of N: its slice of the batch and the sampler skip over the lower ranks' slices, no "
+                                      "communicator, no collective.  A projection of that rank's step time, not a measured scaling curve"}
+        if world == 1 and not args.no_cpu_baseline and args.as_rank is None:
             out.update(cpu_baseline_and_parity(ctx, w, res))
             out.update(first_goal_check())
-        if world == 1 and args.open_vertex_run:
+        if world == 1 and not profiled and args.as_rank is None:
             out.update(open_vertex_run(ctx, w, torch, dev))
+        if world == 1 and not profiled and not args.no_plan_level and args.as_rank is None:
+            out.update(plan_level(args.replan_cycles, cpu_baseline=not args.no_cpu_baseline))
         print(json.dumps(out), flush=True)
     if world > 1 or use_comm:
         dist.barrier()
@@ -387,11 +425,15 @@ def run_rank(args):
         dist.destroy_process_group()
 
 
+# the device sources (path_planner_amd/csrc): what a PMC measurement is stamped with
+KERNEL_SOURCES = ("ppgpu.hip", "pp_kernels.h", "pp_device.h", "pp_sampler.h", "pp_cr.h", "pp_cr_tables.h")
+
+
 def kernel_sources_sha256():
-    """Identity of the kernel sources a PMC measurement belongs to (profiles/traffic.json carries the same stamp)."""
+    """Identity of the kernel sources a PMC measurement belongs to (profiles/traffic.json and profiles/valu.json carry the same stamp)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("ppgpu.hip", "pp_kernels.h", "pp_device.h", "pp_sampler.h", "pp_cr.h", "pp_cr_tables.h"):
+    for f in KERNEL_SOURCES:
         h.update(open(os.path.join(ROOT, "path_planner_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
@@ -484,6 +526,68 @@ def cpu_baseline_and_parity(ctx, w, gpu_res):
                                  "built -O0, the reference's default build type, on the first 2048 edges"},
         "parity": {"ok": rep["ok"], "edges_checked": rep["n"], "flags_equal": rep["flags_equal"], "worst_rel": rep["worst_rel"]},
     }
+
+
+def plan_level(cycles, cpu_baseline=True):
+    """SURVEY 8(d) config 5 and the plan()-level view of the path: the 10 Hz anytime replan loop through
+    the C++ host planner (path_planner_amd/host/plan_cli: GpuAStarPlanner::plan behind the reference's Planner::plan seam, every edge
+    costed on the GPU) — config-3 grid, 32 moving obstacles uniform in the map, 100 ms budget per cycle, 8 192 initial samples doubling,
+    the start advanced 0.1 s along the returned plan, the plan handed back as previousPlan — and, as the CPU baseline of the SAME seam,
+    the oracle's restatement of AStarPlanner::plan given the same wall budget on one host core (the reference plans on one thread).
+    After the timed region, never part of `value`."""
+    import subprocess
+    import tempfile
+    try:
+        from path_planner_amd import workloads
+        from test_gpu_host_planner import CLI, _scenario, _write_map
+        if not os.path.exists(CLI):
+            return {"replan": None, "plan_level": None}
+        w = workloads.config3()
+        w.obst = workloads.obstacles(32, 3, 204.8, time=float(w.start5[4]))
+        budget_s, init = 0.1, 8192
+        with tempfile.TemporaryDirectory() as d:
+            mp = os.path.join(d, "grid.map")
+            _write_map(w.grid, w.res, mp)
+            sc = os.path.join(d, "s.txt")
+            _scenario(w, sc, mp, float(w.start5[4]), 1e-3, 1, init)
+            with open(sc, "a") as f:
+                f.write(f"time_remaining {budget_s!r}\nreplan {cycles} 0.1\n")
+            run = subprocess.run([CLI, sc], capture_output=True, text=True, timeout=600)
+        if run.returncode != 0:
+            raise RuntimeError(run.stdout[-400:] + run.stderr[-400:])
+        r = json.loads(run.stdout.strip().splitlines()[-1])
+        replan = {"workload": "cfg5: cfg3 grid (2048x2048 @0.1 m, 10 % blocked), 5 ribbons, 32 moving obstacles uniform in the map, moving start, "
+                              "previous plan handed back; ONE GPU (BASELINE's 8-GPU form is not the builder's to run)",
+                  "budget_ms": 1e3 * budget_s, "initial_samples": init, "cycles": cycles,
+                  "plan_latency_ms": {"p50": r["wall_ms_p50"], "p99": r["wall_ms_p99"], "max": r["wall_ms_max"], "first_cycle": r["first_cycle_ms"]},
+                  "late_cycles": r["late_cycles"], "iterations_per_cycle": r["mean_iterations"],
+                  "first_goal_iteration": {"median": r["first_goal_iteration_median"], "max": r["first_goal_iteration_max"], "mean": r["first_goal_iteration_mean"],
+                                           "cycles_with_a_goal": r["cycles_with_a_goal"]},
+                  "expansions_per_cycle": r["mean_expanded"], "edges_per_cycle": r["mean_edges"], "round_trips_per_cycle": r["mean_round_trips"],
+                  "samples_reached": r["mean_samples"], "deadline_stops": r["deadline_stops"], "failed_plans": r["failed_plans"],
+                  "failed_plans_with_start_in_collision": r["failed_plans_with_start_in_collision"], "grid_uploads": r["grid_uploads"],
+                  "node_regrowths": r["node_regrowths"], "device_growths": r["device_growths"], "worst_cycle": r["worst_cycle"]}
+        plan = {"seam": "Planner::plan (pp/src/planner/Planner.h:50-51): GpuAStarPlanner, one GPU",
+                "expansions_per_s": r["expansions_per_s_inside_plan"], "edges_per_s": r["edges_per_s_inside_plan"],
+                "note": "inside plan() the search is sequential: each round trip costs the <= 40 edges of up to 16 open vertices, so the plan-level "
+                        "edge rate is bound by round-trip latency, two orders of magnitude below the batch rate (`value`)"}
+        if cpu_baseline:
+            import numpy as np
+            import oracle as orc
+            orc.O.ppo_set_ribbon_width(w.cfg.ribbon_width)
+            world = orc.World(w.cfg, w.grid, w.res, w.obst)
+            exp, edges, its, fg = [], [], [], []
+            n_cpu = 10
+            for _ in range(n_cpu):                 # clock_dt = -1: the wall clock, the same budget as the product's cycles
+                rc, st, _plan, _itf, _ = world.plan(w.ribbons4, w.start5, budget_s, float(w.start5[4]), -1.0, initial_samples=init, dump_edges=1)
+                exp.append(int(st.expanded)); edges.append(int(world.last_plan_edges)); its.append(int(st.iterations)); fg.append(int(st.first_goal_iteration))
+            plan["cpu_baseline"] = {"kind": "port", "cores": 1, "budget_ms": 1e3 * budget_s,
+                                    "sample": f"{n_cpu} plan() calls of the oracle's AStarPlanner restatement (-O2) from the loop's first start state, no previous plan, wall clock",
+                                    "expansions_per_s": float(np.mean(exp)) / budget_s, "edges_per_s": float(np.mean(edges)) / budget_s,
+                                    "iterations_per_call": float(np.mean(its)), "first_goal_iteration_median": int(np.median(fg))}
+        return {"replan": replan, "plan_level": plan}
+    except Exception as e:       # the throughput line must not depend on this leg
+        return {"replan": {"error": repr(e)}, "plan_level": None}
 
 
 def first_goal_check():

@@ -174,6 +174,10 @@ int ppgpu_synchronize(ppgpu_ctx* ctx);
  * Optional: without it the buffers grow on demand (powers of two) and stay for the life of the handle.  8 million samples and
  * 16 vertices take 2.3 GB of the 288 GB. */
 int ppgpu_reserve_samples(ppgpu_ctx* ctx, int64_t max_samples, int32_t max_vertices);
+/* How many times the library has grown a device or pinned-host buffer in this process so far, and the wall time those
+ * allocations took.  A caller with a time contract (Planner.h:42: plan() returns before timeRemaining) reads it before and after
+ * a cycle: a growth inside the budget costs milliseconds and is what ppgpu_reserve_samples is there to avoid.  Either may be NULL. */
+int ppgpu_growth_stats(ppgpu_ctx* ctx, uint64_t* count, double* seconds);
 /* Measurement aid: with timing on, every costing launch records HIP events on the handle's stream between its kernels;
  * ppgpu_last_timing waits for the last launch and returns, in milliseconds: ms_solve = pp_k_solve_edges; ms_pose = the pose
  * sweep with its chunk-skip planner (pp_k_plan_skips + pp_k_pose_sweep); ms_cover = pp_k_cover_sweep alone; ms_heuristic =
@@ -245,7 +249,10 @@ int ppgpu_sampler_init(ppgpu_ctx* ctx, const double* bounds6, uint64_t seed,
 int ppgpu_sampler_add(ppgpu_ctx* ctx, int64_t n_attempts, int64_t* n_total_out);
 
 /* Advance the generator by n_attempts states without storing them (rank r of a sharded
- * batch skips the r * batch attempts that belong to lower ranks; SURVEY.md 8 e). */
+ * batch skips the r * batch attempts that belong to lower ranks; SURVEY.md 8 e).
+ * Asynchronous: launches only.  Where the stream resumes depends on the skipped draws (a sample projected onto a ribbon
+ * consumes a sixth draw, StateGenerator.cpp:21-28), but the position is kept in device memory and the next
+ * ppgpu_sampler_add / ppgpu_sampler_skip starts from it there; an error of the skip is reported by the next ppgpu_sampler_add. */
 int ppgpu_sampler_skip(ppgpu_ctx* ctx, int64_t n_attempts);
 
 /* Replace the sample (target-state) store with caller data; x/y/heading arrays of n. */
@@ -363,13 +370,17 @@ int ppgpu_key_min(ppgpu_ctx* ctx, int32_t n, const uint64_t* d_keys, uint64_t* d
  *   one process, several GPUs:  ppgpu_comm_init_all on the n handles (one per device, rank i = ctxs[i]); each handle's
  *     ppgpu_allreduce_best must then be issued from its own host thread (the call blocks until every rank has joined).
  * ppgpu_comm_info reads the size and this handle's rank back from RCCL (ncclCommCount / ncclCommUserRank).
- * The handle owns its communicator; ppgpu_destroy releases it. */
+ * The handle owns its communicator; ppgpu_destroy releases it.  ppgpu_comm_init_all either gives every handle a communicator
+ * or none (on failure the communicators already made are destroyed again). */
 #define PPGPU_COMM_ID_BYTES 128
 int ppgpu_comm_unique_id(uint8_t* h_id128);
 int ppgpu_comm_init_rank(ppgpu_ctx* ctx, int32_t world, int32_t rank, const uint8_t* h_id128);
 int ppgpu_comm_init_all(ppgpu_ctx** ctxs, int32_t n);
 int ppgpu_comm_info(ppgpu_ctx* ctx, int32_t* world, int32_t* rank);
 int ppgpu_comm_destroy(ppgpu_ctx* ctx);
+/* ncclCommAbort on the handle's communicator: gives it up WITHOUT waiting for outstanding collectives, which releases a rank
+ * that is waiting in a collective another rank never joined (its own failure came first).  Callable from any host thread. */
+int ppgpu_comm_abort(ppgpu_ctx* ctx);
 
 /* Global incumbent across the ranks of one node: lexicographic min of the
  * per-rank keys with one RCCL collective over xGMI (all-gather of 16 bytes per rank, then ppgpu_key_min; RCCL has no

@@ -2,6 +2,7 @@
 // tests/ (ctypes) and bench.py's cpu_baseline leg can drive the CPU restatement with the same
 // records (include/ppgpu.h) the HIP library produces.  Not linked into any product library.
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -525,7 +526,11 @@ int ppo_plan(void* w, int n_ribbons, const double* ribbons4, double cct, const d
     cfg.initialSamples = initial_samples;
     cfg.useBrownPaths = use_brown_paths != 0;
     long calls = 0;
-    cfg.now = [&]() { return clock_t0 + (double)(calls++) * clock_dt; };
+    // clock_dt < 0: the wall clock (clock_t0 + seconds since this call began) — bench.py's plan-level CPU baseline, where the
+    // checker's planner is given the same WALL budget as the product's; every parity comparison uses the counting clock
+    const std::chrono::steady_clock::time_point wall0 = std::chrono::steady_clock::now();
+    if (clock_dt < 0) cfg.now = [&]() { return clock_t0 + std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count(); };
+    else cfg.now = [&]() { return clock_t0 + (double)(calls++) * clock_dt; };
     RibbonManager rm = make_rm(*W, ribbons4, n_ribbons, cct);
     State start(start5[0], start5[1], start5[2], start5[3], start5[4]);
     std::vector<DubinsWrapper> prev;

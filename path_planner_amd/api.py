@@ -38,6 +38,7 @@ def _load():
         "ppgpu_set_stream": (C.c_int, [vp, vp]),
         "ppgpu_synchronize": (C.c_int, [vp]),
         "ppgpu_reserve_samples": (C.c_int, [vp, i64, i32]),
+        "ppgpu_growth_stats": (C.c_int, [vp, C.POINTER(u64), C.POINTER(dbl)]),
         "ppgpu_device_alloc": (C.c_int, [vp, u64, C.POINTER(vp)]),
         "ppgpu_device_free": (C.c_int, [vp, vp]),
         "ppgpu_device_read": (C.c_int, [vp, vp, vp, u64]),
@@ -77,6 +78,7 @@ def _load():
         "ppgpu_comm_init_all": (C.c_int, [C.POINTER(vp), i32]),
         "ppgpu_comm_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32)]),
         "ppgpu_comm_destroy": (C.c_int, [vp]),
+        "ppgpu_comm_abort": (C.c_int, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError here = the library does not export what the header declares
@@ -198,6 +200,11 @@ class Context:
         tot = C.c_int64()
         self._ck(LIB.ppgpu_sampler_add(self._h, int(n_attempts), C.byref(tot)), "ppgpu_sampler_add")
         return tot.value
+
+    def growth_stats(self):
+        n, sec = C.c_uint64(), C.c_double()
+        self._ck(LIB.ppgpu_growth_stats(self._h, C.byref(n), C.byref(sec)), "ppgpu_growth_stats")
+        return int(n.value), float(sec.value)
 
     def sampler_skip(self, n_attempts):
         self._ck(LIB.ppgpu_sampler_skip(self._h, int(n_attempts)), "ppgpu_sampler_skip")

@@ -27,7 +27,8 @@ struct PPSamplerState {
     int on_ribbons;            // m_SampleOnRibbons
     int n_ribbons;
     int initialised;
-    unsigned long long pos;    // pair slots consumed so far
+    const unsigned long long* d_pos;   // device: [0] pair slots consumed so far.  The position lives on the device so that a skip or an
+                                       // add advances it with a launch (pp_k_sampler_advance) and the host never waits for it
 };
 
 // ------------------------------------------------------------------------------ minstd_rand0
@@ -63,6 +64,22 @@ __device__ __forceinline__ double pp_canonical(unsigned& x) {
     return ret;
 }
 __device__ __forceinline__ double pp_uniform(unsigned& x, double a, double b) { return pp_canonical(x) * (b - a) + a; }
+// `pp_uniform(x, 0, 2 pi) < pi / 50` (StateGenerator.cpp:22) for every stream slot: the division of pp_canonical is only taken when
+// the quotient guessed from the reciprocal (a few ulp off at most) lies within 1e-9 of the threshold — one slot in a billion;
+// everywhere else the guess decides, as the exact quotient would.
+__device__ __forceinline__ bool pp_projection_draw(unsigned& x) {
+    const double R = 2147483646.0;
+    unsigned xs = x;
+    x = pp_mulmod(x, 16807u);
+    double sum = (double)(x - 1u) * 1.0;
+    x = pp_mulmod(x, 16807u);
+    sum += (double)(x - 1u) * R;
+    const double guess = sum * (1.0 / (R * R)) * (PP_TWO_PI - 0) + 0;
+    const double thr = PP_PI / 50;
+    if (guess < thr * (1.0 - 1e-9)) return true;
+    if (guess > thr * (1.0 + 1e-9)) return false;
+    return pp_uniform(xs, 0, PP_TWO_PI) < thr;       // too close to call: the reference's own expression
+}
 
 // Step 1, proj bits: proj[qi] bit 0 = (5th draw of a sample starting at slot pos + qi) < pi/50   (StateGenerator.cpp:22)
 
@@ -151,9 +168,10 @@ __device__ inline unsigned pp_u32_prefix_of(const unsigned* blk, int upto, unsig
     return total;
 }
 // 1 + 2a: proj bits of a tile (and of the five slots before it, which its first transitions read) and the tile's transition product
-__global__ __launch_bounds__(256) void pp_k_proj_reduce(unsigned seed, unsigned long long pos, long long nq, unsigned char* proj,
+__global__ __launch_bounds__(256) void pp_k_proj_reduce(unsigned seed, const unsigned long long* d_pos, long long nq, unsigned char* proj,
                                                         unsigned long long* blk, unsigned long long* zero16) {
     __shared__ unsigned long long sh[256];
+    const unsigned long long pos = d_pos[0];
     __shared__ unsigned char sp[PP_SCAN_TILE + 8];             // sp[5 + i] = proj of the tile's slot i; sp[0 .. 4] = the five slots before the tile
     if (blockIdx.x == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0ull;   // end slot / total of this call (written by later launches)
     const long long tile0 = (long long)blockIdx.x * PP_SCAN_TILE;
@@ -166,8 +184,7 @@ __global__ __launch_bounds__(256) void pp_k_proj_reduce(unsigned seed, unsigned 
         for (int i = 0; i < 8; i++) {
             unsigned char b = 0;
             if (q0 + i < nq) {
-                const double u = pp_uniform(x, 0, PP_TWO_PI);
-                b = (u < PP_PI / 50) ? 1 : 0;
+                b = pp_projection_draw(x) ? 1 : 0;
                 proj[q0 + i] = b;
             }
             sp[5 + l0 + i] = b;
@@ -177,8 +194,7 @@ __global__ __launch_bounds__(256) void pp_k_proj_reduce(unsigned seed, unsigned 
             unsigned char b = 0;
             if (q >= 0 && q < nq) {
                 unsigned xh = pp_lcg_jump(seed, 2ull * (pos + (unsigned long long)q + 4ull));
-                const double u = pp_uniform(xh, 0, PP_TWO_PI);
-                b = (u < PP_PI / 50) ? 1 : 0;
+                b = pp_projection_draw(xh) ? 1 : 0;
             }
             sp[threadIdx.x] = b;
         }
@@ -230,9 +246,11 @@ __global__ __launch_bounds__(256) void pp_k_chain_apply_count(unsigned char* pro
     pp_u32_block_scan(c, shc, tot);
     if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
 }
-// 3b: slot of sample i for i < n, and the slot of sample n (= where the next call resumes); cnt = per-tile counts (not yet scanned)
+// 3b: slot of sample i for i < n, and the slot of sample n (= where the next call resumes); cnt = per-tile counts (not yet scanned).
+// skip_pos != NULL (ppgpu_sampler_skip: nothing of this call reads the position any more): the thread that finds sample n's slot
+// advances the stream position there and then — pos[0] += slot — and the last workgroup raises pos[1] if the chain never got that far.
 __global__ __launch_bounds__(256) void pp_k_chain_positions_scan(const unsigned char* proj, long long nq, const unsigned* cnt,
-                                                                 long long n, unsigned* qpos, unsigned long long* end_slot) {
+                                                                 long long n, unsigned* qpos, unsigned long long* end_slot, unsigned long long* skip_pos) {
     __shared__ unsigned sh[256];
     const unsigned before = pp_u32_prefix_of(cnt, (int)blockIdx.x, sh);
     long long q0 = (long long)blockIdx.x * PP_SCAN_TILE + (long long)threadIdx.x * 8;
@@ -240,11 +258,15 @@ __global__ __launch_bounds__(256) void pp_k_chain_positions_scan(const unsigned 
     for (int i = 0; i < 8; i++) if (q0 + i < nq && (proj[q0 + i] & 2u)) c++;
     unsigned total;
     unsigned rank = pp_u32_block_scan(c, sh, total) + before;
+    if (skip_pos && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && (long long)(before + total) <= n) skip_pos[1] = 1ull;
     for (int i = 0; i < 8; i++) {
         long long q = q0 + i;
         if (q < nq && (proj[q] & 2u)) {
-            if ((long long)rank < n) qpos[rank] = (unsigned)q;
-            else if ((long long)rank == n) *end_slot = (unsigned long long)q;   // relative; host adds pos
+            if ((long long)rank < n) { if (!skip_pos) qpos[rank] = (unsigned)q; }
+            else if ((long long)rank == n) {
+                *end_slot = (unsigned long long)q;   // relative; pp_k_sampler_advance (or the line below) adds it to the position
+                if (skip_pos) skip_pos[0] += (unsigned long long)q;
+            }
             rank++;
         }
     }
@@ -283,7 +305,7 @@ __global__ __launch_bounds__(256) void pp_k_generate_keep(PPSamplerState s, cons
     bool kept = false;
     if (i < n) {
         unsigned long long rel = qpos ? (unsigned long long)qpos[i] : 4ull * (unsigned long long)i;
-        unsigned x = pp_lcg_jump(s.seed, 2ull * (s.pos + rel));
+        unsigned x = pp_lcg_jump(s.seed, 2ull * (s.d_pos[0] + rel));
         double speed = pp_uniform(x, s.b[4], s.b[5]);   // drawn first (right-to-left argument evaluation)
         (void)speed;                                    // expand() overwrites it (SamplingBasedPlanner.cpp:113)
         double heading = pp_uniform(x, 0, PP_TWO_PI);
@@ -322,4 +344,17 @@ __global__ __launch_bounds__(256) void pp_k_compact_scan(const unsigned char* ke
     for (int w = 0; w < wave; w++) rank += sc[w];
     if (kept) { sx[base + rank] = cand[i]; sy[base + rank] = cand[n + i]; sh[base + rank] = cand[2 * n + i]; }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = (unsigned long long)(before + sc[0] + sc[1] + sc[2] + sc[3]);
+}
+
+// ------------------------------------------------------------------------------ 6. where the stream resumes
+// The last launch of a skip or an add: pos[0] += the slots this call consumed (the chain scan's end slot, or 4 per sample without
+// ribbons).  pos[1] = sticky error (the chain scan did not reach the end of its batch), pos[2] = samples the add kept, pos[3] = slots
+// consumed by this call: what ppgpu_sampler_add reads back in one copy; ppgpu_sampler_skip reads nothing back.
+__global__ void pp_k_sampler_advance(unsigned long long* pos, const unsigned long long* end_slot, const unsigned long long* total,
+                                     unsigned long long fixed, int on_ribbons) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned long long rel = on_ribbons ? *end_slot : fixed;
+    if (on_ribbons && rel == 0ull) pos[1] = 1ull; else pos[0] += rel;
+    pos[2] = total ? *total : 0ull;
+    pos[3] = rel;
 }

@@ -39,12 +39,26 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #ifndef PP_SLICE_BYTES
 #define PP_SLICE_BYTES (32ull << 30)
 #endif
+// Device / pinned allocations made after start-up are what a real-time caller must know about (a hipMalloc or hipHostMalloc inside a
+// 100 ms planning cycle costs milliseconds): every growth of a library buffer is counted, with the wall time it took
+// (ppgpu_growth_stats; process-wide, the host planner reports the difference over a plan() call).
+#include <atomic>
+#include <chrono>
+static std::atomic<unsigned long long> g_growth_count{0}, g_growth_ns{0};
+struct GrowthTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~GrowthTimer() {
+        g_growth_count.fetch_add(1, std::memory_order_relaxed);
+        g_growth_ns.fetch_add((unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+    }
+};
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;  // elements
     int reserve(size_t n, bool keep, hipStream_t s) {
         if (n <= cap) return PPGPU_OK;
+        GrowthTimer growth;
         size_t ncap = cap ? cap : 64;
         while (ncap < n) ncap *= 2;
         T* np = nullptr;
@@ -88,6 +102,7 @@ struct ppgpu_ctx {
     // sampler (StateGenerator) state
     PPSamplerState sampler{};
     DevBuf<double> samp_ribbons;
+    DevBuf<unsigned long long> samp_pos;           // [0] stream position (pair slots consumed), [1] sticky chain error, [2..3] report of the last add (pp_k_sampler_advance)
     unsigned long long* pinned_counts = nullptr;   // 64 bytes of pinned host memory for the sampler's count read-backs
     std::vector<double> samp_ribbons_host;   // what samp_ribbons holds (ppgpu_sampler_init skips the upload of an unchanged table)
     DevBuf<unsigned char> s_bytes;      // scan / compaction scratch
@@ -193,7 +208,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)ppgpu_comm_destroy(c);
     c->grid.release(); c->grid_clear.release(); c->grid_rowclear.release(); c->obst.release(); c->verts.release(); c->ribbons.release(); c->tgrid.release();
-    c->sx.release(); c->sy.release(); c->sh.release(); c->samp_ribbons.release();
+    c->sx.release(); c->sy.release(); c->sh.release(); c->samp_ribbons.release(); c->samp_pos.release();
     c->s_bytes.release(); c->s_u64.release(); c->s_u32a.release(); c->s_u32b.release(); c->s_cand.release();
     c->tmp_edges.release(); c->tmp_wedges.release(); c->partial.release(); c->tmp_results.release(); c->tmp_child.release();
     c->ord_key.release(); c->ord_val.release(); c->ord_idx.release(); c->ord_fallbacks.release(); c->ord_len.release();
@@ -278,6 +293,13 @@ int ppgpu_reserve_samples(ppgpu_ctx* c, int64_t max_samples, int32_t max_vertice
         (rc = c->ord_key.reserve(nv * 2 * cap, false, st)) || (rc = c->ord_val.reserve(nv * 2 * cap, false, st)) || (rc = c->ord_len.reserve(nv * 2 * cap, false, st)) ||
         (rc = c->ord_blockmin.reserve(nv * nblk * 2, false, st)) || (rc = c->ord_blockcnt.reserve(nv * nblk, false, st)))
         return rc;
+    return PPGPU_OK;
+}
+
+int ppgpu_growth_stats(ppgpu_ctx* c, uint64_t* count, double* seconds) {
+    if (!c) return fail(PPGPU_EINVAL, "null context");
+    if (count) *count = g_growth_count.load(std::memory_order_relaxed);
+    if (seconds) *seconds = 1e-9 * (double)g_growth_ns.load(std::memory_order_relaxed);
     return PPGPU_OK;
 }
 
@@ -535,7 +557,9 @@ int ppgpu_sampler_init(ppgpu_ctx* c, const double* b6, uint64_t seed, int32_t n_
     s.seed = (unsigned)(x == 0 ? 1 : x);
     s.on_ribbons = n_ribbons >= 0 ? 1 : 0;   // the ribbon constructor sets m_SampleOnRibbons even for an empty manager
     s.n_ribbons = n_ribbons > 0 ? n_ribbons : 0;
-    s.pos = 0;
+    if ((rc = c->samp_pos.reserve(8, false, c->stream))) return rc;
+    HIP_TRY(hipMemsetAsync(c->samp_pos.p, 0, 8 * sizeof(unsigned long long), c->stream));   // position 0, no error (in stream order: no host wait)
+    s.d_pos = c->samp_pos.p;
     s.initialised = 1;
     if (n_ribbons > 0) {
         // the generator of every iteration of a plan() call is built from the same ribbon manager (AStarPlanner.cpp:34): the table is
@@ -557,7 +581,7 @@ int ppgpu_sampler_init(ppgpu_ctx* c, const double* b6, uint64_t seed, int32_t n_
 // Steps 1-3 of the sampler: which stream slots do the next n samples start at?  Leaves qpos[0..n)
 // (relative slots) in c->s_u32a, the projection bits in c->s_bytes and the relative slot of sample n
 // (= where the stream resumes) in *d_end (device).  Without ribbons the layout is fixed (4 slots per sample).
-static int sampler_chain(ppgpu_ctx* c, long long n, long long& nq, int& nblk_q, unsigned long long** d_end) {
+static int sampler_chain(ppgpu_ctx* c, long long n, long long& nq, int& nblk_q, unsigned long long** d_end, bool skip = false) {
     PPSamplerState& s = c->sampler;
     hipStream_t st = c->stream;
     int rc;
@@ -577,11 +601,12 @@ static int sampler_chain(ppgpu_ctx* c, long long n, long long& nq, int& nblk_q, 
     unsigned char* proj = c->s_bytes.p;
     // 1. proj[q] for every slot in range (LCG jump-ahead) + 2a. the transition product of every tile of PP_SCAN_TILE slots: the chain
     //    q -> q + 5 + proj[q] as a scan of 6x6 boolean transition matrices (also zeroes the end slot / total of this call)
-    hipLaunchKernelGGL(pp_k_proj_reduce, dim3(nblk_q), dim3(256), 0, st, s.seed, s.pos, nq, proj, c->s_u64.p, c->s_u64.p + nblk_q + 8);
+    hipLaunchKernelGGL(pp_k_proj_reduce, dim3(nblk_q), dim3(256), 0, st, s.seed, s.d_pos, nq, proj, c->s_u64.p, c->s_u64.p + nblk_q + 8);
     // 2b. visited[q] + 3a. visited slots per tile
     hipLaunchKernelGGL(pp_k_chain_apply_count, dim3(nblk_q), dim3(256), 0, st, proj, nq, c->s_u64.p, c->s_u32b.p);
     // 3b. rank the visited slots: slot of each sample, and of sample n
-    hipLaunchKernelGGL(pp_k_chain_positions_scan, dim3(nblk_q), dim3(256), 0, st, proj, nq, c->s_u32b.p, n, c->s_u32a.p, *d_end);
+    hipLaunchKernelGGL(pp_k_chain_positions_scan, dim3(nblk_q), dim3(256), 0, st, proj, nq, c->s_u32b.p, n, c->s_u32a.p, *d_end,
+                       skip ? c->samp_pos.p : (unsigned long long*)nullptr);
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;
 }
@@ -593,17 +618,20 @@ int ppgpu_sampler_skip(ppgpu_ctx* c, int64_t n_attempts) {
     if (!c->sampler.initialised) return fail(PPGPU_ESTATE, "ppgpu_sampler_init must be called first");
     if (n_attempts < 0) return fail(PPGPU_EINVAL, "sampler: negative count");
     PPSamplerState& s = c->sampler;
+    // Launches only: the position after the skip is data-dependent (which samples were projected onto a ribbon), but it stays on the
+    // device (samp_pos); a chain that does not reach the end of its batch raises samp_pos[1], which the next ppgpu_sampler_add reports.
     long long left = n_attempts;
     while (left > 0) {
         long long n = left < 524288 ? left : 524288;
-        if (!s.on_ribbons) { s.pos += 4ull * (unsigned long long)n; left -= n; continue; }
-        long long nq; int nblk_q; unsigned long long* d_end;
-        if ((rc = sampler_chain(c, n, nq, nblk_q, &d_end))) return rc;
-        unsigned long long rel = 0;
-        HIP_TRY(hipMemcpyAsync(&rel, d_end, sizeof(rel), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (rel == 0) return fail(PPGPU_EHIP, "sampler: chain scan did not reach the end of the batch");
-        s.pos += rel;
+        long long nq = 0; int nblk_q = 0; unsigned long long* d_end = nullptr;
+        if (s.on_ribbons) {
+            // three launches; the last of them (pp_k_chain_positions_scan) advances the position itself
+            if ((rc = sampler_chain(c, n, nq, nblk_q, &d_end, true))) return rc;
+        } else {
+            hipLaunchKernelGGL(pp_k_sampler_advance, dim3(1), dim3(1), 0, c->stream, c->samp_pos.p, d_end, (const unsigned long long*)nullptr,
+                               4ull * (unsigned long long)n, 0);
+            HIP_TRY(hipGetLastError());
+        }
         left -= n;
     }
     return PPGPU_OK;
@@ -641,15 +669,16 @@ int ppgpu_sampler_add(ppgpu_ctx* c, int64_t n_attempts, int64_t* n_total_out) {
     hipLaunchKernelGGL(pp_k_compact_scan, dim3((unsigned)nblk_n), dim3(256), 0, st, keep, n, blk32, c->s_cand.p, c->sx.p, c->sy.p,
                        c->sh.p, c->n_samples, d_total);
     HIP_TRY(hipGetLastError());
-    // the two counts come back through pinned memory (a copy to pageable memory waits for the stream by itself, once per copy)
+    hipLaunchKernelGGL(pp_k_sampler_advance, dim3(1), dim3(1), 0, st, c->samp_pos.p, d_end, d_total, 4ull * (unsigned long long)n, s.on_ribbons);
+    HIP_TRY(hipGetLastError());
+    // {chain error, kept, slots consumed} come back in one copy through pinned memory (a copy to pageable memory waits for the
+    // stream by itself); the position itself stays on the device
     volatile unsigned long long* h2 = c->pinned_counts;
-    h2[0] = 0; h2[1] = 0;
-    HIP_TRY(hipMemcpyAsync((void*)&h2[0], d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync((void*)&h2[1], d_end, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    h2[0] = 0; h2[1] = 0; h2[2] = 0;
+    HIP_TRY(hipMemcpyAsync((void*)&h2[0], c->samp_pos.p + 1, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (s.on_ribbons && h2[1] == 0) return fail(PPGPU_EHIP, "sampler: chain scan did not reach the end of the batch");
-    s.pos = s.on_ribbons ? (s.pos + h2[1]) : (s.pos + 4ull * (unsigned long long)n);   // slots consumed so far
-    c->n_samples += (long long)h2[0];
+    if (h2[0] != 0) return fail(PPGPU_EHIP, "sampler: chain scan did not reach the end of the batch (this call or a ppgpu_sampler_skip before it)");
+    c->n_samples += (long long)h2[1];
     c->n_extra = 0;                        // the appended samples overwrote any explicit targets
     if (n_total_out) *n_total_out = c->n_samples;
     return PPGPU_OK;
@@ -1171,6 +1200,7 @@ int64_t ppgpu_expand_capacity(int32_t nv, int32_t k) {
 // grow-only pinned staging: one H2D in, one D2H out per call instead of a dozen pageable copies
 static int stage_reserve(void** p, size_t* cap, size_t n) {
     if (n <= *cap) return PPGPU_OK;
+    GrowthTimer growth;
     size_t ncap = *cap ? *cap : 4096;
     while (ncap < n) ncap *= 2;
     if (*p) HIP_TRY(hipHostFree(*p));
@@ -1319,6 +1349,7 @@ struct Rccl {
     int (*comm_count)(void*, int*) = nullptr;
     int (*comm_user_rank)(void*, int*) = nullptr;
     int (*comm_destroy)(void*) = nullptr;
+    int (*comm_abort)(void*) = nullptr;
     int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     const char* (*error_string)(int) = nullptr;
     std::string error;
@@ -1339,6 +1370,7 @@ const Rccl& rccl_table() {
         r.comm_count = (decltype(r.comm_count))dlsym(lib, "ncclCommCount");
         r.comm_user_rank = (decltype(r.comm_user_rank))dlsym(lib, "ncclCommUserRank");
         r.comm_destroy = (decltype(r.comm_destroy))dlsym(lib, "ncclCommDestroy");
+        r.comm_abort = (decltype(r.comm_abort))dlsym(lib, "ncclCommAbort");
         r.all_gather = (decltype(r.all_gather))dlsym(lib, "ncclAllGather");
         r.error_string = (decltype(r.error_string))dlsym(lib, "ncclGetErrorString");
         if (!r.get_unique_id || !r.comm_init_rank || !r.comm_init_all || !r.comm_count || !r.comm_user_rank || !r.comm_destroy || !r.all_gather) {
@@ -1375,12 +1407,13 @@ extern "C" int ppgpu_comm_init_rank(ppgpu_ctx* c, int32_t world, int32_t rank, c
     HIP_TRY(hipSetDevice(c->device));
     PPNcclId id;
     std::memcpy(id.internal, id128, PPGPU_COMM_ID_BYTES);
+    // the gather buffer first: nothing can fail once the communicator exists
+    int rc2 = c->gather.reserve((size_t)world * 2, false, c->stream);
+    if (rc2) return rc2;
     void* comm = nullptr;
     const int rc = r.comm_init_rank(&comm, world, id, rank);
     if (rc != 0 || !comm) return rccl_fail(r, "ncclCommInitRank", rc);
     c->comm = comm;
-    int rc2 = c->gather.reserve((size_t)world * 2, false, c->stream);
-    if (rc2) return rc2;
     return PPGPU_OK;
 }
 
@@ -1396,15 +1429,19 @@ extern "C" int ppgpu_comm_init_all(ppgpu_ctx** ctxs, int32_t n) {
     }
     const Rccl& r = rccl_table();
     if (!r.ok) return fail(PPGPU_ERCCL, r.error);
-    std::vector<void*> comms((size_t)n, nullptr);
-    const int rc = r.comm_init_all(comms.data(), n, devs.data());
-    if (rc != 0) return rccl_fail(r, "ncclCommInitAll", rc);
+    // every handle's gather buffer first, so that the handles end up with a communicator each or none at all
     for (int i = 0; i < n; i++) {
-        ctxs[i]->comm = comms[(size_t)i];
         HIP_TRY(hipSetDevice(ctxs[i]->device));
         int rc2 = ctxs[i]->gather.reserve((size_t)n * 2, false, ctxs[i]->stream);
         if (rc2) return rc2;
     }
+    std::vector<void*> comms((size_t)n, nullptr);
+    const int rc = r.comm_init_all(comms.data(), n, devs.data());
+    if (rc != 0) {
+        for (void* cm : comms) if (cm) (void)r.comm_destroy(cm);
+        return rccl_fail(r, "ncclCommInitAll", rc);
+    }
+    for (int i = 0; i < n; i++) ctxs[i]->comm = comms[(size_t)i];
     return PPGPU_OK;
 }
 
@@ -1431,6 +1468,20 @@ extern "C" int ppgpu_comm_destroy(ppgpu_ctx* c) {
     const int rc = r.comm_destroy(c->comm);
     c->comm = nullptr;
     if (rc != 0) return rccl_fail(r, "ncclCommDestroy", rc);
+    return PPGPU_OK;
+}
+
+// ncclCommAbort: frees the communicator WITHOUT waiting for its outstanding collectives — the way out for the ranks that entered a
+// collective a failed rank never joined.  May be called from another host thread than the one stuck in the handle's stream.
+extern "C" int ppgpu_comm_abort(ppgpu_ctx* c) {
+    if (!c) return fail(PPGPU_EINVAL, "comm_abort: null context");
+    void* comm = c->comm;
+    if (!comm) return PPGPU_OK;
+    const Rccl& r = rccl_table();
+    if (!r.ok) return fail(PPGPU_ERCCL, r.error);
+    c->comm = nullptr;
+    const int rc = r.comm_abort ? r.comm_abort(comm) : r.comm_destroy(comm);
+    if (rc != 0) return rccl_fail(r, "ncclCommAbort", rc);
     return PPGPU_OK;
 }
 

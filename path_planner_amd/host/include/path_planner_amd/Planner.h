@@ -7,6 +7,7 @@
 // injected clock and seed the same vertices are expanded in the same order.
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -44,6 +45,24 @@ public:
         unsigned long HostHeuristics = 0;     // children whose ribbon list exceeded the device's TSP enumeration: h computed on the host
         unsigned long DeadlineStops = 0;      // round trips / sample doublings not started because they could not end before the deadline
         unsigned long OrderFallbacks = 0;     // (vertex, radius) lists whose push order the device could not replay (ppgpu_order_fallbacks)
+        // Where the budget of this call went, for the time contract ("guaranteed to return before timeRemaining has elapsed",
+        // Planner.h:42): wall milliseconds from plan()'s entry, measured with the steady clock whatever clock is injected.
+        struct BudgetTrace {
+            double PrologueMs = 0;            // entry -> first pass of the big loop (world upload, sampler, root, previous plan)
+            double LoopEndMs = 0;             // when the big loop was left
+            double TotalMs = 0;               // when plan() returned
+            int LastOpKind = 0;               // the last device operation started: 0 none, 1 round trip, 2 sample doubling, 3 Brown-path re-cost
+            double LastOpStartMs = 0, LastOpPredictedMs = 0, LastOpActualMs = 0;
+            double MarginMs = 0;              // what the deadline guard kept clear of the deadline
+            double MaxTripMs = 0;             // the slowest round trip of the call
+            double WorstUnderPredictionMs = 0;   // max over guarded operations of (actual - predicted)
+            unsigned long NodeRegrowths = 0;  // reallocations of the search tree's node array inside the call ...
+            double NodeRegrowthMs = 0;        // ... and what they took
+            unsigned long DeviceGrowths = 0;  // device / pinned buffers the device library grew inside the call (ppgpu_growth_stats) ...
+            double DeviceGrowthMs = 0;        // ... and what that took
+            unsigned long RoundTrips = 0;
+            bool GridUploaded = false;        // the occupancy grid went to the device in this call (false: the device already held this map)
+        } Budget;
     };
     Planner();
     virtual ~Planner() = default;
@@ -55,6 +74,20 @@ protected:
     double now() const { return m_Config.now(); }
     PlannerConfig m_Config;
     Stats m_Stats;
+};
+
+// One search-tree node: what Vertex + its parent Edge hold in the reference (Vertex.h:180-187, Edge.h:133-143)
+struct SearchNode {
+    State state;
+    int parent = -1;
+    RibbonManager ribbons;
+    double g = -1, h = -1;
+    bool coverageAllowed = false;
+    bool infeasible = false;
+    double collisionPenalty = 0;
+    int steps = 0;             // collision-check steps the edge's sweep executed (visualisation only)
+    DubinsWrapper wrapper;     // parent edge's curve
+    double f() const { return g + h; }
 };
 
 // Process-level device handle: stream, persistent buffers (the reference builds a new planner every cycle,
@@ -82,12 +115,13 @@ public:
     // cycle of a new planner already knows: the deadline guard (PlannerConfig::deadlineGuard) predicts the next one from them.
     // Written and read by the planning thread only.
     struct Observed { double samples = 0, seconds = 0; };
-    Observed trips[4];        // the last round trips of expandBatch: sample count, duration
+    static constexpr int kTrips = 8;
+    Observed trips[kTrips];   // the last round trips of expandBatch: sample count, duration
     int tripSlot = 0;
     Observed doubling;        // the last addSamples: attempts, duration
-    void noteTrip(double samples, double seconds) { trips[tripSlot] = {samples, seconds}; tripSlot = (tripSlot + 1) % 4; }
+    void noteTrip(double samples, double seconds) { trips[tripSlot] = {samples, seconds}; tripSlot = (tripSlot + 1) % kTrips; }
     // a round trip over `samples` samples: no longer than the recent ones scaled up to that sample count (their cost grows
-    // less than linearly), plus a margin
+    // less than linearly), plus 15 %
     double predictTrip(double samples) const {
         double worst = 0;
         for (const Observed& o : trips)
@@ -98,6 +132,26 @@ public:
         if (doubling.seconds <= 0) return 0;
         return doubling.seconds * std::max(1.0, attempts / std::max(1.0, doubling.samples)) * 1.15 + 1e-4;
     }
+    // What the guard keeps clear of the deadline on top of its predictions, so that "before" holds and not "at": half a
+    // millisecond (the return path: tracing the plan, the caller's clock read), or twice the spread of the recent round trips
+    // if that is more.
+    double guardMargin() const {
+        double n = 0, sum = 0, sq = 0;
+        for (const Observed& o : trips)
+            if (o.seconds > 0) { n += 1; sum += o.seconds; sq += o.seconds * o.seconds; }
+        double sigma = 0;
+        if (n >= 2) { const double mean = sum / n; sigma = std::sqrt(std::max(0.0, sq / n - mean * mean)); }
+        return std::max(5e-4, 2 * sigma);
+    }
+    // The search tree's node array lives HERE between plan() calls (a planner takes it at the start of plan() and hands it back,
+    // emptied, when it is destroyed): its capacity — and its pages — survive the cycle.  Measured in round 4 (Stats::Budget): a
+    // std::vector that doubles at 65 536 nodes moves 16 MB and faults in 31 MB of fresh pages, 6.9 ms inside a 100 ms budget —
+    // round 3's unexplained +6 ms cycles.
+    std::vector<SearchNode> nodeArena;
+    // Which occupancy map the device holds (identity + Map::version): the planner of the next cycle uploads the grid only when
+    // the Executive has been given another map.  nullptr / 0: nothing cached.
+    const void* gridOf = nullptr;
+    unsigned long gridVersion = 0;
 
 private:
     ppgpu_ctx* m_Handle = nullptr;
@@ -117,22 +171,11 @@ public:
     // several devices of one node: world and samples are replicated on each (the sampler stream is deterministic: every device
     // draws the same samples itself), the open vertices of a batch are dealt across them, records come back to the host search
     explicit GpuAStarPlanner(std::vector<std::shared_ptr<GpuContext>> ctxs) : m_Ctx(ctxs.at(0)), m_Ctxs(std::move(ctxs)) {}
+    ~GpuAStarPlanner() override;      // the search tree is torn down here, as the reference's is (not inside plan()'s budget)
     Stats plan(const RibbonManager& ribbonManager, const State& start, PlannerConfig config, const DubinsPlan& previousPlan,
                double timeRemaining) override;
 
-    // one search-tree node: what Vertex + its parent Edge hold in the reference (Vertex.h:180-187, Edge.h:133-143)
-    struct Node {
-        State state;
-        int parent = -1;
-        RibbonManager ribbons;
-        double g = -1, h = -1;
-        bool coverageAllowed = false;
-        bool infeasible = false;
-        double collisionPenalty = 0;
-        int steps = 0;             // collision-check steps the edge's sweep executed (visualisation only)
-        DubinsWrapper wrapper;     // parent edge's curve
-        double f() const { return g + h; }
-    };
+    typedef SearchNode Node;
 
 private:
     std::shared_ptr<GpuContext> m_Ctx;                    // device 0 of this planner: sampling read-back, wrapper edges, explicit targets
@@ -162,6 +205,10 @@ private:
     void expandOn(GpuContext& ctx, const std::vector<int>& sources, std::vector<std::pair<int, Costed>>& out, unsigned long& edgesCosted) const;
     int costEdgeList(const std::vector<uint64_t>& edges, int maxParentRibbons, std::vector<::ppgpu_edge_result>& res, std::vector<double>& child);
     Node makeChild(int source, unsigned cfgBits, const ::ppgpu_edge_result& r, const double* childRibbons, int stride);
+    void addNode(Node&& n);                // m_Nodes.push_back that counts and times reallocations (Stats::Budget)
+    void noteOperation(int kind, double startedAt, double predicted, double actual);
+    double m_PlanEntry = 0;                // steady-clock time of plan()'s entry
+    bool m_DeadlineStop = false;           // aStar() stopped on the deadline guard: the big loop ends too
     int aStar(double endTime);
     void addSamples(long n);
     int depth(int v) const;
@@ -201,9 +248,13 @@ public:
     // form one — RCCL takes one rank per device — and the keys are then combined on the host instead; Result::rcclRanks says which.
     explicit ShardedIteration(std::vector<std::shared_ptr<GpuContext>> ctxs);
     ~ShardedIteration();
+    // Throws what a shard threw.  A shard that fails before the collective keeps every shard out of it (nothing is left waiting);
+    // a failure inside the collective aborts the communicators (ppgpu_comm_abort) so that the other ranks return.
     Result run(const RibbonManager& ribbonManager, const State& start, const PlannerConfig& config, unsigned long seed, int64_t attempts);
+    int failShardForTest = -1;                 // tests only: this shard throws at the start of its work
 
 private:
+    void release();
     std::vector<std::shared_ptr<GpuContext>> m_Ctxs;
     std::vector<void*> m_Keys, m_Records;      // per device: the 16-byte key and the record buffer (device memory)
     std::vector<size_t> m_RecordCap;

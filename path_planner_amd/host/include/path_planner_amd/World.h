@@ -30,6 +30,14 @@ public:
     // Occupancy as a byte grid for the device (row 0 = y in [0,res)).  The base map has none (rows = 0).
     // Any subclass that only implements isBlocked/extremes/resolution is rasterised cell centre by cell centre.
     virtual void rasterize(std::vector<uint8_t>& cells, int& rows, int& cols, double& res) const;
+    // Non-zero: the map's cells never change while this value is the same (an immutable map returns one number for its whole
+    // life, a map that is edited in place a new one after every edit); the planner then rasterises and uploads it once and
+    // reuses the device's copy in later cycles (Executive hands every cycle's planner the same shared_ptr<Map> until the map
+    // loader replaces it, executive.cpp:321-369).  0 (the default): unknown, upload at every plan().
+    virtual unsigned long version() const { return 0; }
+
+protected:
+    static unsigned long nextVersion();       // process-unique, never 0
 
 private:
     double m_Extremes[4] = {-DBL_MAX, DBL_MAX, -DBL_MAX, DBL_MAX};
@@ -47,6 +55,7 @@ public:
     const double* extremes() const override { return m_Box; }
     double resolution() const override { return m_CellSize; }
     void rasterize(std::vector<uint8_t>& cells, int& rows, int& cols, double& res) const override;
+    unsigned long version() const override { return m_Version; }      // immutable after construction
     int rows() const { return m_Rows; }
     int cols() const { return m_Cols; }
 
@@ -59,6 +68,7 @@ private:
     size_t m_WordsPerRow = 0;
     double m_CellSize = 0;
     double m_Box[4] = {0, 0, 0, 0};      // minX, maxX, minY, maxY
+    unsigned long m_Version = nextVersion();
 };
 
 class DynamicObstaclesManager {

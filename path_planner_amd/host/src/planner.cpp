@@ -64,6 +64,7 @@ struct Lap {
 static const double kTimePenaltyFactor = 1;       // Edge::timePenaltyFactor() (Edge.h:152)
 static const double kCollisionPenaltyFactor = 600;  // Edge::collisionPenaltyFactor() (Edge.h:151)
 static const int kRibbonStride = 64;              // child ribbon capacity per edge = the device's per-vertex limit
+static const size_t kNodeArenaMin = 1u << 18;     // nodes the search tree has room for before its first node arrives (63 MB of address space, touched as used)
 
 Planner::Planner() : m_Config(PlannerConfig(&std::cerr)) {}
 
@@ -164,6 +165,12 @@ void GpuContext::releaseShared() {
 }
 
 // ------------------------------------------------------------------------------------------------ helpers
+GpuAStarPlanner::~GpuAStarPlanner() {
+    // the tree goes (every node's ribbon list is its own allocation), its array goes back to the context for the next cycle's planner
+    m_Nodes.clear();
+    if (m_Ctx && m_Nodes.capacity() > m_Ctx->nodeArena.capacity()) m_Nodes.swap(m_Ctx->nodeArena);
+}
+
 void GpuAStarPlanner::check(int rc, const char* what) const {
     if (rc != PPGPU_OK) throw std::runtime_error(std::string(what) + ": " + ppgpu_last_error());
 }
@@ -191,7 +198,8 @@ int GpuAStarPlanner::depth(int v) const {
 // ------------------------------------------------------------------------------------------------ world upload
 // The snapshot every device of a planner works from: configuration, occupancy grid, obstacle table (SURVEY 8 e: replicated on
 // every device once per replan).
-static void uploadSnapshot(const std::vector<std::shared_ptr<GpuContext>>& ctxs, const PlannerConfig& config, const RibbonManager& ribbonManager,
+// -> true when the occupancy grid was rasterised and uploaded (false: every device already held this very map, Map::version)
+static bool uploadSnapshot(const std::vector<std::shared_ptr<GpuContext>>& ctxs, const PlannerConfig& config, const RibbonManager& ribbonManager,
                            double startStateTime) {
     ppgpu_config c{};
     c.max_speed = config.maxSpeed();
@@ -209,10 +217,17 @@ static void uploadSnapshot(const std::vector<std::shared_ptr<GpuContext>>& ctxs,
     c.heuristic = (int32_t)ribbonManager.heuristic();
     c.tsp_k = ribbonManager.k();
     c.branching_factor = config.branchingFactor();
+    // The grid of a 2048 x 2048 map is 4 million cells to rasterise, pack and upload, and a clearance map to rebuild: ~10 ms of a
+    // 100 ms cycle, for a map the Executive replaces once in minutes.  A map that vouches for its cells (Map::version != 0) is
+    // uploaded once per device and recognised afterwards.
+    const Map* map = config.map().get();
+    const unsigned long mapVersion = map ? map->version() : 0;
+    bool needGrid = false;
+    for (const auto& ctx : ctxs) needGrid = needGrid || mapVersion == 0 || ctx->gridOf != (const void*)map || ctx->gridVersion != mapVersion;
     std::vector<uint8_t> cells;
     int rows = 0, cols = 0;
     double res = 0;
-    if (config.map()) config.map()->rasterize(cells, rows, cols, res);
+    if (map && needGrid) map->rasterize(cells, rows, cols, res);
     std::vector<double> orows;
     const DynamicObstaclesManager& om = config.obstaclesManager();
     om.deviceRows(orows);
@@ -220,15 +235,42 @@ static void uploadSnapshot(const std::vector<std::shared_ptr<GpuContext>>& ctxs,
     for (const auto& ctx : ctxs) {
         ppgpu_ctx* h = ctx->handle();
         check(ppgpu_set_config(h, &c), "ppgpu_set_config");
-        check(ppgpu_set_grid(h, rows ? cells.data() : nullptr, rows, cols, res), "ppgpu_set_grid");
+        if (needGrid) {
+            ctx->gridOf = nullptr; ctx->gridVersion = 0;       // until the upload below has succeeded
+            check(ppgpu_set_grid(h, rows ? cells.data() : nullptr, rows, cols, res), "ppgpu_set_grid");
+            if (mapVersion != 0) { ctx->gridOf = (const void*)map; ctx->gridVersion = mapVersion; }
+        }
         if (om.deviceModel() == PPGPU_OBST_GAUSSIAN)
             check(ppgpu_set_gaussian_obstacles(h, (int32_t)(orows.size() / 9), orows.empty() ? nullptr : orows.data(), 1), "ppgpu_set_gaussian_obstacles");
         else
             check(ppgpu_set_obstacles(h, om.deviceModel(), (int32_t)(orows.size() / 7), orows.empty() ? nullptr : orows.data()), "ppgpu_set_obstacles");
     }
+    return needGrid;
 }
 
-void GpuAStarPlanner::uploadWorld(const State& start) { uploadSnapshot(m_Ctxs, m_Config, m_RibbonManager, start.time()); }
+void GpuAStarPlanner::uploadWorld(const State& start) { m_Stats.Budget.GridUploaded = uploadSnapshot(m_Ctxs, m_Config, m_RibbonManager, start.time()); }
+
+// ------------------------------------------------------------------------------------------------ budget bookkeeping
+void GpuAStarPlanner::addNode(Node&& n) {
+    if (m_Nodes.size() == m_Nodes.capacity()) {        // the vector is about to move every node: counted and timed (Stats::Budget)
+        const double t0 = HostProfile::now();
+        m_Nodes.push_back(std::move(n));
+        m_Stats.Budget.NodeRegrowths++;
+        m_Stats.Budget.NodeRegrowthMs += 1e3 * (HostProfile::now() - t0);
+        return;
+    }
+    m_Nodes.push_back(std::move(n));
+}
+
+void GpuAStarPlanner::noteOperation(int kind, double startedAt, double predicted, double actual) {
+    Stats::BudgetTrace& b = m_Stats.Budget;
+    b.LastOpKind = kind;
+    b.LastOpStartMs = 1e3 * (startedAt - m_PlanEntry);
+    b.LastOpPredictedMs = 1e3 * predicted;
+    b.LastOpActualMs = 1e3 * actual;
+    if (kind == 1) { b.RoundTrips++; b.MaxTripMs = std::max(b.MaxTripMs, 1e3 * actual); }
+    if (predicted > 0) b.WorstUnderPredictionMs = std::max(b.WorstUnderPredictionMs, 1e3 * (actual - predicted));
+}
 
 // ------------------------------------------------------------------------------------------------ open list
 void GpuAStarPlanner::pushVertexQueue(int vi) {   // SamplingBasedPlanner.cpp:7-19
@@ -355,7 +397,11 @@ void GpuAStarPlanner::addSamples(long n) {   // SamplingBasedPlanner::addSamples
         total = kept[0];
         for (int64_t t : kept) if (t != total) throw std::runtime_error("the devices disagree on the sample set");
     }
-    if (n > 0) m_Ctx->doubling = {(double)n, HostProfile::now() - w0};
+    if (n > 0) {
+        const double took = HostProfile::now() - w0;
+        noteOperation(2, w0, m_Stats.Iterations > 0 ? m_Ctx->predictDoubling((double)n) : 0.0, took);
+        m_Ctx->doubling = {(double)n, took};
+    }
     if (n > 0) m_NumSamples = (long)total;
     m_Speculated.clear();   // children costed ahead were chosen among the old samples
 }
@@ -450,7 +496,7 @@ int GpuAStarPlanner::costStateEdges(int source, const std::vector<State>& target
             const bool cov = (cfgBits[i] & PPGPU_EDGE_COVERAGE) != 0;
             g_dump.write(m_Nodes[source].state, res[i], cov ? m_Config.coverageTurningRadius() : m_Config.turningRadius(), cov);
         }
-        m_Nodes.push_back(makeChild(source, cfgBits[i], res[i], child.data() + i * (size_t)stride * 4, stride));
+        addNode(makeChild(source, cfgBits[i], res[i], child.data() + i * (size_t)stride * 4, stride));
         visualizeTrajectory(m_Nodes.back());
         pushVertexQueue((int)m_Nodes.size() - 1);
     }
@@ -529,9 +575,13 @@ void GpuAStarPlanner::expandOn(GpuContext& ctx, const std::vector<int>& sources,
 void GpuAStarPlanner::expandBatch(const std::vector<int>& sources) {
     g_prof.trips++;
     struct TripTimer {
-        GpuContext& c; double samples, w0;
-        ~TripTimer() { c.noteTrip(samples, HostProfile::now() - w0); }
-    } tripTimer{*m_Ctx, (double)m_NumSamples, HostProfile::now()};
+        GpuAStarPlanner& self; GpuContext& c; double samples, w0, predicted;
+        ~TripTimer() {
+            const double took = HostProfile::now() - w0;
+            self.noteOperation(1, w0, predicted, took);
+            c.noteTrip(samples, took);
+        }
+    } tripTimer{*this, *m_Ctx, (double)m_NumSamples, HostProfile::now(), m_Ctx->predictTrip((double)m_NumSamples)};
     const size_t D = std::min(m_Ctxs.size(), sources.size());
     std::vector<std::vector<std::pair<int, Costed>>> parts(std::max<size_t>(D, 1));
     std::vector<unsigned long> costed(parts.size(), 0);
@@ -595,7 +645,7 @@ void GpuAStarPlanner::expand(int source) {
         const bool truncated = (r.flags & PPGPU_F_RIBBON_OVF) && (int)((r.info >> 8) & 0xff) > costed.stride;
         const bool plainInfeasible = (r.flags & PPGPU_F_INFEASIBLE) && !(r.flags & (PPGPU_F_THROWS | PPGPU_F_DUBINS_ERR | PPGPU_F_RIBBON_LOST)) && !truncated;
         if (plainInfeasible && !watch) continue;
-        m_Nodes.push_back(makeChild(source, costed.cfgBits[e], r, costed.childRibbons.data() + e * (size_t)costed.stride * 4, costed.stride));
+        addNode(makeChild(source, costed.cfgBits[e], r, costed.childRibbons.data() + e * (size_t)costed.stride * 4, costed.stride));
         visualizeTrajectory(m_Nodes.back());   // in the reference each edge streams its sweep, then its vertex is pushed
         pushVertexQueue((int)m_Nodes.size() - 1);
     }
@@ -613,8 +663,10 @@ int GpuAStarPlanner::aStar(double endTime) {   // AStarPlanner.cpp:134-148
         }
         // Planner.h:42 "guaranteed to return before timeRemaining has elapsed": an expansion whose children are not costed yet is a
         // device round trip; one that, going by the last ones, would end after the deadline is not started
-        if (guard && !m_Speculated.count(vertex) && t + m_Ctx->predictTrip((double)m_NumSamples) >= endTime) {
+        // (aimed at the deadline minus GpuContext::guardMargin(): "before", not "at")
+        if (guard && !m_Speculated.count(vertex) && t + m_Ctx->predictTrip((double)m_NumSamples) >= endTime - m_Ctx->guardMargin()) {
             m_Stats.DeadlineStops++;
+            m_DeadlineStop = true;
             return -1;
         }
         expand(vertex);
@@ -644,6 +696,7 @@ DubinsPlan GpuAStarPlanner::tracePlan(int v, bool addToStats) {   // Planner.cpp
 // ------------------------------------------------------------------------------------------------ plan()
 Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const State& start, PlannerConfig config,
                                      const DubinsPlan& previousPlan, double timeRemaining) {   // AStarPlanner.cpp:12-132
+    m_PlanEntry = HostProfile::now();
     m_Config = std::move(config);
     double endTime = timeRemaining + now();
     m_Config.setStartStateTime(start.time());
@@ -653,10 +706,18 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
     m_Stats = Stats();
     m_StartStateTime = start.time();
     m_Nodes.clear();
+    // the node array the context keeps between cycles (capacity and pages survive; a regrowth that happens all the same — the
+    // first cycles of a process — is counted in Stats::Budget)
+    if (m_Nodes.capacity() < m_Ctx->nodeArena.capacity()) { m_Ctx->nodeArena.clear(); m_Nodes.swap(m_Ctx->nodeArena); }
+    if (m_Nodes.capacity() < kNodeArenaMin) m_Nodes.reserve(kNodeArenaMin);
     m_Queue.clear();
     m_Speculated.clear();
     m_NumSamples = 0;
+    m_DeadlineStop = false;
     ppgpu_ctx* h = m_Ctx->handle();
+    uint64_t growthsBefore = 0;
+    double growthSecondsBefore = 0;
+    (void)ppgpu_growth_stats(h, &growthsBefore, &growthSecondsBefore);
     unsigned long orderFallbacksBefore = 0;
     for (const auto& ctx : m_Ctxs) orderFallbacksBefore += (unsigned long)ppgpu_order_fallbacks(ctx->handle());
     uploadWorld(start);
@@ -753,7 +814,7 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
                 }
                 c.wrapper = p;
                 if (!c.infeasible && r.end_time < c.wrapper.getEndTime()) c.wrapper.updateEndTime(r.end_time);
-                m_Nodes.push_back(std::move(c));
+                addNode(std::move(c));
             }
             if (m_Nodes.size() == before) break;
             lastPlanEnd = (int)m_Nodes.size() - 1;
@@ -767,6 +828,8 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
     }
 
     // big loop (:61-119)
+    m_Stats.Budget.PrologueMs = 1e3 * (HostProfile::now() - m_PlanEntry);
+    const bool guard = m_Config.deadlineGuard();
     double tPoll;
     while ((tPoll = now()) < endTime) {
         m_Queue.clear();
@@ -789,6 +852,13 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
         if (lastPlanEnd != startV) pushVertexQueue(lastPlanEnd);
         // expandToCoverSpecificSamples(startV, brownPathSamples, ..., true) (:150-162)
         if (!brownPathSamples.empty() && m_Config.coverageTurningRadius() > 0) {
+            // (a device round trip like any other: after the first pass it is not started when it cannot end in time)
+            const double brownPredicted = m_Ctx->predictTrip((double)m_NumSamples);
+            if (guard && m_Stats.Iterations > 0 && tPoll + brownPredicted >= endTime - m_Ctx->guardMargin()) {
+                m_Stats.DeadlineStops++;
+                break;
+            }
+            const double brown0 = HostProfile::now();
             ppgpu_vertex v = makeVertex(m_Nodes[startV]);
             std::vector<double> rib;
             ribbonsToArray(m_Nodes[startV].ribbons, rib);
@@ -801,12 +871,13 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
                 t.push_back(s); c.push_back(PPGPU_EDGE_COVERAGE | PPGPU_EDGE_SLOW); si.push_back(-1);
             }
             costStateEdges(startV, t, c, si);
+            noteOperation(3, brown0, m_Stats.Iterations > 0 ? brownPredicted : 0.0, HostProfile::now() - brown0);
         }
         // first iteration: initialSamples; afterwards double them (:101-102)
         const long moreSamples = m_NumSamples < m_Config.initialSamples() ? m_Config.initialSamples() : m_NumSamples;
         // the deadline guard: a doubling that, with the one round trip that makes it worth anything, cannot end in time is not started
-        if (m_Config.deadlineGuard() && m_Stats.Iterations > 0 &&
-            tPoll + m_Ctx->predictDoubling((double)moreSamples) + m_Ctx->predictTrip((double)(m_NumSamples + moreSamples)) >= endTime) {
+        if (guard && m_Stats.Iterations > 0 &&
+            tPoll + m_Ctx->predictDoubling((double)moreSamples) + m_Ctx->predictTrip((double)(m_NumSamples + moreSamples)) >= endTime - m_Ctx->guardMargin()) {
             m_Stats.DeadlineStops++;
             break;
         }
@@ -822,7 +893,12 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
         }
         if (v >= 0 && m_Stats.FirstGoalIteration < 0) m_Stats.FirstGoalIteration = (long)m_Stats.Iterations;
         m_Stats.Iterations++;
+        // aStar() left because its next round trip could not end in time: neither can another pass of this loop (which would begin with
+        // the Brown-path round trip and a sample doubling) — the reference's loop would find the clock past endTime at this point
+        if (m_DeadlineStop) break;
     }
+    m_Stats.Budget.LoopEndMs = 1e3 * (HostProfile::now() - m_PlanEntry);
+    m_Stats.Budget.MarginMs = guard ? 1e3 * m_Ctx->guardMargin() : 0.0;
     m_Stats.Samples = (unsigned long)m_NumSamples;
     if (m_Best < 0) {
         *m_Config.output() << "Failed to find a plan" << std::endl;
@@ -836,6 +912,15 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
     for (const auto& ctx : m_Ctxs) m_Stats.OrderFallbacks += (unsigned long)ppgpu_order_fallbacks(ctx->handle());
     m_Stats.OrderFallbacks -= orderFallbacksBefore;
     g_prof.report("plan()");
+    {
+        uint64_t growths = 0;
+        double growthSeconds = 0;
+        if (ppgpu_growth_stats(h, &growths, &growthSeconds) == PPGPU_OK) {
+            m_Stats.Budget.DeviceGrowths = (unsigned long)(growths - growthsBefore);
+            m_Stats.Budget.DeviceGrowthMs = 1e3 * (growthSeconds - growthSecondsBefore);
+        }
+    }
+    m_Stats.Budget.TotalMs = 1e3 * (HostProfile::now() - m_PlanEntry);
     return m_Stats;
 }
 
@@ -847,23 +932,42 @@ ShardedIteration::ShardedIteration(std::vector<std::shared_ptr<GpuContext>> ctxs
     bool distinct = true;
     for (size_t i = 0; i < D; i++)
         for (size_t j = 0; j < i; j++) distinct = distinct && m_Ctxs[i]->device() != m_Ctxs[j]->device();
-    for (size_t i = 0; i < D; i++)
-        if (ppgpu_device_alloc(m_Ctxs[i]->handle(), 16, &m_Keys[i]) != PPGPU_OK) throw std::runtime_error(std::string("ppgpu_device_alloc: ") + ppgpu_last_error());
-    if (distinct) {
-        std::vector<ppgpu_ctx*> hs;
-        for (auto& c : m_Ctxs) { ppgpu_comm_destroy(c->handle()); hs.push_back(c->handle()); }
-        if (ppgpu_comm_init_all(hs.data(), (int32_t)D) != PPGPU_OK) throw std::runtime_error(std::string("ppgpu_comm_init_all: ") + ppgpu_last_error());
-        m_Rccl = true;
+    try {
+        // a context that already carries a communicator belongs to someone else's collective (GpuContext::shared handles are
+        // process-level): refuse rather than tear it down under its owner
+        if (distinct)
+            for (auto& c : m_Ctxs) {
+                int32_t world = 0, rank = 0;
+                if (ppgpu_comm_info(c->handle(), &world, &rank) == PPGPU_OK)
+                    throw std::runtime_error("ShardedIteration: device " + std::to_string(c->device()) + " already has a communicator (" +
+                                             std::to_string(world) + " ranks) that this object did not create");
+            }
+        for (size_t i = 0; i < D; i++)
+            if (ppgpu_device_alloc(m_Ctxs[i]->handle(), 16, &m_Keys[i]) != PPGPU_OK) throw std::runtime_error(std::string("ppgpu_device_alloc: ") + ppgpu_last_error());
+        if (distinct) {
+            std::vector<ppgpu_ctx*> hs;
+            for (auto& c : m_Ctxs) hs.push_back(c->handle());
+            // (all handles get a communicator or none does: ppgpu_comm_init_all cleans up after itself)
+            if (ppgpu_comm_init_all(hs.data(), (int32_t)D) != PPGPU_OK) throw std::runtime_error(std::string("ppgpu_comm_init_all: ") + ppgpu_last_error());
+            m_Rccl = true;
+        }
+    } catch (...) {
+        release();        // the destructor does not run for a constructor that throws
+        throw;
     }
 }
 
-ShardedIteration::~ShardedIteration() {
+void ShardedIteration::release() {
     for (size_t i = 0; i < m_Ctxs.size(); i++) {
-        if (m_Rccl) ppgpu_comm_destroy(m_Ctxs[i]->handle());
+        if (m_Rccl) ppgpu_comm_destroy(m_Ctxs[i]->handle());      // only the communicators this object created
         ppgpu_device_free(m_Ctxs[i]->handle(), m_Keys[i]);
         ppgpu_device_free(m_Ctxs[i]->handle(), m_Records[i]);
+        m_Keys[i] = nullptr; m_Records[i] = nullptr; m_RecordCap[i] = 0;
     }
+    m_Rccl = false;
 }
+
+ShardedIteration::~ShardedIteration() { release(); }
 
 ShardedIteration::Result ShardedIteration::run(const RibbonManager& ribbonManager, const State& start, const PlannerConfig& config, unsigned long seed,
                                                int64_t attempts) {
@@ -887,9 +991,11 @@ ShardedIteration::Result ShardedIteration::run(const RibbonManager& ribbonManage
     Result out;
     out.kept.assign(D, 0);
     std::vector<uint64_t> keys(2 * D, ~0ull);
-    auto shard = [&](size_t d) {
+    auto check = [](int rc, const char* what) { if (rc != PPGPU_OK) throw std::runtime_error(std::string(what) + ": " + ppgpu_last_error()); };
+    // Phase 1, per shard, no collective in it: skip, draw, cost, reduce to the shard's best key (left on the device).
+    auto local = [&](size_t d) {
         ppgpu_ctx* h = m_Ctxs[d]->handle();
-        auto check = [](int rc, const char* what) { if (rc != PPGPU_OK) throw std::runtime_error(std::string(what) + ": " + ppgpu_last_error()); };
+        if ((int)d == failShardForTest) throw std::runtime_error("ShardedIteration: injected failure in shard " + std::to_string(d));
         const int64_t lo = (int64_t)d * base + std::min<int64_t>((int64_t)d, extra), n = base + ((int64_t)d < extra ? 1 : 0);
         check(ppgpu_set_vertices(h, 1, &root, root.ribbon_count, rib.empty() ? nullptr : rib.data()), "ppgpu_set_vertices");
         check(ppgpu_sampler_init(h, bounds, seed, (int32_t)(rib.size() / 4), rib.empty() ? nullptr : rib.data()), "ppgpu_sampler_init");
@@ -906,19 +1012,37 @@ ShardedIteration::Result ShardedIteration::run(const RibbonManager& ribbonManage
         }
         if (kept > 0) check(ppgpu_cost_edges_dense(h, 0, 1, 0, kept, 0xF, (ppgpu_edge_result*)m_Records[d], nullptr, 0), "ppgpu_cost_edges_dense");
         check(ppgpu_best_edge(h, 4 * kept, (const ppgpu_edge_result*)m_Records[d], 0, (uint64_t)d * (uint64_t)edgesPerShard, (uint64_t*)m_Keys[d]), "ppgpu_best_edge");
-        if (m_Rccl) check(ppgpu_allreduce_best(h, nullptr, (uint64_t*)m_Keys[d]), "ppgpu_allreduce_best");   // the one collective of the iteration
+    };
+    // Phase 2: the one collective of the iteration, entered only when EVERY shard got through phase 1 — a rank that never joins
+    // an all-gather leaves the others waiting on their streams for ever, with no error anywhere — then the key comes home.
+    auto combine = [&](size_t d) {
+        ppgpu_ctx* h = m_Ctxs[d]->handle();
+        if (m_Rccl) check(ppgpu_allreduce_best(h, nullptr, (uint64_t*)m_Keys[d]), "ppgpu_allreduce_best");
         check(ppgpu_device_read(h, &keys[2 * d], m_Keys[d], 16), "ppgpu_device_read");
     };
-    if (D == 1) {
-        shard(0);
-    } else {
-        for (size_t d = 0; d < D; d++) m_Ctxs[d]->run([&, d] { shard(d); });
+    // each phase on every context's own host thread; all of them joined before anything is thrown
+    auto onAll = [&](const std::function<void(size_t)>& phase, bool abortOthersOnFailure) {
+        if (D == 1) { phase(0); return; }
+        for (size_t d = 0; d < D; d++) m_Ctxs[d]->run([&, d] { phase(d); });
         std::exception_ptr first;
         for (size_t d = 0; d < D; d++) {
-            try { m_Ctxs[d]->wait(); } catch (...) { if (!first) first = std::current_exception(); }
+            try { m_Ctxs[d]->wait(); } catch (...) {
+                if (!first) {
+                    first = std::current_exception();
+                    // a rank failed INSIDE the collective phase: the ranks still waiting for it are released by aborting their
+                    // communicators (ncclCommAbort is made for exactly this); the object is unusable for RCCL afterwards
+                    if (abortOthersOnFailure && m_Rccl) {
+                        for (size_t o = 0; o < D; o++) if (o != d) (void)ppgpu_comm_abort(m_Ctxs[o]->handle());
+                        (void)ppgpu_comm_abort(m_Ctxs[d]->handle());
+                        m_Rccl = false;
+                    }
+                }
+            }
         }
         if (first) std::rethrow_exception(first);
-    }
+    };
+    onAll(local, false);
+    onAll(combine, true);
     for (size_t d = 0; d < D; d++) out.edges += 4 * out.kept[d];
     if (m_Rccl) {
         int32_t world = 0, rank = 0;

@@ -4,6 +4,7 @@
 // and dense track tables.
 #include "path_planner_amd/World.h"
 
+#include <atomic>
 #include <cmath>
 #include <sstream>
 #include <stdexcept>
@@ -11,6 +12,11 @@
 namespace ppamd {
 
 // ------------------------------------------------------------------------------------------------ maps
+unsigned long Map::nextVersion() {
+    static std::atomic<unsigned long> counter{0};
+    return ++counter;
+}
+
 void Map::rasterize(std::vector<uint8_t>& cells, int& rows, int& cols, double& res) const {
     // Any map that answers isBlocked/extremes/resolution can feed the device: sample it at the cell centres of a grid anchored
     // at the origin.  A map without a cell size or without finite bounds (the base Map) uploads as "no grid".

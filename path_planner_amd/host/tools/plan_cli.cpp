@@ -41,6 +41,8 @@ int main(int argc, char** argv) {
     std::vector<int> devices;
     long long shardedAttempts = 0;
     unsigned long shardedSeed = 7;
+    int failShard = -1;
+    std::string cycleLogPath;
     std::string line;
     while (std::getline(in, line)) {
         std::istringstream s(line);
@@ -82,6 +84,8 @@ int main(int argc, char** argv) {
         } else if (k == "devices") {          // device ids of the planner; an id that repeats gets its own second context on that device
             int d; while (s >> d) devices.push_back(d);
         } else if (k == "sharded_batch") { s >> shardedAttempts >> shardedSeed;
+        } else if (k == "fail_shard") { s >> failShard;      // tests: this shard of a sharded_batch throws before its work
+        } else if (k == "cycle_log") { s >> cycleLogPath;    // replan: one JSON line per cycle (Stats::Budget and what the cycle reached)
         } else if (k == "repeat") { s >> repeat;
         } else if (k == "replan") { s >> replans >> replanStep;   // N consecutive cycles, start moved replanStep seconds along the plan
         } else if (k == "real_clock") { int v; s >> v; realClock = v != 0;   // now() = t0 + wall seconds since plan() began
@@ -114,6 +118,7 @@ int main(int argc, char** argv) {
     if (shardedAttempts > 0) {
         try {
             ShardedIteration it(contexts);
+            it.failShardForTest = failShard;
             ShardedIteration::Result r;
             std::vector<double> wall;
             for (int rep = 0; rep < repeat; rep++) {
@@ -142,35 +147,97 @@ int main(int argc, char** argv) {
             // along the returned plan, hand the plan back as previousPlan, repeat.  Real clock, fixed budget per cycle.
             double tNow = t0;
             State cur = start;
-            unsigned long iters = 0, expanded = 0, failures = 0, samples = 0, deadlineStops = 0;
+            unsigned long iters = 0, expanded = 0, failures = 0, samples = 0, deadlineStops = 0, edges = 0, trips = 0, gridUploads = 0;
+            unsigned long failuresExplained = 0;       // failed plans whose start state was in collision (an obstacle's box or a blocked cell)
+            unsigned long nodeRegrowths = 0, deviceGrowths = 0, late = 0;
+            long firstGoalSum = 0, firstGoalCount = 0, firstGoalMax = -1;
+            std::vector<long> firstGoals;
+            std::vector<int> failedCycles;
+            double insidePlanMs = 0;                   // plan() wall time over the cycles after the first
+            Planner::Stats::BudgetTrace worst;         // the budget trace of the slowest cycle after the first
+            int worstCycle = -1;
+            double worstMs = 0;
+            int failureCount = 0, horizonHalvings = 0;  // Executive::planLoop's back-off (executive.cpp:263-277)
+            FILE* cycleLog = cycleLogPath.empty() ? nullptr : std::fopen(cycleLogPath.c_str(), "w");
             for (int cyc = 0; cyc < replans; cyc++) {
                 const auto w0 = std::chrono::steady_clock::now();
                 config.setNowFunction([&]() { return tNow + std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count(); });
                 GpuAStarPlanner planner(contexts);
                 st = planner.plan(rm, cur, config, prev, timeRemaining);
                 wall.push_back(1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count());
-                iters += st.Iterations; expanded += st.Expanded; samples += st.Samples; deadlineStops += st.DeadlineStops;
-                if (cyc > 0 && wall.back() > 1.25e3 * timeRemaining)      // an overrun: what was the cycle doing?
-                    std::fprintf(stderr, "[replan] cycle %d: %.1f ms, %lu iterations, %lu samples, %lu expanded\n", cyc, wall.back(),
+                iters += st.Iterations; expanded += st.Expanded; samples += st.Samples; deadlineStops += st.DeadlineStops; edges += st.EdgesCosted;
+                trips += st.Budget.RoundTrips; gridUploads += st.Budget.GridUploaded ? 1 : 0;
+                nodeRegrowths += st.Budget.NodeRegrowths; deviceGrowths += st.Budget.DeviceGrowths;
+                if (st.FirstGoalIteration >= 0) { firstGoalSum += st.FirstGoalIteration; firstGoalCount++; firstGoalMax = std::max(firstGoalMax, st.FirstGoalIteration); }
+                firstGoals.push_back(st.FirstGoalIteration);
+                const bool startHit = config.obstaclesManager().collisionExists(cur, true) > 0 || (config.map() && config.map()->isBlocked(cur.x(), cur.y()));
+                if (cyc > 0) {
+                    insidePlanMs += wall.back();
+                    if (wall.back() >= 1e3 * timeRemaining) late++;
+                    if (wall.back() > worstMs) { worstMs = wall.back(); worst = st.Budget; worstCycle = cyc; }
+                }
+                const Planner::Stats::BudgetTrace& b = st.Budget;
+                if (cycleLog)
+                    std::fprintf(cycleLog, "{\"cycle\": %d, \"wall_ms\": %.3f, \"iterations\": %lu, \"first_goal_iteration\": %ld, \"samples\": %lu, \"expanded\": %lu, "
+                                 "\"edges\": %lu, \"round_trips\": %lu, \"deadline_stops\": %lu, \"plan_empty\": %s, \"start_in_collision\": %s, \"prologue_ms\": %.3f, "
+                                 "\"loop_end_ms\": %.3f, \"total_ms\": %.3f, \"last_op\": %d, \"last_op_start_ms\": %.3f, \"last_op_predicted_ms\": %.3f, "
+                                 "\"last_op_actual_ms\": %.3f, \"margin_ms\": %.3f, \"max_trip_ms\": %.3f, \"worst_under_prediction_ms\": %.3f, \"node_regrowths\": %lu, "
+                                 "\"node_regrowth_ms\": %.3f, \"device_growths\": %lu, \"device_growth_ms\": %.3f, \"grid_uploaded\": %s}\n",
+                                 cyc, wall.back(), (unsigned long)st.Iterations, st.FirstGoalIteration, (unsigned long)st.Samples, (unsigned long)st.Expanded,
+                                 (unsigned long)st.EdgesCosted, b.RoundTrips, (unsigned long)st.DeadlineStops, st.Plan.empty() ? "true" : "false", startHit ? "true" : "false",
+                                 b.PrologueMs, b.LoopEndMs, b.TotalMs, b.LastOpKind, b.LastOpStartMs, b.LastOpPredictedMs, b.LastOpActualMs, b.MarginMs, b.MaxTripMs,
+                                 b.WorstUnderPredictionMs, b.NodeRegrowths, b.NodeRegrowthMs, b.DeviceGrowths, b.DeviceGrowthMs, b.GridUploaded ? "true" : "false");
+                if (cyc > 0 && wall.back() >= 1e3 * timeRemaining)      // late: what was the cycle doing when the budget ran out?
+                    std::fprintf(stderr, "[replan] cycle %d LATE: %.3f ms of %.1f | loop left at %.3f, last op kind %d started %.3f predicted %.3f took %.3f (margin %.3f) | "
+                                 "max trip %.3f, worst under-prediction %.3f | node regrowths %lu (%.3f ms), device growths %lu (%.3f ms), prologue %.3f | %lu iterations, %lu samples, %lu expanded\n",
+                                 cyc, wall.back(), 1e3 * timeRemaining, b.LoopEndMs, b.LastOpKind, b.LastOpStartMs, b.LastOpPredictedMs, b.LastOpActualMs, b.MarginMs, b.MaxTripMs,
+                                 b.WorstUnderPredictionMs, b.NodeRegrowths, b.NodeRegrowthMs, b.DeviceGrowths, b.DeviceGrowthMs, b.PrologueMs,
                                  (unsigned long)st.Iterations, (unsigned long)st.Samples, (unsigned long)st.Expanded);
                 tNow += replanStep;
-                if (st.Plan.empty()) { failures++; cur.time() = tNow; prev = DubinsPlan(); continue; }
+                if (st.Plan.empty()) {
+                    failures++; failedCycles.push_back(cyc);
+                    if (startHit) failuresExplained++;
+                    // executive.cpp:263-277: the third empty plan in a row halves the time horizon (never below timeMinimum, never restored)
+                    failureCount++;
+                    if (failureCount > 2) {
+                        config.setTimeHorizon(config.timeHorizon() / 2);
+                        if (config.timeHorizon() < config.timeMinimum()) config.setTimeHorizon(config.timeMinimum());
+                        else { failureCount = 0; horizonHalvings++; }
+                    }
+                    cur.time() = tNow; prev = DubinsPlan(); continue;
+                }
+                failureCount = 0;                       // executive.cpp:220
                 prev = st.Plan;
                 State nxt; nxt.time() = tNow;
                 if (prev.containsTime(tNow)) { prev.sample(nxt); cur = nxt; } else { cur.time() = tNow; }
                 cur.speed() = config.maxSpeed();
                 rm.cover(cur.x(), cur.y(), false);      // Executive::updateCovered: the vehicle covers as it moves
             }
+            if (cycleLog) std::fclose(cycleLog);
             // the first cycle of a process allocates the device buffers (they persist in the contexts): reported on its own,
             // the percentiles are over the cycles after it
             const double firstCycle = wall.front();
             if (wall.size() > 1) wall.erase(wall.begin());
             std::sort(wall.begin(), wall.end());
             const double p50 = wall[wall.size() / 2], p99 = wall[std::min(wall.size() - 1, (size_t)(0.99 * wall.size()))];
+            std::vector<long> fg = firstGoals;
+            std::sort(fg.begin(), fg.end());
             std::printf("{\"replans\": %d, \"budget_ms\": %.3f, \"first_cycle_ms\": %.3f, \"wall_ms_p50\": %.3f, \"wall_ms_p99\": %.3f, \"wall_ms_max\": %.3f, "
-                        "\"mean_iterations\": %.2f, \"mean_expanded\": %.1f, \"mean_samples\": %.1f, \"failed_plans\": %lu, \"deadline_stops\": %lu, \"devices\": %zu}\n",
-                        replans, 1e3 * timeRemaining, firstCycle, p50, p99, wall.back(), (double)iters / replans, (double)expanded / replans,
-                        (double)samples / replans, failures, deadlineStops, contexts.size());
+                        "\"late_cycles\": %lu, \"mean_iterations\": %.2f, \"mean_expanded\": %.1f, \"mean_samples\": %.1f, \"mean_edges\": %.1f, \"mean_round_trips\": %.1f, "
+                        "\"first_goal_iteration_median\": %ld, \"first_goal_iteration_max\": %ld, \"first_goal_iteration_mean\": %.3f, \"cycles_with_a_goal\": %ld, "
+                        "\"failed_plans\": %lu, \"failed_plans_with_start_in_collision\": %lu, \"horizon_halvings\": %d, \"final_time_horizon\": %.3f, \"deadline_stops\": %lu, \"grid_uploads\": %lu, "
+                        "\"node_regrowths\": %lu, \"device_growths\": %lu, \"expansions_per_s_inside_plan\": %.1f, \"edges_per_s_inside_plan\": %.1f, "
+                        "\"worst_cycle\": {\"cycle\": %d, \"wall_ms\": %.3f, \"loop_end_ms\": %.3f, \"last_op\": %d, \"last_op_start_ms\": %.3f, \"last_op_predicted_ms\": %.3f, "
+                        "\"last_op_actual_ms\": %.3f, \"margin_ms\": %.3f, \"max_trip_ms\": %.3f, \"node_regrowths\": %lu, \"node_regrowth_ms\": %.3f, \"device_growths\": %lu, "
+                        "\"device_growth_ms\": %.3f, \"prologue_ms\": %.3f}, \"failed_cycles\": [",
+                        replans, 1e3 * timeRemaining, firstCycle, p50, p99, wall.back(), late, (double)iters / replans, (double)expanded / replans,
+                        (double)samples / replans, (double)edges / replans, (double)trips / replans, fg[fg.size() / 2], firstGoalMax,
+                        firstGoalCount ? (double)firstGoalSum / firstGoalCount : -1.0, firstGoalCount, failures, failuresExplained, horizonHalvings, config.timeHorizon(), deadlineStops, gridUploads,
+                        nodeRegrowths, deviceGrowths, insidePlanMs > 0 ? 1e3 * (double)expanded / insidePlanMs : 0.0, insidePlanMs > 0 ? 1e3 * (double)edges / insidePlanMs : 0.0,
+                        worstCycle, worstMs, worst.LoopEndMs, worst.LastOpKind, worst.LastOpStartMs, worst.LastOpPredictedMs, worst.LastOpActualMs, worst.MarginMs,
+                        worst.MaxTripMs, worst.NodeRegrowths, worst.NodeRegrowthMs, worst.DeviceGrowths, worst.DeviceGrowthMs, worst.PrologueMs);
+            for (size_t i = 0; i < failedCycles.size(); i++) std::printf("%s%d", i ? ", " : "", failedCycles[i]);
+            std::printf("], \"devices\": %zu}\n", contexts.size());
             return 0;
         }
         for (int rep = 0; rep < repeat; rep++) {

@@ -223,6 +223,7 @@ class World:
                         prev.shape[0], _p(prev) if prev.shape[0] else None, time_remaining, clock_t0, clock_dt, C.byref(st),
                         _p(plan), 64, _p(itf), 256, _p(dump), dump_edges, C.byref(ne))
         O.ppo_world_set_tsp_limit(self.h, 8)
+        self.last_plan_edges = int(ne.value) if dump_edges else None      # edges the planner true-costed (counted only while dumping)
         return rc, st, plan[:max(st.plan_len, 0)].copy(), itf[:st.iterations].copy(), (dump[:min(ne.value, dump_edges)] if dump_edges else None)
 
 

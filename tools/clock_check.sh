@@ -3,6 +3,7 @@
 # usage: tools/clock_check.sh   -> gpurun_out/clock.txt
 set -e
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+export PP_BENCH_PROFILED=1      # bench.py under rocprofv3: only the headline launches (no open-vertex run, no plan()-level legs)
 mkdir -p gpurun_out
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/clock -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/clock.log 2>&1
 python3 - <<'PY'

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: LDS-side counters of one bench step (own pass: counters only with --kernel-trace)
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+export PP_BENCH_PROFILED=1      # bench.py under rocprofv3: only the headline launches (no open-vertex run, no plan()-level legs)
 rm -rf gpurun_out/pmc_lds
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --kernel-trace --output-format csv -d gpurun_out/pmc_lds -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_lds.log 2>&1 || { tail -5 gpurun_out/pmc_lds.log; exit 1; }
 python3 - <<'PY'

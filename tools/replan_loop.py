@@ -11,7 +11,7 @@ from test_gpu_host_planner import _write_map, _scenario, CLI
 
 cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 100.0
-init = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+init = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
 spec = int(sys.argv[4]) if len(sys.argv) > 4 else None
 w = workloads.config3()
 w.obst = workloads.obstacles(32, 3, 204.8, time=float(w.start5[4]))      # uniform in the map: no free disc around the start
@@ -21,9 +21,11 @@ with tempfile.TemporaryDirectory() as d:
     _scenario(w, sc, mp, float(w.start5[4]), 1e-3, 1, init, speculation=spec)
     with open(sc, "a") as f:
         f.write(f"time_remaining {budget / 1e3!r}\nreplan {cycles} 0.1\n")
+        if os.environ.get("REPLAN_CYCLE_LOG"):
+            f.write(f"cycle_log {os.environ['REPLAN_CYCLE_LOG']}\n")
     out = subprocess.run([CLI, sc], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
-    sys.stderr.write("".join(l + "\n" for l in out.stderr.splitlines() if l.startswith("[replan]")))
+    sys.stderr.write("".join(l + "\n" for l in out.stderr.splitlines() if l.startswith("[replan]") or l.startswith("[profile]")))
     r = json.loads(out.stdout.strip().splitlines()[-1])
     r.update({"initial_samples": init, "speculation": spec if spec is not None else 16, "obstacles": 32, "workload": "cfg3 grid, 5 ribbons"})
     print(json.dumps(r))

@@ -44,7 +44,10 @@ out["costing_kernels"] = list(COSTING)
 out["hbm_bytes_per_costing_launch"] = sum(out["kernels"].get(k, {}).get("fetch_size_bytes", 0.0) + out["kernels"].get(k, {}).get("write_size_bytes", 0.0) for k in COSTING)
 import hashlib
 _h = hashlib.sha256()
-for _f in ("ppgpu.hip", "pp_kernels.h", "pp_device.h", "pp_sampler.h", "pp_cr.h", "pp_cr_tables.h"):
+import sys
+sys.path.insert(0, ROOT)
+from bench import KERNEL_SOURCES
+for _f in KERNEL_SOURCES:
     _h.update(open(os.path.join(ROOT, "path_planner_amd", "csrc", _f), "rb").read())
 out["kernel_sources_sha256"] = _h.hexdigest()       # bench.py reports these bytes only while the sources are the ones measured
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -3,6 +3,7 @@
 # usage: tools/variant_stats.sh name1 "flags1" [name2 "flags2" ...]
 mkdir -p gpurun_out/abl
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+export PP_BENCH_PROFILED=1      # bench.py under rocprofv3: only the headline launches (no open-vertex run, no plan()-level legs)
 while [ $# -ge 2 ]; do
     name=$1; flags=$2; shift 2
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 $flags path_planner_amd/csrc/ppgpu.hip -o gpurun_out/abl/libppgpu_$name.so -ldl || exit 1

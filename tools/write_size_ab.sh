@@ -6,6 +6,7 @@ mkdir -p gpurun_out/abl
 variants=("$@"); [ ${#variants[@]} -eq 0 ] && variants=("fuse0=-DPP_FUSE_HEUR=0")
 variants+=("default=")
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+export PP_BENCH_PROFILED=1      # bench.py under rocprofv3: only the headline launches (no open-vertex run, no plan()-level legs)
 for v in "${variants[@]}"; do
   name=${v%%=*}; flags=${v#*=}
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 $flags path_planner_amd/csrc/ppgpu.hip -o gpurun_out/abl/libppgpu_$name.so -ldl
