@@ -549,7 +549,7 @@ def plan_level(cycles, cpu_baseline=True):
             mp = os.path.join(d, "grid.map")
             _write_map(w.grid, w.res, mp)
             sc = os.path.join(d, "s.txt")
-            _scenario(w, sc, mp, float(w.start5[4]), 1e-3, 1, init)
+            _scenario(w, sc, mp, float(w.start5[4]), 1e-3, 1, init, devices=[0, 0])     # two contexts = two HIP streams on the one GPU
             with open(sc, "a") as f:
                 f.write(f"time_remaining {budget_s!r}\nreplan {cycles} 0.1\n")
             run = subprocess.run([CLI, sc], capture_output=True, text=True, timeout=600)
@@ -557,7 +557,8 @@ def plan_level(cycles, cpu_baseline=True):
             raise RuntimeError(run.stdout[-400:] + run.stderr[-400:])
         r = json.loads(run.stdout.strip().splitlines()[-1])
         replan = {"workload": "cfg5: cfg3 grid (2048x2048 @0.1 m, 10 % blocked), 5 ribbons, 32 moving obstacles uniform in the map, moving start, "
-                              "previous plan handed back; ONE GPU (BASELINE's 8-GPU form is not the builder's to run)",
+                              "previous plan handed back; ONE GPU, two device contexts (streams) so that two round trips are in flight "
+                              "(BASELINE's 8-GPU form is not the builder's to run)",
                   "budget_ms": 1e3 * budget_s, "initial_samples": init, "cycles": cycles,
                   "plan_latency_ms": {"p50": r["wall_ms_p50"], "p99": r["wall_ms_p99"], "max": r["wall_ms_max"], "first_cycle": r["first_cycle_ms"]},
                   "late_cycles": r["late_cycles"], "iterations_per_cycle": r["mean_iterations"],

@@ -2919,33 +2919,58 @@ __device__ __forceinline__ void pp_ord_set(PPOrdHeap& h, int slot, double cost, 
 __device__ __forceinline__ void pp_ord_move(PPOrdHeap& h, int to, int from) {
     pp_ord_set(h, to, pp_readlane(h.cost, from), pp_readlane(h.len, from), pp_readlane_i(h.idx, from));
 }
-// std::__push_heap(first, holeIndex, topIndex = 0, value, comp = cost <)
+// std::__push_heap(first, holeIndex, topIndex = 0, value, comp = cost <): the value climbs from `hole` past every ancestor whose
+// cost is below it, until the first one that is not; the ancestors it passes move one step down the path.  Round 4: the whole
+// climb at once instead of a loop of read-lane / compare / move per level (the replay's exact heap steps were 0.8 us each, most of
+// pp_k_expand_order's 117 us on a planner round trip).  Lane a is an ancestor of `hole` iff (hole + 1) >> (level difference) == a + 1;
+// ancestors have smaller indices the nearer the root, so "the first ancestor, seen from the hole, that is not below the value" is
+// the HIGHEST lane among the ancestors that are not below it, and the ones passed are the ancestors above that lane.
 __device__ __forceinline__ void pp_ord_sift_up(PPOrdHeap& h, int hole, double cost, double len, int idx) {
-    while (hole > 0) {
-        const int parent = (hole - 1) >> 1;
-        if (!(pp_readlane(h.cost, parent) < cost)) break;
-        pp_ord_move(h, hole, parent);
-        hole = parent;
-    }
-    pp_ord_set(h, hole, cost, len, idx);
+    const int lane = pp_lane();
+    const int lh = 31 - __clz(hole + 1), ll = 31 - __clz(lane + 1);
+    const bool onPath = (ll <= lh) && (((hole + 1) >> (lh - ll)) == lane + 1);          // the hole and its ancestors
+    const bool isAnc = onPath && lane != hole;
+    const unsigned long long anc = __ballot(isAnc);
+    const unsigned long long stays = __ballot(isAnc && !(h.cost < cost));                // `comp(first + parent, value)` false
+    unsigned long long passed = anc;
+    if (stays) passed &= ~((2ull << (63 - __clzll((long long)stays))) - 1ull);            // only the ancestors between the hole and the first that stays
+    // every lane of the path whose parent is passed takes its parent's entry
+    const int par = lane > 0 ? ((lane - 1) >> 1) : 0;
+    const double pc = __shfl(h.cost, par, PP_WAVE), pl = __shfl(h.len, par, PP_WAVE);
+    const int pi = __shfl(h.idx, par, PP_WAVE);
+    const bool recv = onPath && lane > 0 && ((passed >> par) & 1ull) != 0ull;
+    h.cost = recv ? pc : h.cost; h.len = recv ? pl : h.len; h.idx = recv ? pi : h.idx;
+    const int fin = passed ? (__ffsll((long long)passed) - 1) : hole;                     // the topmost ancestor passed, or the hole itself
+    pp_ord_set(h, fin, cost, len, idx);
 }
-// std::pop_heap on n + 1 elements: the last one is taken out as `value`, the root leaves, std::__adjust_heap(first, 0, n, value)
+// std::pop_heap on n + 1 elements: the last one is taken out as `value`, the root leaves, std::__adjust_heap(first, 0, n, value):
+// the hole sinks from the root to a leaf — at every node to the larger child, the RIGHT one on equal costs, a lone left child when
+// n is even — the children on that path move up one step, and the value climbs back from the leaf (__push_heap).  Every node's
+// choice is made at once (two shuffles), the path is then a handful of read-lanes.
 __device__ __forceinline__ void pp_ord_pop(PPOrdHeap& h, int n) {
+    const int lane = pp_lane();
     const double vc = pp_readlane(h.cost, n), vl = pp_readlane(h.len, n);
     const int vi = pp_readlane_i(h.idx, n);
-    int hole = 0, second = 0;
-    while (second < (n - 1) / 2) {
-        second = 2 * (second + 1);
-        if (pp_readlane(h.cost, second) < pp_readlane(h.cost, second - 1)) second--;
-        pp_ord_move(h, hole, second);
-        hole = second;
+    const int left = 2 * lane + 1, right = 2 * lane + 2;
+    const double cl = __shfl(h.cost, left < PP_WAVE ? left : 0, PP_WAVE), cr = __shfl(h.cost, right < PP_WAVE ? right : 0, PP_WAVE);
+    int pick = -1;
+    if (right < n) pick = (cr < cl) ? left : right;          // `if (comp(first + secondChild, first + (secondChild - 1))) secondChild--`
+    else if (left < n) pick = left;                          // `(len & 1) == 0 && secondChild == (len - 2) / 2`
+    unsigned long long path = 1ull;
+    int bottom = 0;
+    for (;;) {
+        const int nx = pp_readlane_i(pick, bottom);
+        if (nx < 0) break;
+        path |= 1ull << nx;
+        bottom = nx;
     }
-    if ((n & 1) == 0 && second == (n - 2) / 2) {
-        second = 2 * (second + 1);
-        pp_ord_move(h, hole, second - 1);
-        hole = second - 1;
-    }
-    pp_ord_sift_up(h, hole, vc, vl, vi);
+    // every node of the path but the last takes the entry of the child the hole went to
+    const int src = pick >= 0 ? pick : 0;
+    const double sc = __shfl(h.cost, src, PP_WAVE), sl = __shfl(h.len, src, PP_WAVE);
+    const int si = __shfl(h.idx, src, PP_WAVE);
+    const bool recv = ((path >> lane) & 1ull) != 0ull && lane != bottom;
+    h.cost = recv ? sc : h.cost; h.len = recv ? sl : h.len; h.idx = recv ? si : h.idx;
+    pp_ord_sift_up(h, bottom, vc, vl, vi);
 }
 // The four steps of the replay, each as parallel as its data allows (the first version did everything in the one workgroup of a
 // (vertex, radius): two serial passes over all samples and a gather per 64 candidates made it the slowest kernel of the planner's
@@ -3277,10 +3302,11 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
 // copy; this puts its parts where the other kernels expect them (vertex array, ribbon pool, the slots behind the stored
 // samples, flags).  Everything is 8-byte words except the flags.
 __global__ __launch_bounds__(256) void pp_k_expand_unpack(const unsigned char* blk, int nv, int n_ribbons, ppgpu_vertex* verts, double* ribbons,
-                                                        double* ex, double* ey, double* eh, unsigned char* flags) {
+                                                        double* ex, double* ey, double* eh, unsigned char* flags, unsigned* zero_word) {
     const size_t wv = (size_t)nv * (sizeof(ppgpu_vertex) / 8), wr = (size_t)n_ribbons * 4;
     const unsigned long long* src = (const unsigned long long*)blk;
     const size_t total = wv + wr + 3 * (size_t)nv;
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;      // the push-order fallback counter of this round trip
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total + (size_t)nv; i += (size_t)gridDim.x * 256) {
         if (i < wv) ((unsigned long long*)verts)[i] = src[i];
         else if (i < wv + wr) ((unsigned long long*)ribbons)[i - wv] = src[i];
@@ -3296,8 +3322,10 @@ __global__ __launch_bounds__(256) void pp_k_expand_unpack(const unsigned char* b
 // per vertex, unused slots hold an all-ones descriptor (vertex index out of range: the costing kernels skip it).
 __global__ __launch_bounds__(64) void pp_k_build_expand_edges(int nverts, int k, const int* nearest_idx /* [nv][2][k] */, const unsigned char* has_extra,
                                                              long long first_extra, int two_speeds, int two_radii, int E,
-                                                             unsigned long long* edges) {
+                                                             unsigned long long* edges, const unsigned* fallbacks, unsigned long long* header) {
     const int v = blockIdx.x * 64 + threadIdx.x;
+    // (the push-order fallback count of this round trip travels home in the block's header: one download instead of two)
+    if (v == 0 && header) header[0] = fallbacks ? (unsigned long long)*fallbacks : 0ull;
     if (v >= nverts) return;
     unsigned long long* out = edges + (size_t)v * E;
     int n = 0;

@@ -11,11 +11,16 @@
 //
 // So the stream is measured in "pair slots" (one double draw each); sample i starts at slot q_i,
 // q_{i+1} = q_i + 5 + proj(q_i), where proj(q) is a pure function of the slot (the draw at q + 4).
-// The LCG admits O(log n) jump-ahead, so proj() is evaluated for every slot in parallel; which
-// slots the chain actually visits is a linear recurrence over GF(2)-like booleans,
-//     vis[q+1] = vis[q-4] & !proj[q-4]  |  vis[q-5] & proj[q-5],
-// i.e. a prefix "product" of 6x6 boolean matrices — an associative scan.  A second (integer) scan
-// ranks the visited slots, giving every sample its slot; samples are then generated one per thread.
+// The LCG admits O(log n) jump-ahead, so proj() is evaluated for every slot in parallel.  Which slots the
+// chain visits is then a walk with ONE live state: d_q = how many slots lie between q and the next
+// visited slot (0: q itself is visited), d_0 = 0 and
+//     d_{q+1} = d_q > 0 ? d_q - 1 : 4 + proj[q].
+// Each slot is a function on the six states {0..5}; functions compose associatively, so the walk is a
+// prefix scan over function composition (18 bits per function: six 3-bit entries; a composition is six
+// table look-ups).  Rounds 1-3 scanned 6x6 boolean transition matrices of the equivalent linear recurrence
+// (vis[q+1] = vis[q-4] & !proj[q-4] | vis[q-5] & proj[q-5]: 36 bit-products per composition, most of the
+// chain kernels' instructions); the visited bits are the same.  A second (integer) scan ranks the visited
+// slots, giving every sample its slot; samples are then generated one per thread.
 #pragma once
 #include "pp_device.h"
 
@@ -40,15 +45,20 @@ __device__ __forceinline__ unsigned pp_mulmod(unsigned a, unsigned b) {
     if (r >= PP_LCG_M) r -= PP_LCG_M;
     return (unsigned)r;
 }
-// engine state after `k` calls from state x
-__device__ inline unsigned pp_lcg_jump(unsigned x, unsigned long long k) {
-    unsigned a = 16807u, acc = 1u;
-    while (k) {
-        if (k & 1ull) acc = pp_mulmod(acc, a);
-        a = pp_mulmod(a, a);
-        k >>= 1;
+// engine state after `k` calls from state x: x * 16807^k, the power from its binary digits and a table of 16807^(2^i) mod m
+struct PPLcgPowers {
+    unsigned v[64];
+    constexpr PPLcgPowers() : v() {
+        unsigned long long a = 16807ull;
+        for (int i = 0; i < 64; i++) { v[i] = (unsigned)a; a = (a * a) % PP_LCG_M; }
     }
-    return pp_mulmod(x, acc);
+};
+__device__ const PPLcgPowers pp_lcg_powers = PPLcgPowers();
+__device__ inline unsigned pp_lcg_jump(unsigned x, unsigned long long k) {
+    unsigned acc = x;
+    for (int i = 0; k; i++, k >>= 1)
+        if (k & 1ull) acc = pp_mulmod(acc, pp_lcg_powers.v[i]);
+    return acc;
 }
 // one generate_canonical<double,53> from state x (advanced by two calls)
 __device__ __forceinline__ double pp_canonical(unsigned& x) {
@@ -84,46 +94,52 @@ __device__ __forceinline__ bool pp_projection_draw(unsigned& x) {
 // Step 1, proj bits: proj[qi] bit 0 = (5th draw of a sample starting at slot pos + qi) < pi/50   (StateGenerator.cpp:22)
 
 // ------------------------------------------------------------------------------ 2. chain scan
-// 6x6 boolean matrix, row i in bits [6i, 6i+6); C = A after B.
-__device__ __forceinline__ unsigned long long pp_bm_compose(unsigned long long A, unsigned long long B) {
-    unsigned long long C = 0;
+// A function on the states {0..5}, entry d in bits [3d, 3d + 3).  pp_fn_compose(later, earlier) = later after earlier.
+#define PP_FN_IDENTITY (0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12) | (5u << 15))
+__device__ __forceinline__ unsigned pp_fn_apply(unsigned f, unsigned d) { return (f >> (3u * d)) & 7u; }
+__device__ __forceinline__ unsigned pp_fn_compose(unsigned later, unsigned earlier) {
+    unsigned r = 0;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        unsigned ra = (unsigned)((A >> (6 * i)) & 63ull);
-        unsigned rc = 0;
+    for (int d = 0; d < 6; d++) r |= ((later >> (3u * ((earlier >> (3 * d)) & 7u))) & 7u) << (3 * d);
+    return r;
+}
+// one slot: a visited slot (state 0) sends the walk 5 + proj slots on, i.e. to state 4 + proj seen from the next slot; every
+// other state counts down
+__device__ __forceinline__ unsigned pp_fn_step(unsigned p) { return (4u + p) | (0u << 3) | (1u << 6) | (2u << 9) | (3u << 12) | (4u << 15); }
+// the composition of the 256 thread aggregates of a workgroup, in thread order (later threads on the left); every thread gets it.
+// sh = 4 words of LDS.
+__device__ inline unsigned pp_fn_block_total(unsigned agg, unsigned* sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-        for (int k = 0; k < 6; k++) rc |= ((ra >> k) & 1u) ? (unsigned)((B >> (6 * k)) & 63ull) : 0u;
-        C |= (unsigned long long)rc << (6 * i);
+    for (int o = 1; o < 64; o <<= 1) {                        // lane i: the composition of lanes [i, i + 2o) after step o
+        const unsigned hi = (unsigned)__shfl_down((int)agg, o, 64);
+        if (lane + o < 64) agg = pp_fn_compose(hi, agg);
     }
-    return C;
-}
-#define PP_BM_IDENTITY (1ull | (2ull << 6) | (4ull << 12) | (8ull << 18) | (16ull << 24) | (32ull << 30))
-// transition of slot qi: V_{q+1} = M V_q with V_q = (vis[q], vis[q-1], ..., vis[q-5])
-__device__ __forceinline__ unsigned long long pp_bm_step(const unsigned char* proj, long long qi) {
-    unsigned p4 = qi >= 4 ? (proj[qi - 4] & 1u) : 0u;
-    unsigned p5 = qi >= 5 ? (proj[qi - 5] & 1u) : 0u;
-    unsigned row0 = ((p4 ^ 1u) << 4) | (p5 << 5);
-    return (unsigned long long)row0 | (1ull << 6) | (2ull << 12) | (4ull << 18) | (8ull << 24) | (16ull << 30);
-}
-// inclusive scan over the 256 thread aggregates of a workgroup; returns this thread's EXCLUSIVE prefix
-// (identity for thread 0) and the workgroup aggregate through `total`.  Later elements compose on the left.
-__device__ inline unsigned long long pp_bm_block_scan(unsigned long long agg, unsigned long long* sh, unsigned long long& total) {
-    const int t = threadIdx.x;
-    sh[t] = agg;
+    if (lane == 0) sh[wave] = agg;
     __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        unsigned long long mine = sh[t];
-        unsigned long long other = (t >= o) ? sh[t - o] : PP_BM_IDENTITY;
-        __syncthreads();
-        sh[t] = pp_bm_compose(mine, other);
-        __syncthreads();
+    const unsigned total = pp_fn_compose(sh[3], pp_fn_compose(sh[2], pp_fn_compose(sh[1], sh[0])));
+    __syncthreads();
+    return total;
+}
+// this thread's EXCLUSIVE prefix (identity for thread 0) of the thread aggregates, in thread order.  sh = 4 words of LDS.
+__device__ inline unsigned pp_fn_block_exclusive(unsigned agg, unsigned* sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = agg;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {                        // lane i: the composition of lanes (i - 2o, i] after step o
+        const unsigned lo = (unsigned)__shfl_up((int)inc, o, 64);
+        if (lane >= o) inc = pp_fn_compose(inc, lo);
     }
-    total = sh[255];
-    unsigned long long excl = (t == 0) ? PP_BM_IDENTITY : sh[t - 1];
+    if (lane == 63) sh[wave] = inc;
     __syncthreads();
-    return excl;
+    unsigned before = PP_FN_IDENTITY;                          // the waves before this one
+    for (int w = 0; w < wave; w++) before = pp_fn_compose(sh[w], before);
+    __syncthreads();
+    unsigned excl = (unsigned)__shfl_up((int)inc, 1, 64);
+    if (lane == 0) excl = PP_FN_IDENTITY;
+    return pp_fn_compose(excl, before);
 }
-// vis[q] = (P_q e_0)[0] = P_q[0][0]; stored as bit 1 of proj[q]
+// vis[q] = (state before slot q == 0); stored as bit 1 of proj[q]
 
 // ------------------------------------------------------------------------------ 3. integer scans
 __device__ inline unsigned pp_u32_block_scan(unsigned agg, unsigned* sh, unsigned& total) {
@@ -149,16 +165,14 @@ __device__ inline unsigned pp_u32_block_scan(unsigned agg, unsigned* sh, unsigne
 // aggregates before it for itself (a few hundred 8-byte values: cheaper than a launch that does it once), and neighbouring
 // steps share a kernel where one only consumes what the other's own workgroup produced.  Same arithmetic, same bits.
 //
-// prefix of the matrices blk[0 .. upto): composed in order (later on the left), by the whole workgroup
-__device__ inline unsigned long long pp_bm_prefix_of(const unsigned long long* blk, int upto, unsigned long long* sh) {
-    unsigned long long agg = PP_BM_IDENTITY;
+// prefix of the tile functions blk[0 .. upto): composed in order (later on the left), by the whole workgroup
+__device__ inline unsigned pp_fn_prefix_of(const unsigned* blk, int upto, unsigned* sh) {
+    unsigned agg = PP_FN_IDENTITY;
     const int per = (upto + 255) / 256;                       // consecutive entries per thread
     const int b0 = (int)threadIdx.x * per;
     for (int i = 0; i < per; i++)
-        if (b0 + i < upto) agg = pp_bm_compose(blk[b0 + i], agg);
-    unsigned long long total;
-    pp_bm_block_scan(agg, sh, total);
-    return total;
+        if (b0 + i < upto) agg = pp_fn_compose(blk[b0 + i], agg);
+    return pp_fn_block_total(agg, sh);
 }
 __device__ inline unsigned pp_u32_prefix_of(const unsigned* blk, int upto, unsigned* sh) {
     unsigned agg = 0;
@@ -167,81 +181,60 @@ __device__ inline unsigned pp_u32_prefix_of(const unsigned* blk, int upto, unsig
     pp_u32_block_scan(agg, sh, total);
     return total;
 }
-// 1 + 2a: proj bits of a tile (and of the five slots before it, which its first transitions read) and the tile's transition product
+// 1 + 2a: proj bits of a tile and the tile's function (the composition of its slots' steps)
 __global__ __launch_bounds__(256) void pp_k_proj_reduce(unsigned seed, const unsigned long long* d_pos, long long nq, unsigned char* proj,
-                                                        unsigned long long* blk, unsigned long long* zero16) {
-    __shared__ unsigned long long sh[256];
+                                                        unsigned* blk, unsigned long long* zero16) {
+    __shared__ unsigned sh[4];
     const unsigned long long pos = d_pos[0];
-    __shared__ unsigned char sp[PP_SCAN_TILE + 8];             // sp[5 + i] = proj of the tile's slot i; sp[0 .. 4] = the five slots before the tile
     if (blockIdx.x == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0ull;   // end slot / total of this call (written by later launches)
     const long long tile0 = (long long)blockIdx.x * PP_SCAN_TILE;
-    {
-        // a thread's eight slots are consecutive: the draw that decides slot q ends where the one of slot q + 1 begins (two engine calls
-        // each), so one jump-ahead per thread and then the engine's own steps
-        const int l0 = (int)threadIdx.x * 8;
-        const long long q0 = tile0 + l0;
-        unsigned x = (q0 < nq) ? pp_lcg_jump(seed, 2ull * (pos + (unsigned long long)q0 + 4ull)) : 1u;
+    // a thread's eight slots are consecutive: the draw that decides slot q ends where the one of slot q + 1 begins (two engine calls
+    // each), so one jump-ahead per thread and then the engine's own steps
+    const long long q0 = tile0 + (long long)threadIdx.x * 8;
+    unsigned agg = PP_FN_IDENTITY;
+    if (q0 < nq) {
+        unsigned x = pp_lcg_jump(seed, 2ull * (pos + (unsigned long long)q0 + 4ull));
+        unsigned long long bytes = 0ull;
         for (int i = 0; i < 8; i++) {
-            unsigned char b = 0;
             if (q0 + i < nq) {
-                b = pp_projection_draw(x) ? 1 : 0;
-                proj[q0 + i] = b;
+                const unsigned b = pp_projection_draw(x) ? 1u : 0u;
+                bytes |= (unsigned long long)b << (8 * i);
+                agg = pp_fn_compose(pp_fn_step(b), agg);
             }
-            sp[5 + l0 + i] = b;
         }
-        if (threadIdx.x < 5) {                                 // the five slots before the tile
-            const long long q = tile0 - 5 + (long long)threadIdx.x;
-            unsigned char b = 0;
-            if (q >= 0 && q < nq) {
-                unsigned xh = pp_lcg_jump(seed, 2ull * (pos + (unsigned long long)q + 4ull));
-                b = pp_projection_draw(xh) ? 1 : 0;
-            }
-            sp[threadIdx.x] = b;
-        }
+        if (q0 + 8 <= nq) *reinterpret_cast<unsigned long long*>(proj + q0) = bytes;      // (the buffer is 8-byte aligned, q0 a multiple of 8)
+        else for (int i = 0; q0 + i < nq; i++) proj[q0 + i] = (unsigned char)((bytes >> (8 * i)) & 0xffu);
     }
-    __syncthreads();
-    const int l0 = (int)threadIdx.x * 8;
-    unsigned long long agg = PP_BM_IDENTITY;
-    for (int i = 0; i < 8; i++) {
-        const long long q = tile0 + l0 + i;
-        if (q < nq) {
-            const unsigned p4 = q >= 4 ? (unsigned)sp[5 + l0 + i - 4] : 0u, p5 = q >= 5 ? (unsigned)sp[5 + l0 + i - 5] : 0u;
-            const unsigned row0 = ((p4 ^ 1u) << 4) | (p5 << 5);
-            const unsigned long long m = (unsigned long long)row0 | (1ull << 6) | (2ull << 12) | (4ull << 18) | (8ull << 24) | (16ull << 30);
-            agg = pp_bm_compose(m, agg);
-        }
-    }
-    unsigned long long total;
-    pp_bm_block_scan(agg, sh, total);
+    const unsigned total = pp_fn_block_total(agg, sh);
     if (threadIdx.x == 0) blk[blockIdx.x] = total;
 }
-// 2b + 3a: the tile's visited bits (prefix of the tiles before it worked out here) and how many of its slots are visited
-__global__ __launch_bounds__(256) void pp_k_chain_apply_count(unsigned char* proj, long long nq, const unsigned long long* blk, unsigned* cnt) {
-    __shared__ unsigned long long sh[256];
+// 2b + 3a: the tile's visited bits (the function of the tiles before it worked out here) and how many of its slots are visited
+__global__ __launch_bounds__(256) void pp_k_chain_apply_count(unsigned char* proj, long long nq, const unsigned* blk, unsigned* cnt) {
+    __shared__ unsigned sh[4];
     __shared__ unsigned shc[256];
-    const unsigned long long before = pp_bm_prefix_of(blk, (int)blockIdx.x, sh);
-    long long q0 = (long long)blockIdx.x * PP_SCAN_TILE + (long long)threadIdx.x * 8;
-    unsigned long long m[8];
-    unsigned long long agg = PP_BM_IDENTITY;
+    const unsigned before = pp_fn_prefix_of(blk, (int)blockIdx.x, sh);
+    const long long q0 = (long long)blockIdx.x * PP_SCAN_TILE + (long long)threadIdx.x * 8;
+    unsigned long long bytes = 0ull;
+    if (q0 + 8 <= nq) bytes = *reinterpret_cast<const unsigned long long*>(proj + q0);
+    else for (int i = 0; q0 + i < nq; i++) bytes |= (unsigned long long)proj[q0 + i] << (8 * i);
+    unsigned agg = PP_FN_IDENTITY;
+    for (int i = 0; i < 8; i++)
+        if (q0 + i < nq) agg = pp_fn_compose(pp_fn_step((unsigned)(bytes >> (8 * i)) & 1u), agg);
+    const unsigned excl = pp_fn_block_exclusive(agg, sh);
+    // the walk starts on slot 0 (state 0); the state in front of this thread's first slot
+    unsigned d = pp_fn_apply(excl, pp_fn_apply(before, 0u));
+    unsigned c = 0;
     for (int i = 0; i < 8; i++) {
-        long long q = q0 + i;
-        m[i] = (q < nq) ? pp_bm_step(proj, q) : PP_BM_IDENTITY;
-        agg = pp_bm_compose(m[i], agg);
+        if (q0 + i < nq) {
+            const unsigned p = (unsigned)(bytes >> (8 * i)) & 1u;
+            const unsigned vis = (d == 0u) ? 1u : 0u;
+            bytes |= (unsigned long long)(vis << 1) << (8 * i);
+            c += vis;
+            d = d ? d - 1u : 4u + p;
+        }
     }
-    unsigned long long total;
-    unsigned long long pre = pp_bm_block_scan(agg, sh, total);
-    pre = pp_bm_compose(pre, before);
-    unsigned vis[8], c = 0;
-    for (int i = 0; i < 8; i++) {
-        vis[i] = (unsigned)(pre & 1ull);
-        pre = pp_bm_compose(m[i], pre);
-        if (q0 + i < nq) c += vis[i];
-    }
-    __syncthreads();   // every thread has read its proj[q-4], proj[q-5] neighbours (bit 0 only is read; bit 1 written)
-    for (int i = 0; i < 8; i++) {
-        long long q = q0 + i;
-        if (q < nq) proj[q] = (unsigned char)((proj[q] & 1u) | (vis[i] << 1));
-    }
+    if (q0 + 8 <= nq) *reinterpret_cast<unsigned long long*>(proj + q0) = bytes;
+    else for (int i = 0; q0 + i < nq; i++) proj[q0 + i] = (unsigned char)((bytes >> (8 * i)) & 0xffu);
     unsigned tot;
     pp_u32_block_scan(c, shc, tot);
     if (threadIdx.x == 0) cnt[blockIdx.x] = tot;

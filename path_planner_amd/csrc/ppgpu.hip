@@ -599,11 +599,12 @@ static int sampler_chain(ppgpu_ctx* c, long long n, long long& nq, int& nblk_q, 
     *d_end = c->s_u64.p + nblk_q + 8;
     if (!s.on_ribbons) { HIP_TRY(hipMemsetAsync(c->s_u64.p + nblk_q + 8, 0, 16 * sizeof(unsigned long long), st)); return PPGPU_OK; }
     unsigned char* proj = c->s_bytes.p;
-    // 1. proj[q] for every slot in range (LCG jump-ahead) + 2a. the transition product of every tile of PP_SCAN_TILE slots: the chain
-    //    q -> q + 5 + proj[q] as a scan of 6x6 boolean transition matrices (also zeroes the end slot / total of this call)
-    hipLaunchKernelGGL(pp_k_proj_reduce, dim3(nblk_q), dim3(256), 0, st, s.seed, s.d_pos, nq, proj, c->s_u64.p, c->s_u64.p + nblk_q + 8);
+    unsigned* tilefn = reinterpret_cast<unsigned*>(c->s_u64.p);      // one 18-bit function per tile (the first nblk_q words' worth of s_u64)
+    // 1. proj[q] for every slot in range (LCG jump-ahead) + 2a. the function of every tile of PP_SCAN_TILE slots: the chain
+    //    q -> q + 5 + proj[q] as a scan over compositions of functions on its six states (also zeroes the end slot / total of this call)
+    hipLaunchKernelGGL(pp_k_proj_reduce, dim3(nblk_q), dim3(256), 0, st, s.seed, s.d_pos, nq, proj, tilefn, c->s_u64.p + nblk_q + 8);
     // 2b. visited[q] + 3a. visited slots per tile
-    hipLaunchKernelGGL(pp_k_chain_apply_count, dim3(nblk_q), dim3(256), 0, st, proj, nq, c->s_u64.p, c->s_u32b.p);
+    hipLaunchKernelGGL(pp_k_chain_apply_count, dim3(nblk_q), dim3(256), 0, st, proj, nq, tilefn, c->s_u32b.p);
     // 3b. rank the visited slots: slot of each sample, and of sample n
     hipLaunchKernelGGL(pp_k_chain_positions_scan, dim3(nblk_q), dim3(256), 0, st, proj, nq, c->s_u32b.p, n, c->s_u32a.p, *d_end,
                        skip ? c->samp_pos.p : (unsigned long long*)nullptr);
@@ -748,7 +749,7 @@ int ppgpu_select_nearest(ppgpu_ctx* c, int32_t v0, int32_t nv, int32_t k, int32_
 // The k winners of every (vertex, radius) of vertices [0, nv) in the reference's push order -> c->ord_idx, and both Dubins lengths
 // of every (vertex, sample) -> c->tmp_lengths: lengths + block minima, bound, candidate lists, sort + replay (pp_kernels.h).
 // Asynchronous; *c->ord_fallbacks.p counts lists that kept ascending length.
-static int launch_expand_order(ppgpu_ctx* c, int nv, int k) {
+static int launch_expand_order(ppgpu_ctx* c, int nv, int k, bool zero_fallbacks = true) {
     const long long ns = c->n_samples;
     long long cap = 64;
     while (cap < ns && cap < 65536) cap <<= 1;         // candidates per list; pp_k_expand_order filters them down to at most PP_ORD_CAP
@@ -761,7 +762,7 @@ static int launch_expand_order(ppgpu_ctx* c, int nv, int k) {
         (rc = c->ord_blockcnt.reserve((size_t)nv * nblk, false, c->stream)) || (rc = c->ord_bound.reserve((size_t)nv * 2, false, c->stream)) ||
         (rc = c->ord_count.reserve((size_t)nv * 2, false, c->stream)))
         return rc;
-    HIP_TRY(hipMemsetAsync(c->ord_fallbacks.p, 0, sizeof(unsigned), c->stream));
+    if (zero_fallbacks) HIP_TRY(hipMemsetAsync(c->ord_fallbacks.p, 0, sizeof(unsigned), c->stream));      // (ppgpu_expand_host: its unpack kernel does it)
     const int two_radii = (c->cfg.coverage_turning_radius != c->cfg.turning_radius) ? 1 : 0;
     hipLaunchKernelGGL(pp_k_lengths_minima, dim3((unsigned)nblk, (unsigned)nv), dim3(256), 0, c->stream, c->verts.p, c->sx.p, c->sy.p, c->sh.p, ns,
                        c->cfg.turning_radius, c->cfg.coverage_turning_radius, c->cfg.collision_checking_increment, c->tmp_lengths.p,
@@ -1252,30 +1253,31 @@ int ppgpu_expand_host(ppgpu_ctx* c, int32_t nv, const ppgpu_vertex* hv, int32_t 
         (rc = c->tgrid.reserve((size_t)nv * c->ng, false, st)) || (rc = c->sx.reserve(need, true, st)) || (rc = c->sy.reserve(need, true, st)) ||
         (rc = c->sh.reserve(need, true, st)) || (rc = c->s_bytes.reserve((size_t)nv, false, st)))
         return rc;
-    // ---- stage out (device end): descriptors | records | child ribbons, one block, one download
-    const size_t q_e = 0, q_r = q_e + (size_t)cap * sizeof(uint64_t), q_c = q_r + (size_t)cap * sizeof(ppgpu_edge_result),
+    // ---- stage out (device end): header {push-order fallbacks} | descriptors | records | child ribbons, one block, one download
+    const size_t q_e = 128, q_r = q_e + (size_t)cap * sizeof(uint64_t), q_c = q_r + (size_t)cap * sizeof(ppgpu_edge_result),
                  out_bytes = q_c + (h_child ? (size_t)cap * stride * 4 * sizeof(double) : 0);
     if ((rc = c->dstage_out.reserve(out_bytes, false, st))) return rc;
+    unsigned long long* d_header = (unsigned long long*)c->dstage_out.p;
     unsigned long long* d_edges = (unsigned long long*)(c->dstage_out.p + q_e);
     ppgpu_edge_result* d_results = (ppgpu_edge_result*)(c->dstage_out.p + q_r);
     double* d_child = h_child ? (double*)(c->dstage_out.p + q_c) : nullptr;
-    if ((rc = c->dstage_in.reserve(in_bytes, false, st))) return rc;
+    if ((rc = c->dstage_in.reserve(in_bytes, false, st)) || (rc = c->ord_fallbacks.reserve(1, false, st))) return rc;
     HIP_TRY(hipMemcpyAsync(c->dstage_in.p, sin, in_bytes, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(pp_k_expand_unpack, dim3((unsigned)((in_bytes / 8 + nv + 255) / 256)), dim3(256), 0, st, c->dstage_in.p, nv, n_ribbons,
-                       c->verts.p, c->ribbons.p, c->sx.p + ns, c->sy.p + ns, c->sh.p + ns, c->s_bytes.p);
+                       c->verts.p, c->ribbons.p, c->sx.p + ns, c->sy.p + ns, c->sh.p + ns, c->s_bytes.p, c->ord_fallbacks.p);
     c->nverts = nv; c->nribbons = n_ribbons; c->max_vertex_ribbons = maxr; c->n_extra = nv;
     hipLaunchKernelGGL(pp_k_time_grid, dim3((unsigned)nv), dim3(64), 0, st, c->verts.p, nv, c->cfg.start_state_time,
                        c->cfg.collision_checking_increment, c->cfg.max_speed, c->ng, c->tgrid.p);
     // ---- k nearest per (vertex, radius), on the device
-    if (select && (rc = launch_expand_order(c, nv, k))) return rc;   // the k winners per (vertex, radius) in the order expand() pushes them
+    if (select && (rc = launch_expand_order(c, nv, k, false))) return rc;   // the k winners per (vertex, radius) in the order expand() pushes them
     const double slow = c->cfg.slow_speed <= 0 ? c->cfg.max_speed : c->cfg.slow_speed;     // PlannerConfig::slowSpeed()
     const int two_speeds = (slow != c->cfg.max_speed) ? 1 : 0;                              // SamplingBasedPlanner.cpp:57-59
     const int two_radii = (c->cfg.coverage_turning_radius != c->cfg.turning_radius) ? 1 : 0;  // :60-63
     hipLaunchKernelGGL(pp_k_build_expand_edges, dim3((unsigned)((nv + 63) / 64)), dim3(64), 0, st, nv, k, select ? c->ord_idx.p : nullptr,
-                       c->s_bytes.p, ns, two_speeds, two_radii, E, d_edges);
+                       c->s_bytes.p, ns, two_speeds, two_radii, E, d_edges, select ? c->ord_fallbacks.p : nullptr, d_header);
     HIP_TRY(hipGetLastError());
-    // ---- cost the whole list
-    if (h_child) HIP_TRY(hipMemsetAsync(d_child, 0, (size_t)cap * stride * 4 * sizeof(double), st));
+    // ---- cost the whole list.  (The child block is NOT cleared on the device: an edge's slots beyond its own ribbon count are
+    // written by nobody and read by nobody there; the copy-out below hands the caller zeros for them.)
     PPParams p;
     fill_params(c, p);
     p.edges = d_edges; p.wedges = nullptr;
@@ -1283,14 +1285,11 @@ int ppgpu_expand_host(ppgpu_ctx* c, int32_t nv, const ppgpu_vertex* hv, int32_t 
     p.n_edges = cap;
     p.out = d_results; p.child = d_child; p.stride = stride;
     if ((rc = launch_cost(c, p))) return rc;
-    if ((rc = stage_reserve(&c->stage_out, &c->stage_out_cap, out_bytes + 16))) return rc;
+    if ((rc = stage_reserve(&c->stage_out, &c->stage_out_cap, out_bytes))) return rc;
     char* sout = (char*)c->stage_out;
     HIP_TRY(hipMemcpyAsync(sout, c->dstage_out.p, out_bytes, hipMemcpyDeviceToHost, st));
-    unsigned* fb = (unsigned*)(sout + out_bytes);          // pinned, behind the block
-    *fb = 0;
-    if (select) HIP_TRY(hipMemcpyAsync(fb, c->ord_fallbacks.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    c->order_fallbacks += *fb;
+    c->order_fallbacks += *(const unsigned long long*)sout;
     const uint64_t* se = (const uint64_t*)(sout + q_e);
     const ppgpu_edge_result* sr = (const ppgpu_edge_result*)(sout + q_r);
     const double* sc = (const double*)(sout + q_c);
@@ -1299,7 +1298,14 @@ int ppgpu_expand_host(ppgpu_ctx* c, int32_t nv, const ppgpu_vertex* hv, int32_t 
         if (se[i] == ~0ull) continue;
         h_edges[n] = se[i];
         h_results[n] = sr[i];
-        if (h_child) std::memcpy(h_child + (size_t)n * stride * 4, sc + (size_t)i * stride * 4, (size_t)stride * 4 * sizeof(double));
+        if (h_child) {
+            // the edge's own ribbons, zeros behind them (a record that reports more ribbons than the stride holds: the stride's worth)
+            int have = (int)((sr[i].info >> 8) & 0xffu);
+            if (have > stride || (sr[i].flags & PPGPU_F_THROWS)) have = (sr[i].flags & PPGPU_F_THROWS) ? 0 : stride;
+            double* dst = h_child + (size_t)n * stride * 4;
+            std::memcpy(dst, sc + (size_t)i * stride * 4, (size_t)have * 4 * sizeof(double));
+            std::memset(dst + (size_t)have * 4, 0, (size_t)(stride - have) * 4 * sizeof(double));
+        }
         n++;
     }
     *n_edges = n;

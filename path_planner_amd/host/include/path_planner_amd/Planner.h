@@ -90,6 +90,18 @@ struct SearchNode {
     double f() const { return g + h; }
 };
 
+// What one device round trip of GpuAStarPlanner brought back — edge descriptors, records, child ribbons, compacted vertex by
+// vertex — kept whole: the children of an open vertex costed ahead of its expansion are a RANGE of one block, not copies.  Blocks
+// are recycled through their context's pool (a 300 KB buffer from malloc is a fresh mmap, page faults and all, every time).
+struct TripBlock {
+    std::unique_ptr<uint64_t[]> edges;
+    std::unique_ptr<unsigned char[]> records;     // ppgpu_edge_result (128 bytes) each
+    std::unique_ptr<double[]> child;              // `stride` x 4 doubles per edge
+    size_t edgeCap = 0, childCap = 0;
+    int stride = 0;
+    void reserve(size_t nEdges, size_t childDoubles);
+};
+
 // Process-level device handle: stream, persistent buffers (the reference builds a new planner every cycle,
 // executive.cpp:85-90, so nothing device-side may live in the planner object).  Throws std::runtime_error.
 // shared(device) hands out ONE context per device for the life of the process: the cache holds a strong reference, so the
@@ -104,7 +116,9 @@ public:
     GpuContext& operator=(const GpuContext&) = delete;
     ppgpu_ctx* handle() const { return m_Handle; }
     int device() const { return m_Device; }
-    static std::shared_ptr<GpuContext> shared(int device = 0);   // one per device per process, kept until releaseShared()
+    // one per (device, lane) per process, kept until releaseShared().  Lane 0 is "the" context of a device; further lanes are further
+    // streams (with their own buffers) on the same device: a planner given {shared(0, 0), shared(0, 1)} keeps two round trips in flight.
+    static std::shared_ptr<GpuContext> shared(int device = 0, int lane = 0);
     static std::vector<std::shared_ptr<GpuContext>> shared(const std::vector<int>& devices);
     static void releaseShared();
     // run `job` on this context's thread; wait() blocks until it has finished and rethrows what it threw
@@ -152,6 +166,9 @@ public:
     // the Executive has been given another map.  nullptr / 0: nothing cached.
     const void* gridOf = nullptr;
     unsigned long gridVersion = 0;
+    // round-trip result blocks not referred to by any planner any more are handed out again (used by this context's thread only)
+    std::vector<std::shared_ptr<TripBlock>> tripPool;
+    std::shared_ptr<TripBlock> takeTripBlock(size_t nEdges, size_t childDoubles);
 
 private:
     ppgpu_ctx* m_Handle = nullptr;
@@ -170,7 +187,10 @@ public:
     explicit GpuAStarPlanner(std::shared_ptr<GpuContext> ctx = GpuContext::shared()) : m_Ctx(ctx), m_Ctxs{ctx} {}
     // several devices of one node: world and samples are replicated on each (the sampler stream is deterministic: every device
     // draws the same samples itself), the open vertices of a batch are dealt across them, records come back to the host search
-    explicit GpuAStarPlanner(std::vector<std::shared_ptr<GpuContext>> ctxs) : m_Ctx(ctxs.at(0)), m_Ctxs(std::move(ctxs)) {}
+    explicit GpuAStarPlanner(std::vector<std::shared_ptr<GpuContext>> ctxs) : m_Ctx(ctxs.at(0)) {
+        for (auto& c : ctxs)                 // (a context named twice is one context)
+            if (std::find(m_Ctxs.begin(), m_Ctxs.end(), c) == m_Ctxs.end()) m_Ctxs.push_back(c);
+    }
     ~GpuAStarPlanner() override;      // the search tree is torn down here, as the reference's is (not inside plan()'s budget)
     Stats plan(const RibbonManager& ribbonManager, const State& start, PlannerConfig config, const DubinsPlan& previousPlan,
                double timeRemaining) override;
@@ -189,10 +209,8 @@ private:
     // Edges of open vertices costed ahead of their expansion, as the device returned them: a child Node is built only when the
     // search expands the parent, and only for edges it would push (an infeasible edge never becomes a vertex).
     struct Costed {
-        std::vector<unsigned> cfgBits;
-        std::vector<unsigned char> records;   // ppgpu_edge_result each
-        std::vector<double> childRibbons;     // `stride` x 4 doubles per edge
-        int stride = 0;
+        std::shared_ptr<TripBlock> block;     // the round trip that costed them
+        size_t first = 0, count = 0;          // this vertex's edges: [first, first + count) of the block, in push order
     };
     std::unordered_map<int, Costed> m_Speculated;
 
@@ -200,9 +218,19 @@ private:
     void pushVertexQueue(int v);
     int popVertexQueue();
     bool goalCondition(const Node& v) const;
-    void expand(int source);
-    void expandBatch(const std::vector<int>& sources);
-    void expandOn(GpuContext& ctx, const std::vector<int>& sources, std::vector<std::pair<int, Costed>>& out, unsigned long& edgesCosted) const;
+    bool expand(int source);               // false: the deadline guard did not start the round trip it needed
+    struct Batch;                          // one device round trip, from the pick to the harvest (planner.cpp)
+    std::vector<std::shared_ptr<Batch>> m_InFlight;        // started, not yet harvested: at most one per context
+    std::unordered_map<int, Batch*> m_InFlightOf;          // open vertex -> the round trip that is costing its children
+    void packBatch(Batch& b) const;
+    static void runBatch(Batch& b, int k);
+    void submitBatch(std::shared_ptr<Batch> b, GpuContext& ctx);
+    void harvestBatch(Batch* b, bool keep);
+    void dropBatch(Batch* b);
+    void drainInFlight();
+    GpuContext& freeContext();
+    void pickBatch(int source, std::vector<int>& batch) const;
+    double m_EndTime = 0;                  // the deadline of this plan() call, on the injected clock
     int costEdgeList(const std::vector<uint64_t>& edges, int maxParentRibbons, std::vector<::ppgpu_edge_result>& res, std::vector<double>& child);
     Node makeChild(int source, unsigned cfgBits, const ::ppgpu_edge_result& r, const double* childRibbons, int stride);
     void addNode(Node&& n);                // m_Nodes.push_back that counts and times reallocations (Stats::Budget)

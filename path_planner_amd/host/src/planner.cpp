@@ -63,8 +63,10 @@ struct Lap {
 
 static const double kTimePenaltyFactor = 1;       // Edge::timePenaltyFactor() (Edge.h:152)
 static const double kCollisionPenaltyFactor = 600;  // Edge::collisionPenaltyFactor() (Edge.h:151)
+static const double kHostMargin = 1e-4;           // seconds the guarded search loop stops short of the deadline (tracing the plan, statistics, the return)
 static const int kRibbonStride = 64;              // child ribbon capacity per edge = the device's per-vertex limit
-static const size_t kNodeArenaMin = 1u << 18;     // nodes the search tree has room for before its first node arrives (63 MB of address space, touched as used)
+static const size_t kNodeArenaMin = 1u << 20;     // nodes the search tree has room for before its first node arrives (250 MB of address space, touched as used;
+                                                  // a 100 ms cycle of config 5 makes 250 000 - 300 000 of them)
 
 Planner::Planner() : m_Config(PlannerConfig(&std::cerr)) {}
 
@@ -77,11 +79,11 @@ Planner::Stats Planner::plan(const RibbonManager&, const State&, PlannerConfig c
 GpuContext::GpuContext(int device) : m_Device(device) {
     if (ppgpu_create(device, &m_Handle) != PPGPU_OK) throw std::runtime_error(std::string("ppgpu_create: ") + ppgpu_last_error());
     // The anytime search doubles its sample set every iteration; a 10 Hz cycle with a 100 ms budget reaches one to four million.
-    // Sizing the sample-dependent buffers once (8 M samples, batches of 16 vertices: 2.3 GB of 288) keeps device allocations out of
-    // every later cycle's budget.  PPAMD_RESERVE_SAMPLES=0 leaves them to grow on demand.
+    // Sizing the sample-dependent buffers once (8 M samples, batches of up to 64 vertices: 9 GB of 288) keeps device allocations out
+    // of every later cycle's budget.  PPAMD_RESERVE_SAMPLES=0 leaves them to grow on demand.
     long long reserve = 8ll << 20;
     if (const char* e = std::getenv("PPAMD_RESERVE_SAMPLES")) reserve = std::atoll(e);
-    if (reserve > 0 && ppgpu_reserve_samples(m_Handle, reserve, 16) != PPGPU_OK) {
+    if (reserve > 0 && ppgpu_reserve_samples(m_Handle, reserve, 64) != PPGPU_OK) {
         const std::string why = ppgpu_last_error();
         ppgpu_destroy(m_Handle);      // the destructor does not run for a constructor that throws
         m_Handle = nullptr;
@@ -136,25 +138,44 @@ void GpuContext::wait() {
     }
 }
 
+void TripBlock::reserve(size_t nEdges, size_t childDoubles) {
+    if (nEdges > edgeCap) {
+        edges.reset(new uint64_t[nEdges]);
+        records.reset(new unsigned char[nEdges * sizeof(ppgpu_edge_result)]);
+        edgeCap = nEdges;
+    }
+    if (childDoubles > childCap) { child.reset(new double[childDoubles]); childCap = childDoubles; }
+}
+
+std::shared_ptr<TripBlock> GpuContext::takeTripBlock(size_t nEdges, size_t childDoubles) {
+    for (auto& b : tripPool)
+        if (b.use_count() == 1) { b->reserve(nEdges, childDoubles); return b; }       // nobody but the pool holds it
+    tripPool.push_back(std::make_shared<TripBlock>());
+    tripPool.back()->reserve(nEdges, childDoubles);
+    return tripPool.back();
+}
+
 namespace {
 std::mutex g_ctxMutex;
 // deliberately never destroyed: contexts must not outlive the HIP runtime's own static teardown
-std::map<int, std::shared_ptr<GpuContext>>& contextCache() {
-    static auto* cache = new std::map<int, std::shared_ptr<GpuContext>>();
+std::map<std::pair<int, int>, std::shared_ptr<GpuContext>>& contextCache() {
+    static auto* cache = new std::map<std::pair<int, int>, std::shared_ptr<GpuContext>>();
     return *cache;
 }
 }  // namespace
 
-std::shared_ptr<GpuContext> GpuContext::shared(int device) {
+std::shared_ptr<GpuContext> GpuContext::shared(int device, int lane) {
     std::lock_guard<std::mutex> lock(g_ctxMutex);
-    std::shared_ptr<GpuContext>& sp = contextCache()[device];
+    std::shared_ptr<GpuContext>& sp = contextCache()[{device, lane}];
     if (!sp) sp = std::make_shared<GpuContext>(device);
     return sp;
 }
 
+// a device id that repeats names a further context (its own stream and buffers) on that device: {0, 0} = two streams on device 0
 std::vector<std::shared_ptr<GpuContext>> GpuContext::shared(const std::vector<int>& devices) {
     std::vector<std::shared_ptr<GpuContext>> out;
-    for (int d : devices) out.push_back(shared(d));
+    std::map<int, int> seen;
+    for (int d : devices) out.push_back(shared(d, seen[d]++));
     if (out.empty()) out.push_back(shared(0));
     return out;
 }
@@ -166,6 +187,7 @@ void GpuContext::releaseShared() {
 
 // ------------------------------------------------------------------------------------------------ helpers
 GpuAStarPlanner::~GpuAStarPlanner() {
+    try { drainInFlight(); } catch (...) {}     // (after an exception left plan(): nothing of this planner may still run on a context)
     // the tree goes (every node's ribbon list is its own allocation), its array goes back to the context for the next cycle's planner
     m_Nodes.clear();
     if (m_Ctx && m_Nodes.capacity() > m_Ctx->nodeArena.capacity()) m_Nodes.swap(m_Ctx->nodeArena);
@@ -370,6 +392,7 @@ bool GpuAStarPlanner::goalCondition(const Node& v) const {   // :42-50
 
 // ------------------------------------------------------------------------------------------------ sampling
 void GpuAStarPlanner::addSamples(long n) {   // SamplingBasedPlanner::addSamples (:157-168)
+    drainInFlight();                          // round trips still running were chosen among the old samples (and use the contexts)
     Lap lap(5);
     int64_t total = 0;
     // every device draws the same attempts from the same generator state itself (the stream is a pure function of seed and
@@ -429,7 +452,7 @@ GpuAStarPlanner::Node GpuAStarPlanner::makeChild(int source, unsigned cfgBits, c
     c.steps = (int)(r.info >> 16);
     c.g = r.g;
     c.h = r.h;
-    c.ribbons = src.ribbons;   // keeps heuristic, K, turning radius
+    c.ribbons = RibbonManager(src.ribbons.heuristic(), src.ribbons.turningRadius(), src.ribbons.k());   // the parent's settings; its list is replaced below
     c.ribbons.assign(childRibbons, nChild, r.coverage_completed_time);
     if (hostHeuristic) {       // Vertex::computeApproxToGo (Vertex.cpp:49-64): the child's heading goes where the callee says yaw
         c.h = c.ribbons.approximateDistanceUntilDone(c.state.x(), c.state.y(), c.state.heading()) / m_Config.maxSpeed() * kTimePenaltyFactor;
@@ -506,157 +529,268 @@ int GpuAStarPlanner::costStateEdges(int source, const std::vector<State>& target
 // SamplingBasedPlanner::expand (:52-151) for several open vertices in ONE device round trip: every vertex's edges are what
 // expand() would build for it alone (nearest ribbon endpoint at each speed and radius, then the k nearest samples per radius
 // at each speed, in the order of the reference's heap array), in that order; the children are kept aside, not pushed.
-// Reads the search tree, writes only `out` / `edgesCosted`: several of these run at once on different devices.
-void GpuAStarPlanner::expandOn(GpuContext& ctx, const std::vector<int>& sources, std::vector<std::pair<int, Costed>>& out,
-                               unsigned long& edgesCosted) const {
-    ppgpu_ctx* h = ctx.handle();
-    const int M = (int)sources.size();
-    std::unique_ptr<Lap> lap(new Lap(1));
-    // these vertices become the device's open-vertex array
-    std::vector<ppgpu_vertex> verts((size_t)M);
-    std::vector<double> pool;
+//
+// A round trip is a Batch.  It is PACKED on the planning thread (reads the search tree), RUN on its context — inline when the
+// planner has one context, on the context's own host thread when it has several, so that the planning thread goes on building and
+// pushing children (and packing the next batch) meanwhile — and HARVESTED on the planning thread again.  With several contexts the
+// planner keeps the others busy with PREFETCH batches: the next-best open vertices, costed on the chance that the search pops them
+// before anything cheaper turns up (it nearly always does: config 5 costs 1.1 edges ahead for every edge it consumes).  Two contexts
+// on ONE device are two HIP streams: a round trip is a chain of a dozen latency-bound launches that leave most of the chip idle, and
+// two of them overlap almost for free.  What is pushed, and in which order, never depends on any of this.
+struct GpuAStarPlanner::Batch {
+    std::vector<int> sources;
+    std::vector<ppgpu_vertex> verts;
+    std::vector<double> pool, nearest;
     int maxParent = 0;
-    for (int i = 0; i < M; i++) {
-        const Node& n = m_Nodes[sources[i]];
-        verts[i] = makeVertex(n);
-        verts[i].ribbon_offset = (int32_t)(pool.size() / 4);
-        pool.insert(pool.end(), n.ribbons.rows(), n.ribbons.rows() + 4 * (size_t)n.ribbons.count());
-        maxParent = std::max(maxParent, (int)verts[i].ribbon_count);
+    GpuContext* ctx = nullptr;
+    bool threaded = false;                 // running on ctx's thread (wait() before anything else touches ctx)
+    // filled by run()
+    std::shared_ptr<TripBlock> block;
+    int64_t n = 0;
+    unsigned long edgesCosted = 0;
+    double started = 0, took = 0, predicted = 0, samples = 0;
+};
+
+void GpuAStarPlanner::packBatch(Batch& b) const {
+    Lap lap(1);
+    const int M = (int)b.sources.size();
+    b.verts.resize((size_t)M);
+    b.pool.clear();
+    b.maxParent = 0;
+    for (int i = 0; i < M; i++) {                     // these vertices become the device's open-vertex array
+        const Node& n = m_Nodes[b.sources[i]];
+        b.verts[i] = makeVertex(n);
+        b.verts[i].ribbon_offset = (int32_t)(b.pool.size() / 4);
+        b.pool.insert(b.pool.end(), n.ribbons.rows(), n.ribbons.rows() + 4 * (size_t)n.ribbons.count());
+        b.maxParent = std::max(b.maxParent, (int)b.verts[i].ribbon_count);
     }
     // nearest point to cover (:64-81): one explicit target per vertex that has one (computed on the host, as in the reference)
-    std::vector<double> nearest((size_t)M * 3, std::nan(""));
+    b.nearest.assign((size_t)M * 3, std::nan(""));
     for (int i = 0; i < M; i++) {
-        const Node& n = m_Nodes[sources[i]];
+        const Node& n = m_Nodes[b.sources[i]];
         if (n.ribbons.done()) continue;
         State s = n.ribbons.getNearestEndpointAsState(n.state);
         if (n.state.distanceTo(s) > m_Config.collisionCheckingIncrement()) {
-            nearest[3 * i] = s.x(); nearest[3 * i + 1] = s.y(); nearest[3 * i + 2] = s.heading();
+            b.nearest[3 * i] = s.x(); b.nearest[3 * i + 1] = s.y(); b.nearest[3 * i + 2] = s.heading();
         }
     }
-    // everything else of expand() — k nearest samples per radius, edge list in push order, costing — is one device round trip
-    const int k = m_Config.branchingFactor();
+}
+
+// everything else of expand() — k nearest samples per radius, edge list in push order, costing — is one device round trip.
+// Touches only the batch and its context (runs on the context's thread when the planner has several).
+void GpuAStarPlanner::runBatch(Batch& b, int k) {
+    GpuContext& ctx = *b.ctx;
+    ppgpu_ctx* h = ctx.handle();
+    const int M = (int)b.sources.size();
     const int64_t cap = ppgpu_expand_capacity(M, k);
-    std::vector<uint64_t> edges((size_t)cap);
-    std::vector<ppgpu_edge_result> res((size_t)cap);
-    std::vector<double> child;
-    int64_t n = 0;
-    int stride = std::min(kRibbonStride, maxParent + 6);
-    lap.reset(new Lap(2));
+    int stride = std::min(kRibbonStride, b.maxParent + 6);
+    b.started = HostProfile::now();
     for (;;) {
-        child.assign((size_t)cap * stride * 4, 0.0);
-        check(ppgpu_expand_host(h, M, verts.data(), (int32_t)(pool.size() / 4), pool.empty() ? nullptr : pool.data(), nearest.data(), k, &n,
-                                edges.data(), res.data(), child.data(), stride),
-              "ppgpu_expand_host");
-        edgesCosted += (unsigned long)n;
+        b.block = ctx.takeTripBlock((size_t)cap, (size_t)cap * stride * 4);      // (the call fills the first n entries; nothing is read beyond them)
+        b.block->stride = stride;
+        ppgpu_edge_result* res = reinterpret_cast<ppgpu_edge_result*>(b.block->records.get());
+        if (ppgpu_expand_host(h, M, b.verts.data(), (int32_t)(b.pool.size() / 4), b.pool.empty() ? nullptr : b.pool.data(), b.nearest.data(), k, &b.n,
+                              b.block->edges.get(), res, b.block->child.get(), stride) != PPGPU_OK)
+            throw std::runtime_error(std::string("ppgpu_expand_host: ") + ppgpu_last_error());
+        b.edgesCosted += (unsigned long)b.n;
         bool retry = false;
         if (stride < kRibbonStride)
-            for (int64_t i = 0; i < n && !retry; i++)
+            for (int64_t i = 0; i < b.n && !retry; i++)
                 retry = (res[i].flags & PPGPU_F_RIBBON_OVF) && (int)((res[i].info >> 8) & 0xff) > stride;
         if (!retry) break;
         stride = kRibbonStride;       // some child does not fit: again at the device's full per-vertex capacity
     }
-    lap.reset(new Lap(3));
-    out.clear();
-    out.resize((size_t)M);
-    for (int i = 0; i < M; i++) { out[i].first = sources[i]; out[i].second.stride = stride; }   // an entry even when a vertex has no edges at all
-    for (int64_t e = 0; e < n; e++) {
-        const int owner = (int)((edges[e] >> 32) & 0xffffffu);
-        Costed& c = out[(size_t)owner].second;
-        c.cfgBits.push_back((unsigned)(edges[e] >> 56));
-        const unsigned char* r = reinterpret_cast<const unsigned char*>(&res[e]);
-        c.records.insert(c.records.end(), r, r + sizeof(ppgpu_edge_result));
-        const double* cr = child.data() + (size_t)e * stride * 4;
-        c.childRibbons.insert(c.childRibbons.end(), cr, cr + (size_t)stride * 4);
+    b.took = HostProfile::now() - b.started;
+}
+
+// pack + start: inline (one context) or on the context's thread
+void GpuAStarPlanner::submitBatch(std::shared_ptr<Batch> bp, GpuContext& ctx) {
+    Batch& b = *bp;
+    b.ctx = &ctx;
+    b.samples = (double)m_NumSamples;
+    b.predicted = ctx.predictTrip(b.samples);
+    packBatch(b);
+    const int k = m_Config.branchingFactor();
+    for (int v : b.sources) m_InFlightOf[v] = &b;
+    b.threaded = m_Ctxs.size() > 1;
+    m_InFlight.push_back(std::move(bp));
+    g_prof.trips++;
+    if (b.threaded) {
+        Batch* raw = &b;
+        ctx.run([raw, k] { runBatch(*raw, k); });
+    } else {
+        Lap lap(2);
+        try { runBatch(b, k); } catch (...) { dropBatch(&b); throw; }
     }
 }
 
-// One batch of open vertices: on one device as it is; on several, dealt round-robin (the batch is sorted by f, so every device
-// gets vertices of every priority and the one the search is waiting for sits first on device 0), one host thread per device.
-void GpuAStarPlanner::expandBatch(const std::vector<int>& sources) {
-    g_prof.trips++;
-    struct TripTimer {
-        GpuAStarPlanner& self; GpuContext& c; double samples, w0, predicted;
-        ~TripTimer() {
-            const double took = HostProfile::now() - w0;
-            self.noteOperation(1, w0, predicted, took);
-            c.noteTrip(samples, took);
-        }
-    } tripTimer{*this, *m_Ctx, (double)m_NumSamples, HostProfile::now(), m_Ctx->predictTrip((double)m_NumSamples)};
-    const size_t D = std::min(m_Ctxs.size(), sources.size());
-    std::vector<std::vector<std::pair<int, Costed>>> parts(std::max<size_t>(D, 1));
-    std::vector<unsigned long> costed(parts.size(), 0);
-    if (D <= 1) {
-        expandOn(*m_Ctx, sources, parts[0], costed[0]);
-    } else {
-        std::vector<std::vector<int>> share(D);
-        for (size_t i = 0; i < sources.size(); i++) share[i % D].push_back(sources[i]);
-        for (size_t d = 0; d < D; d++) m_Ctxs[d]->run([&, d] { expandOn(*m_Ctxs[d], share[d], parts[d], costed[d]); });
-        std::exception_ptr first;
-        for (size_t d = 0; d < D; d++) {
-            try { m_Ctxs[d]->wait(); } catch (...) { if (!first) first = std::current_exception(); }
-        }
-        if (first) std::rethrow_exception(first);
+// the batch is over (wait for its thread if it has one): its children go to m_Speculated, its figures to the statistics
+void GpuAStarPlanner::harvestBatch(Batch* bp, bool keep) {
+    std::shared_ptr<Batch> own;
+    for (auto it = m_InFlight.begin(); it != m_InFlight.end(); ++it)
+        if (it->get() == bp) { own = std::move(*it); m_InFlight.erase(it); break; }
+    Batch& b = *own;
+    for (int v : b.sources) m_InFlightOf.erase(v);
+    if (b.threaded) {
+        Lap lap(2);
+        b.ctx->wait();                         // rethrows what the round trip threw
     }
-    for (size_t d = 0; d < parts.size(); d++) {
-        m_Stats.EdgesCosted += costed[d];
-        for (auto& kv : parts[d]) m_Speculated[kv.first] = std::move(kv.second);
+    noteOperation(1, b.started, b.predicted, b.took);
+    b.ctx->noteTrip(b.samples, b.took);
+    m_Stats.EdgesCosted += b.edgesCosted;
+    if (!keep) return;                         // costed against a sample set that is no longer the search's
+    Lap lap(3);
+    const int M = (int)b.sources.size();
+    std::vector<Costed> out((size_t)M);
+    for (int i = 0; i < M; i++) out[i].block = b.block;         // an entry even when a vertex has no edges at all
+    // the list comes back compacted vertex by vertex, in the order the vertices went in: a vertex's edges are one run of it
+    for (int64_t e = 0; e < b.n; e++) {
+        const int owner = (int)((b.block->edges[e] >> 32) & 0xffffffu);
+        Costed& c = out[(size_t)owner];
+        if (c.count == 0) c.first = (size_t)e;
+        else if (c.first + c.count != (size_t)e) throw std::runtime_error("ppgpu_expand_host: a vertex's edges are not contiguous in the returned list");
+        c.count++;
     }
+    for (int i = 0; i < M; i++) m_Speculated[b.sources[i]] = std::move(out[i]);
+}
+
+void GpuAStarPlanner::dropBatch(Batch* bp) {
+    for (int v : bp->sources) m_InFlightOf.erase(v);
+    for (auto it = m_InFlight.begin(); it != m_InFlight.end(); ++it)
+        if (it->get() == bp) { m_InFlight.erase(it); break; }
+}
+
+// every round trip still running is waited for and thrown away (the sample set changes, or plan() is about to return: nothing of
+// this planner may still be running on a context when it does)
+void GpuAStarPlanner::drainInFlight() {
+    std::exception_ptr first;
+    while (!m_InFlight.empty()) {
+        try { harvestBatch(m_InFlight.front().get(), false); } catch (...) { if (!first) first = std::current_exception(); }
+    }
+    m_InFlightOf.clear();
+    if (first) std::rethrow_exception(first);
+}
+
+// a context with no round trip of this planner on it; when all are busy, the one whose batch was started first is harvested
+GpuContext& GpuAStarPlanner::freeContext() {
+    for (auto& c : m_Ctxs) {
+        bool busy = false;
+        for (auto& b : m_InFlight) busy = busy || b->ctx == c.get();
+        if (!busy) return *c;
+    }
+    GpuContext* c = m_InFlight.front()->ctx;
+    harvestBatch(m_InFlight.front().get(), true);
+    return *c;
 }
 
 // expand(source) as the search sees it.  The device answers for `source` and, speculatively, for the open vertices the
 // search is most likely to pop next (smallest f first), so that most later calls find their children already costed.  What
 // is pushed, and in which order, is exactly what expanding one vertex at a time would push: speculation only changes when
 // the arithmetic happens.  Nothing survives a change of the sample set (m_Speculated is cleared by addSamples).
-void GpuAStarPlanner::expand(int source) {
+// The open vertices a round trip costs besides `source`: the up to speculation() - 1 entries of smallest f among those whose
+// children are not costed yet and that are not goals.  The open list is a binary min-heap on f: walked best-first from its root
+// (a small heap of heap positions) the entries come out in non-decreasing f, so the walk touches about as many entries as it
+// returns — round 3 scanned and partially sorted the whole list (100 000+ entries late in a cycle: up to 40 of a cycle's 100 ms).
+// Ties in f are taken smallest node index first, as before: the walk goes on through every entry that ties with the last one taken.
+void GpuAStarPlanner::pickBatch(int source, std::vector<int>& batch) const {
+    batch.clear();
+    if (source >= 0) batch.push_back(source);          // -1: a prefetch batch, nobody is waiting for any of it
+    const size_t want = (size_t)std::max(0, m_Config.speculation() - (source >= 0 ? 1 : 0));
+    if (want == 0 || m_Queue.empty()) return;
+    typedef std::pair<double, size_t> Entry;                  // (f, position in m_Queue)
+    auto worse = [](const Entry& a, const Entry& b) { return a.first > b.first; };
+    std::vector<Entry> frontier;
+    frontier.emplace_back(m_Nodes[m_Queue[0]].f(), 0);
+    std::vector<std::pair<double, int>> cand;                 // (f, node)
+    double lastF = 0;
+    while (!frontier.empty()) {
+        std::pop_heap(frontier.begin(), frontier.end(), worse);
+        const Entry e = frontier.back();
+        frontier.pop_back();
+        if (cand.size() >= want && e.first > lastF) break;    // everything left is worse than what is already taken
+        const int v = m_Queue[e.second];
+        if (!m_Speculated.count(v) && !m_InFlightOf.count(v) && !goalCondition(m_Nodes[v])) { cand.emplace_back(e.first, v); lastF = std::max(lastF, e.first); }
+        for (size_t c = 2 * e.second + 1; c <= 2 * e.second + 2 && c < m_Queue.size(); c++) {
+            frontier.emplace_back(m_Nodes[m_Queue[c]].f(), c);
+            std::push_heap(frontier.begin(), frontier.end(), worse);
+        }
+    }
+    std::sort(cand.begin(), cand.end());                      // (f, node index): the order the whole-list scan used to produce
+    for (size_t i = 0; i < cand.size() && i < want; i++) batch.push_back(cand[i].second);
+}
+
+bool GpuAStarPlanner::expand(int source) {
     visualizeVertex(source, "vertex", true);
     auto it = m_Speculated.find(source);
     if (it == m_Speculated.end()) {
-        std::vector<int> batch{source};
-        const int want = m_Config.speculation();
-        std::unique_ptr<Lap> lap(new Lap(0));
-        if (want > 1 && !m_Queue.empty()) {
-            std::vector<int> cand;
-            for (int v : m_Queue)
-                if (!m_Speculated.count(v) && !goalCondition(m_Nodes[v])) cand.push_back(v);
-            const size_t take = std::min(cand.size(), (size_t)(want - 1));
-            std::partial_sort(cand.begin(), cand.begin() + take, cand.end(), [&](int a, int b) {
-                const double fa = m_Nodes[a].f(), fb = m_Nodes[b].f();
-                return fa < fb || (fa == fb && a < b);
-            });
-            batch.insert(batch.end(), cand.begin(), cand.begin() + take);
+        auto flying = m_InFlightOf.find(source);
+        if (flying == m_InFlightOf.end()) {
+            GpuContext& ctx = freeContext();           // (may harvest a batch: the source can be among its vertices now)
+            if (!m_Speculated.count(source)) {
+                std::shared_ptr<Batch> b(new Batch());
+                {
+                    Lap lap(0);
+                    pickBatch(source, b->sources);
+                }
+                // the deadline guard once more, with the clock as it stands now that the batch is chosen (only when the guard is on: a
+                // counting clock must see the reference's call sequence)
+                if (m_Config.deadlineGuard() && now() + ctx.predictTrip((double)m_NumSamples) >= m_EndTime - m_Ctx->guardMargin()) return false;
+                Batch* mine = b.get();
+                submitBatch(std::move(b), ctx);
+                // while that one runs: the other contexts take the next-best open vertices (prefetch)
+                while (m_InFlight.size() < m_Ctxs.size()) {
+                    std::shared_ptr<Batch> p(new Batch());
+                    {
+                        Lap lap(0);
+                        pickBatch(-1, p->sources);
+                    }
+                    if (p->sources.empty()) break;
+                    GpuContext& pc = freeContext();
+                    if (m_Config.deadlineGuard() && now() + pc.predictTrip((double)m_NumSamples) >= m_EndTime - m_Ctx->guardMargin()) break;
+                    submitBatch(std::move(p), pc);
+                }
+                harvestBatch(mine, true);
+            }
+        } else {
+            harvestBatch(flying->second, true);        // costed ahead and still running (or just finished): wait for it
         }
-        lap.reset();
-        expandBatch(batch);
         it = m_Speculated.find(source);
+        if (it == m_Speculated.end()) throw std::runtime_error("GpuAStarPlanner: a round trip came back without the vertex it was started for");
     }
-    Costed costed = std::move(it->second);
+    const Costed costed = std::move(it->second);
     m_Speculated.erase(it);
     Lap lapPush(4);
     const bool watch = m_Config.visualizations();
-    for (size_t e = 0; e < costed.cfgBits.size(); e++) {
-        ppgpu_edge_result r;
-        std::memcpy(&r, costed.records.data() + e * sizeof(ppgpu_edge_result), sizeof(r));
+    const TripBlock& blk = *costed.block;
+    const ppgpu_edge_result* records = reinterpret_cast<const ppgpu_edge_result*>(blk.records.get());
+    for (size_t e = costed.first; e < costed.first + costed.count; e++) {
+        const ppgpu_edge_result& r = records[e];
+        const unsigned cfgBits = (unsigned)(blk.edges[e] >> 56);
         // an infeasible edge is never pushed (SamplingBasedPlanner.cpp:8): no vertex is made for it, unless the search is being
         // watched (its sweep is streamed all the same) or the record carries an error (makeChild throws what the reference throws)
         {
-            const bool cov = (costed.cfgBits[e] & PPGPU_EDGE_COVERAGE) != 0;
+            const bool cov = (cfgBits & PPGPU_EDGE_COVERAGE) != 0;
             g_dump.write(m_Nodes[source].state, r, cov ? m_Config.coverageTurningRadius() : m_Config.turningRadius(), cov);
         }
-        const bool truncated = (r.flags & PPGPU_F_RIBBON_OVF) && (int)((r.info >> 8) & 0xff) > costed.stride;
+        const bool truncated = (r.flags & PPGPU_F_RIBBON_OVF) && (int)((r.info >> 8) & 0xff) > blk.stride;
         const bool plainInfeasible = (r.flags & PPGPU_F_INFEASIBLE) && !(r.flags & (PPGPU_F_THROWS | PPGPU_F_DUBINS_ERR | PPGPU_F_RIBBON_LOST)) && !truncated;
         if (plainInfeasible && !watch) continue;
-        addNode(makeChild(source, costed.cfgBits[e], r, costed.childRibbons.data() + e * (size_t)costed.stride * 4, costed.stride));
+        addNode(makeChild(source, cfgBits, r, blk.child.get() + e * (size_t)blk.stride * 4, blk.stride));
         visualizeTrajectory(m_Nodes.back());   // in the reference each edge streams its sweep, then its vertex is pushed
         pushVertexQueue((int)m_Nodes.size() - 1);
     }
     m_Stats.Expanded++;
+    return true;
 }
 
 int GpuAStarPlanner::aStar(double endTime) {   // AStarPlanner.cpp:134-148
     int vertex = popVertexQueue();
     const bool guard = m_Config.deadlineGuard();
+    // with the guard on even the host-only part of the loop (an expansion whose children were costed ahead: a few microseconds of
+    // pushes) stops a little short of the deadline, so that plan() is back BEFORE it
+    const double loopEnd = guard ? endTime - kHostMargin : endTime;
     double t;
-    while ((t = now()) < endTime) {
+    while ((t = now()) < loopEnd) {
         if (goalCondition(m_Nodes[vertex])) {
             visualizeVertex(vertex, "vertex", false);
             return vertex;
@@ -669,7 +803,11 @@ int GpuAStarPlanner::aStar(double endTime) {   // AStarPlanner.cpp:134-148
             m_DeadlineStop = true;
             return -1;
         }
-        expand(vertex);
+        if (!expand(vertex)) {                // (the guard again, after the batch was picked)
+            m_Stats.DeadlineStops++;
+            m_DeadlineStop = true;
+            return -1;
+        }
         if (m_Queue.empty()) return -1;
         vertex = popVertexQueue();
     }
@@ -699,6 +837,7 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
     m_PlanEntry = HostProfile::now();
     m_Config = std::move(config);
     double endTime = timeRemaining + now();
+    m_EndTime = endTime;
     m_Config.setStartStateTime(start.time());
     m_RibbonManager = ribbonManager;
     m_RibbonManager.changeHeuristicIfTooManyRibbons();
@@ -712,6 +851,7 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
     if (m_Nodes.capacity() < kNodeArenaMin) m_Nodes.reserve(kNodeArenaMin);
     m_Queue.clear();
     m_Speculated.clear();
+    drainInFlight();
     m_NumSamples = 0;
     m_DeadlineStop = false;
     ppgpu_ctx* h = m_Ctx->handle();
@@ -831,7 +971,7 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
     m_Stats.Budget.PrologueMs = 1e3 * (HostProfile::now() - m_PlanEntry);
     const bool guard = m_Config.deadlineGuard();
     double tPoll;
-    while ((tPoll = now()) < endTime) {
+    while ((tPoll = now()) < (guard ? endTime - kHostMargin : endTime)) {
         m_Queue.clear();
         if (m_Best >= 0 && m_Nodes[m_Best].f() <= m_Nodes[startV].f()) {
             *m_Config.output() << "Found best possible plan, assuming heuristic admissibility" << std::endl;
@@ -884,6 +1024,7 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
         addSamples(moreSamples);
         visualizeSamples();
         int v = aStar(endTime);
+        drainInFlight();                       // prefetched round trips still running: the next pass changes the sample set (and uses the contexts)
         if (m_Best < 0 || (v >= 0 && m_Nodes[v].f() + 0.0 < m_Nodes[m_Best].f())) {
             m_Best = v;
             if (v >= 0 && m_Config.visualizations()) {   // :113-116
@@ -897,6 +1038,7 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
         // the Brown-path round trip and a sample doubling) — the reference's loop would find the clock past endTime at this point
         if (m_DeadlineStop) break;
     }
+    drainInFlight();                           // nothing of this planner runs on a context once plan() has returned
     m_Stats.Budget.LoopEndMs = 1e3 * (HostProfile::now() - m_PlanEntry);
     m_Stats.Budget.MarginMs = guard ? 1e3 * m_Ctx->guardMargin() : 0.0;
     m_Stats.Samples = (unsigned long)m_NumSamples;

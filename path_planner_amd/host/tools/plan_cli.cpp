@@ -105,11 +105,7 @@ int main(int argc, char** argv) {
     if (haveGauss) config.setObstaclesManager(gauss);
     std::vector<std::shared_ptr<GpuContext>> contexts;
     try {
-        for (size_t i = 0; i < devices.size(); i++) {
-            bool seen = false;
-            for (size_t j = 0; j < i; j++) seen = seen || devices[j] == devices[i];
-            contexts.push_back(seen ? std::make_shared<GpuContext>(devices[i]) : GpuContext::shared(devices[i]));
-        }
+        if (!devices.empty()) contexts = GpuContext::shared(devices);     // an id that repeats: a further context (stream) on that device
         if (contexts.empty()) contexts.push_back(GpuContext::shared(0));
     } catch (const std::exception& e) {
         std::printf("{\"exception\": \"%s\"}\n", e.what());
