@@ -426,7 +426,8 @@ def run_rank(args):
 
 
 # the device sources (path_planner_amd/csrc): what a PMC measurement is stamped with
-KERNEL_SOURCES = ("ppgpu.hip", "pp_kernels.h", "pp_device.h", "pp_sampler.h", "pp_cr.h", "pp_cr_tables.h")
+KERNEL_SOURCES = ("ppgpu.hip", "pp_kernels.h", "pp_k_common.h", "pp_k_solve.h", "pp_k_sweep.h", "pp_k_cover.h", "pp_k_heuristic.h", "pp_k_expand.h",
+                  "pp_k_incumbent.h", "pp_device.h", "pp_sampler.h", "pp_cr.h", "pp_cr_tables.h")
 
 
 def kernel_sources_sha256():

@@ -398,24 +398,38 @@ struct PPSeg {
     double bx, by, bth, sb, cb;   // base pose (unit radius, origin at qi), sin/cos of the base heading
     double lo, hi;                // tprime in [lo, hi) is sampled on this segment
     double o1, o2;                // tt = (tprime - o1) - o2
-    int type, pad;                // 0 = L, 1 = S, 2 = R
+    int type;                     // 0 = L, 1 = S, 2 = R
 };
-__device__ __forceinline__ void pp_curve_segments(const PPCurve& c, PPSeg* sg) {
-    sg[0] = PPSeg{0.0, 0.0, c.qth, c.s0, c.c0, -INFINITY, c.p0, 0.0, 0.0, c.t0, 0};
-    sg[1] = PPSeg{c.b1x, c.b1y, c.b1th, c.s1, c.c1, c.p0, c.p0 + c.p1, c.p0, 0.0, c.t1, 0};
-    sg[2] = PPSeg{c.b2x, c.b2y, c.b2th, c.s2, c.c2, c.p0 + c.p1, INFINITY, c.p0, c.p1, c.t2, 0};
+// What the setup record keeps of a segment: its base.  Everything else of PPSeg follows from the record's p0, p1 and hi1 = p0 + p1
+// (rounded once, by the solver) and from the Dubins word:
+//     segment 0: tprime in (-inf, p0),  tt = (tprime - 0) - 0        segment 1: [p0, hi1), tt = (tprime - p0) - 0
+//     segment 2: [hi1, +inf),           tt = (tprime - p0) - p1      (dubins_path_sample's own subtractions, in its order)
+struct PPSegBase { double bx, by, bth, sb, cb; };
+__device__ __forceinline__ void pp_curve_segments(const PPCurve& c, PPSegBase* sg) {
+    sg[0] = PPSegBase{0.0, 0.0, c.qth, c.s0, c.c0};
+    sg[1] = PPSegBase{c.b1x, c.b1y, c.b1th, c.s1, c.c1};
+    sg[2] = PPSegBase{c.b2x, c.b2y, c.b2th, c.s2, c.c2};
 }
+__device__ __forceinline__ double pp_seg_o1(int i, double p0) { return i >= 1 ? p0 : 0.0; }
+__device__ __forceinline__ double pp_seg_o2(int i, double p1) { return i == 2 ? p1 : 0.0; }
+// the kinds of a word's segments (a record without a path keeps word 0's, as the solver's pp_curve_init does)
+__device__ __forceinline__ int pp_word_seg_type(int word, int i) { return pp_seg_type(word < 0 ? 0 : word, i); }
 // Wave-uniform reads of data written by an EARLIER kernel, through the constant address space: the compiler then always
 // issues scalar loads (s_load) for them, which it otherwise only does where it can prove no store in this kernel aliases.
 #define PP_AS4 __attribute__((address_space(4)))
 __device__ __forceinline__ const PP_AS4 double* pp_const_f64(const void* p) { return (const PP_AS4 double*)(unsigned long long)p; }
 __device__ __forceinline__ const PP_AS4 int* pp_const_i32(const void* p) { return (const PP_AS4 int*)(unsigned long long)p; }
 __device__ __forceinline__ const PP_AS4 unsigned long long* pp_const_u64(const void* p) { return (const PP_AS4 unsigned long long*)(unsigned long long)p; }
-__device__ __forceinline__ PPSeg pp_seg_load_uniform(const PPSeg* g) {
+// segment `cur` (wave-uniform) of a setup record as the sweeps keep it in scalar registers: five scalar loads for the base, the rest
+// chosen among the record's p0 / p1 / hi1 / word, which the caller has in scalar registers already
+__device__ __forceinline__ PPSeg pp_seg_load_uniform(const PPSegBase* g, int cur, double p0, double p1, double hi1, int word) {
     const PP_AS4 double* d = pp_const_f64(g);
     PPSeg s;
-    s.bx = d[0]; s.by = d[1]; s.bth = d[2]; s.sb = d[3]; s.cb = d[4]; s.lo = d[5]; s.hi = d[6]; s.o1 = d[7]; s.o2 = d[8];
-    s.type = pp_const_i32(g)[18]; s.pad = 0;
+    s.bx = d[0]; s.by = d[1]; s.bth = d[2]; s.sb = d[3]; s.cb = d[4];
+    s.lo = cur == 0 ? -INFINITY : (cur == 1 ? p0 : hi1);
+    s.hi = cur == 0 ? p0 : (cur == 1 ? hi1 : INFINITY);
+    s.o1 = pp_seg_o1(cur, p0); s.o2 = pp_seg_o2(cur, p1);
+    s.type = pp_word_seg_type(word, cur);
     return s;
 }
 // which segment dubins_path_sample() picks for tprime: `tprime < p0`, else `tprime < p0 + p1`, else the third
@@ -457,52 +471,9 @@ __device__ __forceinline__ bool pp_is_blocked(const PPGrid& g, double x, double 
     uint32_t w = g.bits[(size_t)r * g.wpr + (c >> 5)];
     return (w >> (c & 31)) & 1u;
 }
-// The same lookup with the chunk's occupancy words staged in LDS first (BASELINE's north_star: "occupancy grid tiled into LDS").
-// MEASUREMENT VARIANT, -DPP_GRID_LDS (tools/variant_stats.sh; DESIGN.md Appendix B has the number): the wave finds the bounding box of
-// its 64 cells (rows x 32-cell words), copies those words from the L2-resident bit grid into its LDS tile with coalesced loads
-// (a chunk moves at most 3.2 m: some 35 rows x 2 words at 0.1 m cells), and every lane reads its word there.  Chunks whose box
-// does not fit the tile take the direct lookup.  `tile` = PP_GRID_TILE_WORDS dwords private to the wave.
-#define PP_GRID_TILE_WORDS 256
-__device__ __forceinline__ bool pp_is_blocked_lds(const PPGrid& g, double x, double y, bool valid, uint32_t* tile) {
-    if (g.rows == 0) return false;
-    const double cx = x * g.inv_res, cy = y * g.inv_res;
-    const unsigned cxl = (unsigned)(cx * (1.0 - 4e-9)), cxh = (unsigned)(cx * (1.0 + 4e-9));
-    const unsigned cyl = (unsigned)(cy * (1.0 - 4e-9)), cyh = (unsigned)(cy * (1.0 + 4e-9));
-    unsigned r = cyl, c = cxl;
-    bool outside = (x < 0) | (cxl >= (unsigned)g.cols) | (y < 0) | (cyl >= (unsigned)g.rows);
-    if (__ballot((cxl != cxh) | (cyl != cyh)) != 0ull) {
-        const double qx = x / g.res, qy = y / g.res;
-        outside = (x < 0) | (qx >= (double)g.cols) | (y < 0) | (qy >= (double)g.rows);
-        r = (unsigned)qy;
-        c = (unsigned)qx;
-    }
-    const bool in = valid & !outside;
-    const unsigned wd = c >> 5;
-    // bounding box of the in-grid cells, over the wave
-    unsigned rmin = in ? r : 0xffffffffu, rmax = in ? r : 0u, wmin = in ? wd : 0xffffffffu, wmax = in ? wd : 0u;
-    for (int o = 32; o > 0; o >>= 1) {
-        rmin = min(rmin, (unsigned)__shfl_xor((int)rmin, o, PP_WAVE)); rmax = max(rmax, (unsigned)__shfl_xor((int)rmax, o, PP_WAVE));
-        wmin = min(wmin, (unsigned)__shfl_xor((int)wmin, o, PP_WAVE)); wmax = max(wmax, (unsigned)__shfl_xor((int)wmax, o, PP_WAVE));
-    }
-    uint32_t w = 0u;
-    if (__ballot(in) == 0ull) return valid & outside;
-    const unsigned nrows = rmax - rmin + 1u, nw = wmax - wmin + 1u, total = nrows * nw;
-    if (total <= (unsigned)PP_GRID_TILE_WORDS) {
-        const int lane = pp_lane();
-        for (unsigned i = (unsigned)lane; i < total; i += PP_WAVE) {
-            const unsigned rr = (nw == 1u) ? i : ((nw == 2u) ? (i >> 1) : (i / nw));
-            const unsigned ww = i - rr * nw;
-            tile[i] = g.bits[(size_t)(rmin + rr) * g.wpr + (wmin + ww)];
-        }
-        pp_wave_lds_fence();
-        if (in) w = tile[(r - rmin) * nw + (wd - wmin)];
-        pp_wave_lds_fence();
-    } else if (in) {
-        w = g.bits[(size_t)r * g.wpr + wd];
-    }
-    if (outside) return valid;
-    return valid & (((w >> (c & 31)) & 1u) != 0u);
-}
+// (BASELINE's north_star asks for the occupancy grid "tiled into LDS".  Built and measured in round 3 — the wave copies the words under
+// its 64 cells into an LDS tile, every lane reads its word there, commit c47d58f — parity green, pose sweep 496 -> 606 us: the whole
+// 2048 x 2048 bit grid is 512 KiB and lives in every XCD's 4 MiB L2, so the direct lookup above stays.  DESIGN.md Appendix B.)
 
 // ----------------------------------------------------------------------------- dynamic obstacles
 // BinaryDynamicObstaclesManager::Obstacle with the per-call constants hoisted on the HOST with
@@ -819,12 +790,7 @@ __device__ __forceinline__ bool pp_any_erasable_piece(const PPRibbon& r, int n, 
 // The run covers samples first .. first + L - 1; the endpoint moves to the projection of the last of them, the same expression the
 // step-by-step run applies at its last step.  A sample that does not clear its margins ends the long run there and ordinary
 // windows take over: flags cannot differ.  With ell = 0 (and sinDt = 0) every expression below is the step-by-step one.
-#ifdef PP_RUN_NOINLINE
-#define PP_RUN_INLINE __noinline__
-#else
-#define PP_RUN_INLINE inline
-#endif
-__device__ PP_RUN_INLINE int pp_corridor_run(const PPRibbon& r, int n, double w, int adv, bool moveEnd, double x, double y, bool stepOk,
+__device__ inline int pp_corridor_run(const PPRibbon& r, int n, double w, int adv, bool moveEnd, double x, double y, bool stepOk,
                                       unsigned long long coverMask, int first, double span, double& newX, double& newY,
                                       double ell = 0.0, double sinDt = 0.0) {
     const int lane = pp_lane();
@@ -903,7 +869,7 @@ __device__ PP_RUN_INLINE int pp_corridor_run(const PPRibbon& r, int n, double w,
 // Long runs (ell > 0, see pp_corridor_run): a sample vouches for the steps between the previous sample and itself when it lies
 // inside a piece with ell to spare and no piece could split anywhere within ell of it — or cover() is off at ALL of those steps
 // (bit i of coverMask: cover() runs at SOME step sample i vouches for).
-__device__ PP_RUN_INLINE int pp_quiet_run(const PPRibbon& r, int n, double w, double x, double y, bool stepOk,
+__device__ inline int pp_quiet_run(const PPRibbon& r, int n, double w, double x, double y, bool stepOk,
                                    unsigned long long coverMask, int first, double span, double ell = 0.0) {
     const int lane = pp_lane();
     const double g = 1e-9;

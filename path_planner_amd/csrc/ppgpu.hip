@@ -859,7 +859,7 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     // chunk skipping needs the clearance map (or no grid at all) and solved curves (a given curve may start late or end early)
     // both prepasses pay for themselves on large launches only: a planner round trip of a few hundred edges is latency-bound
     const bool big = total >= c->prepass_min_edges;
-    p.track_skip = (PP_CHUNK_SKIP && big && !p.wedges && (c->rows == 0 || c->grid_clear.p) && p.ng >= PP_WAVE) ? c->track_skip.p : nullptr;
+    p.track_skip = (big && !p.wedges && (c->rows == 0 || c->grid_clear.p) && p.ng >= PP_WAVE) ? c->track_skip.p : nullptr;
     p.track_carry = c->track_carry.p;
     if (!big) p.track_far = nullptr;
     p.track_pen = c->track_pen.p; p.track_chunk_pen = c->track_chunk_pen.p;
@@ -881,7 +881,7 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         if (rc) return rc;
         p.live_list = c->live_list.p; p.live_count = c->need_big.p + 12;
     }
-#if defined(PP_DBG_COUNTS) || defined(PP_DBG_EVENTS) || defined(PP_ABL_ONLY_EVENTS) || defined(PP_NO_LANE_FINISH)
+#if defined(PP_DBG_COUNTS)
     const bool laneFinishBuilt = false;     // (those builds keep every edge with its wave: pp_cover_sweep_edge)
 #else
     const bool laneFinishBuilt = true;
@@ -948,61 +948,6 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
             hipLaunchKernelGGL(pp_k_cover_finish, dim3((unsigned)((p.n_edges + PP_FINISH_THREADS - 1) / PP_FINISH_THREADS)), dim3(PP_FINISH_THREADS), 0, c->stream, p);
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     }
-#ifdef PP_DBG_QUIET
-    {   // developer aid: how the approach chains of the last slice ended
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        unsigned cnt[16];
-        HIP_TRY(hipMemcpy(cnt, c->need_big.p, sizeof(cnt), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[quiet] edges %lld: finished by the lane %u, no events but left to the wave %u, handed over %u\n", p.n_edges, cnt[8], cnt[9], cnt[10]);
-        HIP_TRY(hipMemset(c->need_big.p + 8, 0, 8 * sizeof(unsigned)));
-    }
-#endif
-#ifdef PP_DBG_SKIPS
-    if (p.track_skip) {   // developer aid: how many of the chunks the sweeps reached were skipped (last slice)
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        std::vector<unsigned char> sk((size_t)p.n_edges * p.nch);
-        std::vector<PPTrackSummary> sm((size_t)p.n_edges);
-        HIP_TRY(hipMemcpy(sk.data(), c->track_skip.p, sk.size(), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(sm.data(), c->track_summary.p, sm.size() * sizeof(PPTrackSummary), hipMemcpyDeviceToHost));
-        unsigned long long reached = 0, skipped = 0, marked = 0;
-        for (long long e = 0; e < p.n_edges; e++) {
-            const int nreach = (sm[(size_t)e].limit + 63) / 64;
-            for (int ch = 0; ch < p.nch; ch++) {
-                marked += sk[(size_t)e * p.nch + ch];
-                if (ch < nreach) { reached++; skipped += sk[(size_t)e * p.nch + ch]; }
-            }
-        }
-        std::fprintf(stderr, "[skips] edges %lld, chunks reached %llu, skipped %llu (%.1f %%), marked in all %llu\n", p.n_edges, reached, skipped,
-                     reached ? 100.0 * skipped / reached : 0.0, marked);
-        // how many chunks per edge the pose sweep samples, and how often the only one is the edge's last (partial or stopping) chunk
-        unsigned long long hist[8] = {0, 0, 0, 0, 0, 0, 0, 0}, onlyLast = 0, lastPartial = 0;
-        for (long long e = 0; e < p.n_edges; e++) {
-            const int lim = sm[(size_t)e].limit, nreach = (lim + 63) / 64 + ((lim % 64 == 0) ? 1 : 0);   // the chunk the sweep stops in is reached too
-            int sampled = 0, lastSampled = 0;
-            for (int ch = 0; ch < p.nch && ch < nreach; ch++)
-                if (!(sk[(size_t)e * p.nch + ch] & 1)) { sampled++; lastSampled = (ch == nreach - 1); }
-            hist[sampled < 7 ? sampled : 7]++;
-            if (sampled == 1 && lastSampled) onlyLast++;
-            if (lim % 64 != 0) lastPartial++;
-        }
-        {
-            // which chunks are sampled, and what the planner knew about them: [position: first / middle / last reached][skip byte >> 1: neither half clear, grid clear, obstacles clear, both]
-            unsigned long long why[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-            for (long long e = 0; e < p.n_edges; e++) {
-                const int lim = sm[(size_t)e].limit, nreach = (lim + 63) / 64 + ((lim % 64 == 0) ? 1 : 0);
-                for (int ch = 0; ch < p.nch && ch < nreach; ch++) {
-                    const unsigned b = sk[(size_t)e * p.nch + ch];
-                    if (!(b & 1)) why[ch == nreach - 1 ? 2 : (ch == 0 ? 0 : 1)][(b >> 1) & 3]++;
-                }
-            }
-            for (int i = 0; i < 3; i++)
-                std::fprintf(stderr, "[skips] sampled %s chunks: nothing clear %llu, grid clear %llu, obstacles clear %llu, both clear (geometry / heading bits) %llu\n",
-                             i == 0 ? "first" : (i == 1 ? "middle" : "last"), why[i][0], why[i][1], why[i][2], why[i][3]);
-        }
-        std::fprintf(stderr, "[skips] sampled chunks per edge: 0:%llu 1:%llu 2:%llu 3:%llu 4:%llu 5:%llu 6:%llu 7+:%llu; only the last one %llu; limit not a multiple of 64: %llu\n",
-                     hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], onlyLast, lastPartial);
-    }
-#endif
     p.e_base = 0;
     p.n_edges = total;
     if (p.heuristic == PPGPU_H_TSP_DUBINS_ALL || p.heuristic == PPGPU_H_TSP_DUBINS_K)
@@ -1032,18 +977,6 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
         const long long need = (total + PP_H_WPB - 1) / PP_H_WPB;
         hipLaunchKernelGGL(pp_k_heuristic_big, dim3((unsigned)(need < PP_BIG_GRID ? need : PP_BIG_GRID)), dim3(PP_H_WPB * 64), 0, c->stream, p);
     }
-#ifdef PP_HL_COUNT
-    if (p.defer_h) {   // developer aid: how much of the lane heuristic's enumeration the bound cut away
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        unsigned cnt[2];
-        HIP_TRY(hipMemcpy(cnt, c->need_big.p + 14, sizeof(cnt), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[lane tsp] last-two-level calls per wave: %u of %u without pruning\n", cnt[0], cnt[1]);
-        unsigned hw = 0;
-        HIP_TRY(hipMemcpy(&hw, c->need_big.p + 13, sizeof(hw), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[finish] edges left to pp_k_heuristic_listed: %u\n", hw);
-        HIP_TRY(hipMemset(c->need_big.p + 14, 0, 2 * sizeof(unsigned)));
-    }
-#endif
     if (forked) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     c->last_launch_edges = total; c->last_launch_packed = p.live_list != nullptr;
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], c->stream)); c->ev_launches++; }

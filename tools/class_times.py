@@ -1,6 +1,6 @@
 """Developer tool (GPU box): HIP-event times of the costing launch's kernel groups for each of the four edge configurations
 of the bench workload alone (dense launch with cfg_mask 1, 2, 4, 8) and for all four: which class of edges the time goes to.
-PPGPU_LIB_OVERRIDE selects a variant library (e.g. one built with -DPP_ABL_NO_EVENTS: the cover sweep without its event loop)."""
+PPGPU_LIB_OVERRIDE selects a variant library."""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
