@@ -803,8 +803,21 @@ __device__ inline int pp_corridor_run(const PPRibbon& r, int n, double w, int ad
     const double px = dxr * dot / sqL + Sx;
     const double py = dyr * dot / sqL + Sy;
     const double num = dyr * x - dxr * y + Ex * Sy - Ey * Sx;
-    const double lim = w / 2.0 - ell;
-    const bool strictOk = (lim > 0.0) & ((num * num) < ((lim * lim) * sqL) * (1.0 - g));
+    // Long runs, round 4: what a sample vouches for is decided on the CHORD from the sample before it.  The steps between two samples
+    // lie on a curve of curvature <= 1/rho and arc length <= ell, so they stay within sag = ell^2 / (8 rho) of the chord; a condition
+    // whose region is convex (inside a corridor: a strip; a projection beyond one end of a piece: a half-plane, projections being
+    // linear and contracting) holds at all of them when it holds at BOTH samples with sag to spare.  Rounds 3's margin was ell itself
+    // (every step within ell of its sample): 5 cm where sag is 0.02 mm, so a long run could not start until the vehicle was 5 cm
+    // inside the strict corridor and 5 cm past the piece the split left behind it — the first window after a split was never one.
+    // The first sample of a window is the step after the last event and vouches for itself alone: it needs no partner (it is tested
+    // with the same margin, being the next sample's partner).
+    const double sag = (ell > 0.0) ? (ell * sinDt * 0.125) * (1.0 + 1e-9) + 1e-9 : 0.0;
+    const double lim = w / 2.0 - sag;
+    bool strictOk = (lim > 0.0) & ((num * num) < ((lim * lim) * sqL) * (1.0 - g));
+    if (ell > 0.0) {                                              // wave-uniform
+        const bool prevOk = __shfl_up((int)strictOk, 1, PP_WAVE) != 0;
+        strictOk = strictOk & ((lane == first) | prevOk);
+    }
     // the moving endpoint this step will see: the previous step's projection (the piece's own endpoint for the first)
     double qx = __shfl_up(px, 1, PP_WAVE), qy = __shfl_up(py, 1, PP_WAVE);
     if (lane == first) { qx = moveEnd ? Ex : Sx; qy = moveEnd ? Ey : Sy; }
@@ -843,13 +856,23 @@ __device__ inline int pp_corridor_run(const PPRibbon& r, int n, double w, int ad
             const double dq = ex - sx, eq = ey - sy;
             const double dt = (x - sx) * dq + (y - sy) * eq;
             const double ppx = dq * dt / ql + sx, ppy = eq * dt / ql + sy;
-            const double T2 = PP_RIBBON_TOL + g + ell;
+            const double T2 = PP_RIBBON_TOL + g + sag;
             const double c1 = ppx - sx, c2 = ppx - ex, d1 = ppy - sy, d2 = ppy - ey;
-            const bool cpOut = (((c1 < -T2) & (c2 < -T2)) | ((c1 > T2) & (c2 > T2))) | (((d1 < -T2) & (d2 < -T2)) | ((d1 > T2) & (d2 > T2)));
+            // which of the four half-plane pairs of Ribbon::containsProjection puts the projection outside the piece
+            const int outCode = (((c1 < -T2) & (c2 < -T2)) ? 1 : 0) | (((c1 > T2) & (c2 > T2)) ? 2 : 0) | (((d1 < -T2) & (d2 < -T2)) ? 4 : 0) | (((d1 > T2) & (d2 > T2)) ? 8 : 0);
             const double nq = eq * x - dq * y + ex * sy - ey * sx;
-            const double lo = w / 2.0 + ell;
+            const double lo = w / 2.0 + sag;
             const bool strictOut = (nq * nq) > ((lo * lo) * ql) * (1.0 + g);
-            ok = ok & (far | cpOut | strictOut);
+            bool clear = (outCode != 0) | strictOut;
+            if (ell > 0.0) {
+                // ... on the same side as the sample before (a chord cannot leave a half-plane both its ends are in)
+                const int prevCode = __shfl_up(outCode, 1, PP_WAVE);
+                const bool prevStrictOut = __shfl_up((int)strictOut, 1, PP_WAVE) != 0;
+                const bool prevPos = __shfl_up((int)(nq > 0.0), 1, PP_WAVE) != 0;
+                const bool pair = ((outCode & prevCode) != 0) | (strictOut & prevStrictOut & ((nq > 0.0) == prevPos));
+                clear = (lane == first) ? clear : pair;
+            }
+            ok = ok & (far | clear);
         }
     }
     const unsigned long long okMask = __ballot(ok);
@@ -870,9 +893,11 @@ __device__ inline int pp_corridor_run(const PPRibbon& r, int n, double w, int ad
 // inside a piece with ell to spare and no piece could split anywhere within ell of it — or cover() is off at ALL of those steps
 // (bit i of coverMask: cover() runs at SOME step sample i vouches for).
 __device__ inline int pp_quiet_run(const PPRibbon& r, int n, double w, double x, double y, bool stepOk,
-                                   unsigned long long coverMask, int first, double span, double ell = 0.0) {
+                                   unsigned long long coverMask, int first, double span, double ell = 0.0, double sinDt = 0.0) {
     const int lane = pp_lane();
     const double g = 1e-9;
+    // long runs: decisions on the chord from the sample before, with the sagitta to spare at both of its ends (see pp_corridor_run)
+    const double sagL = (ell > 0.0) ? (ell * sinDt * 0.125) * (1.0 + 1e-9) + 1e-9 : 0.0;
     const bool cand = stepOk & (lane >= first);
     bool inside = false, maySplit = false;
     unsigned long long pieces = pp_pieces_in_reach(r, n, w, pp_readlane(x, first), pp_readlane(y, first), span);
@@ -889,20 +914,32 @@ __device__ inline int pp_quiet_run(const PPRibbon& r, int n, double w, double x,
             const double dt = (x - sx) * dq + (y - sy) * eq;
             const double ppx = dq * dt / ql + sx, ppy = eq * dt / ql + sy;
             const double c1 = ppx - sx, c2 = ppx - ex, d1 = ppy - sy, d2 = ppy - ey;
-            const double Ti = PP_RIBBON_TOL - g, To = PP_RIBBON_TOL + g + ell;
+            const double Ti = PP_RIBBON_TOL - g, To = PP_RIBBON_TOL + g + sagL;
             bool cpIn = !((((c1 < -Ti) & (c2 < -Ti)) | ((c1 > Ti) & (c2 > Ti))) | (((d1 < -Ti) & (d2 < -Ti)) | ((d1 > Ti) & (d2 > Ti))));
             if (ell > 0.0) {
-                // inside the piece's extent by ell, measured along the piece (dt / |piece| = distance of the projection from the
-                // start): every pose within ell then projects inside the extent, where the reference's per-coordinate test passes
-                const double marginLen = (ell + 1e-6) * sqrt(ql);
+                // inside the piece's extent by the sagitta, measured along the piece (dt / |piece| = distance of the projection from
+                // the start): every pose within it then projects inside the extent, where the reference's per-coordinate test passes
+                const double marginLen = (sagL + 1e-6) * sqrt(ql);
                 cpIn = (dt > marginLen) & ((ql - dt) > marginLen);
             }
-            const bool cpOut = (((c1 < -To) & (c2 < -To)) | ((c1 > To) & (c2 > To))) | (((d1 < -To) & (d2 < -To)) | ((d1 > To) & (d2 > To)));
+            const int outCode = (((c1 < -To) & (c2 < -To)) ? 1 : 0) | (((c1 > To) & (c2 > To)) ? 2 : 0) | (((d1 < -To) & (d2 < -To)) ? 4 : 0) | (((d1 > To) & (d2 > To)) ? 8 : 0);
             const double nq = eq * x - dq * y + ex * sy - ey * sx;
             const double A = nq * nq;
-            const double wi = w - ell, wo = w / 2.0 + ell;
-            inside = inside | (!far & cpIn & (wi > 0.0) & (A < ((wi * wi) * ql) * (1.0 - g)));
-            maySplit = maySplit | (!far & !cpOut & !(A > ((wo * wo) * ql) * (1.0 + g)));
+            const double wi = w - sagL, wo = w / 2.0 + sagL;
+            bool in = !far & cpIn & (wi > 0.0) & (A < ((wi * wi) * ql) * (1.0 - g));     // inside this piece's corridor (a rectangle: convex)
+            const bool strictOut = A > ((wo * wo) * ql) * (1.0 + g);
+            bool clear = far | (outCode != 0) | strictOut;                              // cannot be strictly inside this piece
+            if (ell > 0.0) {
+                // both this sample and the one before it, in the same piece / beyond the same face of it: then every step between them
+                const bool prevIn = __shfl_up((int)in, 1, PP_WAVE) != 0;
+                const int prevCode = __shfl_up(outCode, 1, PP_WAVE);
+                const bool prevStrictOut = __shfl_up((int)strictOut, 1, PP_WAVE) != 0, prevPos = __shfl_up((int)(nq > 0.0), 1, PP_WAVE) != 0;
+                // (far: farther from the piece than its reach plus ell, so every step within ell of this sample is out of its reach)
+                const bool pairClear = far | ((outCode & prevCode) != 0) | (strictOut & prevStrictOut & ((nq > 0.0) == prevPos));
+                if (lane != first) { in = in & prevIn; clear = pairClear; }
+            }
+            inside = inside | in;
+            maySplit = maySplit | !clear;
         }
     }
     const bool coverOn = ((coverMask >> lane) & 1ull) != 0ull;

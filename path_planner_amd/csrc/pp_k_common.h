@@ -12,6 +12,7 @@ struct PPParams {
     int heuristic, tsp_k;
     int fuse_h;                          // the cover sweep's wave goes straight on to the edge's heuristic (see PP_FUSE_HEUR)
     int quiet_finish;                    // pp_k_approach_events finishes the edges whose cover sweep has nothing to do
+    int lane_split;                      // ... and splits the ribbon an edge enters itself (the wave then starts inside the corridor run)
     int defer_h;                         // ... unless the edge left its ribbons untouched: then pp_k_heuristic_lanes does it (large launches)
     double h_rho;                        // RibbonManager::m_TurningRadius of the Dubins-TSP heuristics
     // world
@@ -35,13 +36,15 @@ struct PPParams {
     // workspace: one PPEdgeSetup per edge from pp_k_solve_edges, then what the pose sweep leaves for the cover sweep
     struct PPEdgeSetup* setup;
     unsigned short* track_hits;          // [edge][ngp]  dynamic-obstacle boxes hit at step k
-    unsigned long long* track_eq;        // [edge][nch]  bit k & 63 of word k >> 6: heading(k) == heading(k - 1)
+    unsigned long long* track_eq;        // [edge][nch]  bit k & 63 of word k >> 6: heading(k) == heading(k - 1).  Until the pose sweep has sampled
+                                         //              a chunk its word holds, as a double, the heading of the step before the chunk
+                                         //              (pp_k_plan_skips leaves it for chunks it does not skip; round 4: one dense row
+                                         //              instead of two half-empty ones)
     unsigned* track_chunk_hits;          // [edge][nch]  hits summed over the chunk's executable steps
     double* track_pen;                   // Gaussian model only: [edge][ngp] collisionExists(step k) ...
     double* track_chunk_pen;             // ... and [edge][nch] its sum times the penalty factor over the chunk's executable steps
     struct PPTrackSummary* track_summary;
     unsigned char* track_skip;           // [edge][nch]  1: the pose sweep skips this 64-step chunk (pp_k_plan_skips); NULL: no skipping
-    double* track_carry;                 // [edge][nch]  heading of the step before the chunk, for edges that may not cover while turning
     int2* track_far;                     // [edge] {first event the cover sweep's wave has to visit, last event before it} (pp_k_approach_events)
     unsigned long long* work;            // work-queue heads of the per-edge kernels (PP_Q_*), zeroed by pp_k_solve_edges
     unsigned* live_list; unsigned* live_count;     // {workspace slot, list position} of the edges the cover sweep still has to visit (pp_k_approach_events)
@@ -71,10 +74,16 @@ struct PPEdgeSetupBody {
 struct __attribute__((aligned(128))) PPEdgeSetup : PPEdgeSetupBody {};
 static_assert(sizeof(PPEdgeSetup) == 256 && sizeof(PPEdgeSetupBody) == 248, "PPEdgeSetup is sized for two 128-byte lines");
 // this lane's pose on segment i of a record (dubins_path_sample on that segment, un-normalised yaw): the lane-per-edge kernels
+// (p0, p1, word: the record's own, which a caller that samples several poses keeps in registers — per pose only the 40-byte base
+// is then read, and the three bases share the record's first 128-byte line)
+template <bool TAB = false>
+__device__ __forceinline__ void pp_setup_seg_pose(const PPEdgeSetupBody* S, int i, double tprime, double p0, double p1, int word, double& ux, double& uy, double& uth) {
+    const PPSegBase* g = &S->seg[i];
+    pp_curve_seg<TAB>(pp_word_seg_type(word, i), (tprime - pp_seg_o1(i, p0)) - pp_seg_o2(i, p1), g->bx, g->by, g->bth, g->sb, g->cb, ux, uy, uth);
+}
 template <bool TAB = false>
 __device__ __forceinline__ void pp_setup_seg_pose(const PPEdgeSetupBody* S, int i, double tprime, double& ux, double& uy, double& uth) {
-    const PPSegBase* g = &S->seg[i];
-    pp_curve_seg<TAB>(pp_word_seg_type(S->type, i), (tprime - pp_seg_o1(i, S->p0)) - pp_seg_o2(i, S->p1), g->bx, g->by, g->bth, g->sb, g->cb, ux, uy, uth);
+    pp_setup_seg_pose<TAB>(S, i, tprime, S->p0, S->p1, S->type, ux, uy, uth);
 }
 // The lane-per-edge prepasses read a record per LANE.  Straight from memory that is one 64-line gather per field; they stage the
 // records of their workgroup in LDS instead (contiguous, coalesced 8-byte-per-lane loads) and read the fields from there.  The

@@ -45,13 +45,14 @@ __device__ __forceinline__ int pp_event_stride(double D, double inc_d, double in
 // One ribbon's part of a coverage event at (x, y), lane form (the expressions of pp_k_cover_finish / pp_ribbons_event): does the ribbon
 // contain the point (RibbonManager::minDistanceFrom then returns 0) and does it contain it strictly (cover() would split it)?
 // Only called for a ribbon whose grown bounding box holds the point; outside it neither can be.
-__device__ __forceinline__ void pp_lane_ribbon_contains(double sx, double sy, double ex, double ey, double x, double y, double w, bool& inside, bool& strict) {
+__device__ __forceinline__ void pp_lane_ribbon_contains(double sx, double sy, double ex, double ey, double x, double y, double w, bool& inside, bool& strict,
+                                                        double& px, double& py) {
     const double T = PP_RIBBON_TOL;
     const double dxr = ex - sx, dyr = ey - sy;
     const double sqL = dxr * dxr + dyr * dyr;
     const double dot = (x - sx) * dxr + (y - sy) * dyr;
-    const double px = dxr * dot / sqL + sx;                  // Ribbon::getProjection (Ribbon.cpp:72-78)
-    const double py = dyr * dot / sqL + sy;
+    px = dxr * dot / sqL + sx;                               // Ribbon::getProjection (Ribbon.cpp:72-78)
+    py = dyr * dot / sqL + sy;
     const double a1 = px - sx, a2 = px - ex, b1 = py - sy, b2 = py - ey;
     const bool outx = ((a1 < -T) & (a2 < -T)) | ((a1 > T) & (a2 > T));
     const bool outy = ((b1 < -T) & (b2 < -T)) | ((b1 > T) & (b2 > T));
@@ -62,14 +63,20 @@ __device__ __forceinline__ void pp_lane_ribbon_contains(double sx, double sy, do
     strict = cp && (ld < (w / 2.0));
 }
 #define PP_FAR_DONE (-2)
+// PPParams::track_far[e].y = (last event before the hand-over) + 1 in the low 20 bits, and, when the approach lane has already split the
+// one ribbon the vehicle entered (round 4): PP_FAR_SPLIT, which piece the corridor run that follows moves (6 bits) and which of its ends
+#define PP_FAR_LAST_MASK 0xfffff
+#define PP_FAR_SPLIT (1 << 30)
+#define PP_FAR_MOVE_END (1 << 29)
+#define PP_FAR_PIECE_SHIFT 21
 __device__ __forceinline__ void pp_lane_pose(const PPEdgeSetupBody* S, double t, double wStart, double speed, double length, double rho, double rho_inv,
-                                             double qx, double qy, double hi0, double hi1, double& x, double& y, double& uth, bool& err) {
+                                             double qx, double qy, double hi0, double hi1, double p1, int word, double& x, double& y, double& uth, bool& err) {
     double dist = (t - wStart) * speed;                                     // DubinsWrapper.cpp:36
     if (dist < 0 || dist > length) dist = dist - 1e-5;                      // EDUBPARAM retry, :39-42
     if (dist < 0 || dist > length) { err = true; dist = fmin(fmax(dist, 0.0), length); }
     const double tprime = (rho_inv != 0.0) ? dist * rho_inv : dist / rho;
     double ux, uy;
-    pp_setup_seg_pose(S, pp_seg_of(tprime, hi0, hi1), tprime, ux, uy, uth);
+    pp_setup_seg_pose(S, pp_seg_of(tprime, hi0, hi1), tprime, hi0, p1, word, ux, uy, uth);      // (hi0 = the record's p0)
     x = ux * rho + qx;
     y = uy * rho + qy;
 }
@@ -88,7 +95,8 @@ __device__ __forceinline__ bool pp_finish_quiet_edge(const PPParams& p, const PP
     const bool deferH = p.defer_h && pp_lane_tsp_ok(p.heuristic, p.tsp_k, nrib);
     if (p.fuse_h && !deferH && p.heuristic != PPGPU_H_MAX_DISTANCE) return false;
     const double wStart = S->wStart, wEnd = S->wEnd, speed = S->speed, length = S->length, rho = S->rho, rho_inv = S->rho_inv, qx = S->qx, qy = S->qy;
-    const double hi0 = S->p0, hi1 = S->hi1;
+    const double hi0 = S->p0, hi1 = S->hi1, segP1 = S->p1;
+    const int dubWord = S->type;
     const double srcT = V->time;
     const bool cov = (S->cbits & PPGPU_EDGE_COVERAGE) != 0;
     const double endTime = fmin(p.horizon + 1e-12 + p.sst, wEnd);           // Edge.cpp:90; no event shortened it
@@ -118,9 +126,9 @@ __device__ __forceinline__ bool pp_finish_quiet_edge(const PPParams& p, const PP
     if (!(wStart <= endTime && wEnd >= endTime)) return false;              // DubinsWrapper::containsTime: the reference throws
     double ix = V->x, iy = V->y, uth;
     bool perr = false, ignored = false;
-    if (lastIdx >= 0) pp_lane_pose(S, tg[lastIdx], wStart, speed, length, rho, rho_inv, qx, qy, hi0, hi1, ix, iy, uth, ignored);
+    if (lastIdx >= 0) pp_lane_pose(S, tg[lastIdx], wStart, speed, length, rho, rho_inv, qx, qy, hi0, hi1, segP1, dubWord, ix, iy, uth, ignored);
     double endX, endY;
-    pp_lane_pose(S, endTime, wStart, speed, length, rho, rho_inv, qx, qy, hi0, hi1, endX, endY, uth, perr);
+    pp_lane_pose(S, endTime, wStart, speed, length, rho, rho_inv, qx, qy, hi0, hi1, segP1, dubWord, endX, endY, uth, perr);
     if (perr) return false;
     const double endHeading = pp_heading_from_yaw(pp_mod2pi(uth));
     if (cov || coverFinal) {                                                // the last cover (:182-191): only if it cannot touch a ribbon
@@ -205,7 +213,8 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
     const long long e = e0 + threadIdx.x;
     const bool valid = e < p.n_edges;
     const PPEdgeSetupBody* S = p.setup + p.ws_base + (valid ? e : 0);
-    int2 out; out.x = 0; out.y = -1;
+    int2 out; out.x = 0; out.y = 0;                 // {first event of the wave, (last event before it) + 1 | PP_FAR_* bits}
+    int splitInfo = 0;
     const unsigned sflags = S->sflags;
     const int dubType = S->type;
     // do all lanes of this wave start from the same open vertex?
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
             const double* rp = p.ribbons + 4 * (size_t)V->ribbon_offset;
             const double* tg = p.tgrid + (size_t)S->vi * p.ng;
             const double wStart = S->wStart, speed = S->speed, length = S->length, rho = S->rho, rho_inv = S->rho_inv, qx = S->qx, qy = S->qy;
-            const double hi0 = S->p0, hi1 = S->hi1;
+            const double hi0 = S->p0, hi1 = S->hi1, segP1 = S->p1;
             const double endTime0 = fmin(p.horizon + 1e-12 + p.sst, S->wEnd);
             const double w = p.ribw, grow = w + 1e-3, minLength0 = 2 * w;
             bool tiny = false;
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
                 if (dist < 0 || dist > length) { handOver = true; break; }              // the wavefront's code flags the error
                 const double tprime = (rho_inv != 0.0) ? dist * rho_inv : dist / rho;
                 double ux, uy, uth;
-                pp_setup_seg_pose(S, pp_seg_of(tprime, hi0, hi1), tprime, ux, uy, uth);
+                pp_setup_seg_pose(S, pp_seg_of(tprime, hi0, hi1), tprime, hi0, segP1, dubType, ux, uy, uth);
                 const double x = ux * rho + qx, y = uy * rho + qy;
                 bool inBox = false;
                 int boxCount = 0, boxIdx = 0;
@@ -284,7 +293,9 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
                 if (inBox) {
                     if (boxCount == 1 && nearBudget-- > 0) {
                         bool inside, strict;
-                        pp_lane_ribbon_contains(rp[4 * boxIdx], rp[4 * boxIdx + 1], rp[4 * boxIdx + 2], rp[4 * boxIdx + 3], x, y, w, inside, strict);
+                        double px, py;
+                        const double bsx = rp[4 * boxIdx], bsy = rp[4 * boxIdx + 1], bex = rp[4 * boxIdx + 2], bey = rp[4 * boxIdx + 3];
+                        pp_lane_ribbon_contains(bsx, bsy, bex, bey, x, y, w, inside, strict, px, py);
                         // Edge.cpp:159: cover() runs when coverage is allowed on this edge or the heading did not change since the last step
                         const bool coverOn = covEdge || (((p.track_eq[(size_t)(p.ws_base + e) * p.nch + (k >> 6)] >> (k & 63)) & 1ull) != 0ull);
                         if (!(strict && coverOn)) {
@@ -293,13 +304,38 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
                             k = k + pp_event_stride(D, p.inc_d, p.inv_inc_d, p.ng) + 1;
                             continue;
                         }
+                        // Round 4: the event that SPLITS the one ribbon in reach is the lane's too, when both halves stay (the vehicle
+                        // entered the strict corridor somewhere along the ribbon): RibbonManager::cover over the list in order changes
+                        // this ribbon only — nothing else is in reach, nothing is short enough to be erased — into [start, projection]
+                        // and [projection, end] (Ribbon::split, Ribbon.cpp:9-17; covered(strict), :23-25).  The new list goes into the
+                        // edge's child-ribbon slot and the wave starts one step later, inside the corridor run that nearly always
+                        // follows (the half the vehicle travels into, by the direction of travel: the run's own checks decide, a wrong
+                        // guess costs it one attempt) — and in long-run mode from its first window.  The wave used to spend a window
+                        // and its most expensive kind of event here, then a 64-step run before the first long one.
+                        const double thr = minLength0 * minLength0 / (2.0 * 2.0);
+                        const bool keepF = !(pp_sq_len(bsx, bsy, px, py) < thr), keepR = !(pp_sq_len(px, py, bex, bey) < thr);
+                        if (keepF && keepR && p.lane_split && nrib + 1 <= p.stride && nrib + 1 <= PP_WAVE) {
+                            double* c = p.child + (size_t)pp_edge_position(p, p.e_base + e) * p.stride * 4;
+                            for (int i = 0; i < boxIdx; i++) { c[4 * i] = rp[4 * i]; c[4 * i + 1] = rp[4 * i + 1]; c[4 * i + 2] = rp[4 * i + 2]; c[4 * i + 3] = rp[4 * i + 3]; }
+                            c[4 * boxIdx] = bsx; c[4 * boxIdx + 1] = bsy; c[4 * boxIdx + 2] = px; c[4 * boxIdx + 3] = py;
+                            c[4 * boxIdx + 4] = px; c[4 * boxIdx + 5] = py; c[4 * boxIdx + 6] = bex; c[4 * boxIdx + 7] = bey;
+                            for (int i = boxIdx + 1; i < nrib; i++) { c[4 * i + 4] = rp[4 * i]; c[4 * i + 5] = rp[4 * i + 1]; c[4 * i + 6] = rp[4 * i + 2]; c[4 * i + 7] = rp[4 * i + 3]; }
+                            // which half does the vehicle travel into?  The direction of travel is the pose's yaw.
+                            double sn, cs;
+                            pp_sincos_bounded(uth, &sn, &cs);
+                            const bool towardsEnd = (cs * (bex - bsx) + sn * (bey - bsy)) > 0.0;
+                            splitInfo = PP_FAR_SPLIT | (towardsEnd ? 0 : PP_FAR_MOVE_END) | ((towardsEnd ? boxIdx + 1 : boxIdx) << PP_FAR_PIECE_SHIFT);
+                            lastEv = k;
+                            k = k + 1;
+                            handOver = true; break;
+                        }
                     }
                     handOver = true; break;                                             // a ribbon changes here (or two are in reach, or the budget is spent): the wavefront takes over
                 }
                 lastEv = k;
                 k = k + pp_event_stride(D, p.inc_d, p.inv_inc_d, p.ng) + 1;
             }
-            out.x = k; out.y = lastEv;
+            out.x = k; out.y = (lastEv + 1) | splitInfo;
             if (!handOver && k >= limit && p.quiet_finish &&
                 pp_finish_quiet_edge(p, S, V, p.ws_base + e, pp_edge_position(p, p.e_base + e), limit, lastEv, oneVertex ? rpU : rp, tg, s_rec + (size_t)threadIdx.x * PP_REC_STRIDE, oneVertex))
                 out.x = PP_FAR_DONE;
@@ -424,9 +460,24 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
     int rdt = -1;                       // `auto ribbonsDoneTime = -1;` is an int (Edge.cpp:92)
     int nextEvent = 0;                  // toCoverDistance starts at 0: step 0 is an event
     int lastEv = -1;
+    int handCont = 0, handPiece = 0, handCount = 0;   // (handCount: entries of the child slot the lane's split list occupies)
+    bool handMoveEnd = false;
     if (p.track_far) {                  // the approach was walked by pp_k_approach_events: start where it handed over
         nextEvent = pp_const_i32(&p.track_far[e].x)[0];
-        lastEv = pp_const_i32(&p.track_far[e].y)[0];
+        const int fy = pp_const_i32(&p.track_far[e].y)[0];
+        lastEv = (fy & PP_FAR_LAST_MASK) - 1;
+        if (fy & PP_FAR_SPLIT) {
+            // the lane split the ribbon the vehicle entered: the list as it stands is in the edge's child slot, and the wave begins inside
+            // the corridor run (long-run mode allowed at once)
+            nrib = nrib + 1;
+            rib = PPRibbon{0, 0, 0, 0};
+            if (lane < nrib) {
+                const double* rp = p.child + ((size_t)eg * p.stride + lane) * 4;
+                rib.sx = rp[0]; rib.sy = rp[1]; rib.ex = rp[2]; rib.ey = rp[3];
+            }
+            handCont = 1 | 4; handPiece = (fy >> PP_FAR_PIECE_SHIFT) & 0x3f; handMoveEnd = (fy & PP_FAR_MOVE_END) != 0;
+            handCount = nrib;
+        }
     }
     const double w = p.ribw;
     const double inc_d = p.inc_d;
@@ -453,9 +504,9 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
     // ---- phase B: coverage events among steps [0, limit)
     if (!throwsRef) {
         bool ended = false;
-        int cont = 0, contPiece = 0;        // 1 / 2: the last window ended inside a corridor / quiet run (of piece contPiece); + 4: it was
+        int cont = handCont, contPiece = handPiece;   // 1 / 2: the last window ended inside a corridor / quiet run (of piece contPiece); + 4: it was
                                             // one run from end to end (a long run is worth trying)
-        bool contMoveEnd = false;
+        bool contMoveEnd = handMoveEnd;
         while (!ended) {
             if (nextEvent >= limit) break;
             // a window of 64 steps of the track starting AT the next event, one step per lane (stretches without events are
@@ -519,7 +570,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                     const double ell = (stride > 1) ? ((double)stride * PP_STEP_LEN() + 1e-6) : 0.0;
                     const double span = (stride > 1) ? 64.0 * ell : runSpan;
                     if (kind == 1) L = pp_corridor_run(rib, nrib, w, contPiece, contMoveEnd, q.x, q.y, stepOk, coverMask, 0, span, nsx, nsy, ell, ell / PP_SF64(rho));
-                    else L = pp_quiet_run(rib, nrib, w, q.x, q.y, stepOk, coverAny, 0, span, ell);
+                    else L = pp_quiet_run(rib, nrib, w, q.x, q.y, stepOk, coverAny, 0, span, ell, ell / PP_SF64(rho));
                     PP_TRACE("[wave]   continued run (kind %d, stride %d) from %d: L %d\n", kind, stride, base, L);
                     if (L > 0) {
                         if (kind == 1 && lane == contPiece) {
@@ -616,7 +667,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
             st->cct = cct; st->endTime = endTime; st->lastEv = lastEv; st->rdt = rdt; st->flags = flags | (infeasible ? PPGPU_F_INFEASIBLE : 0u);
             st->nrib = nrib;                                          // (same lane, program order: after the -1 above)
         }
-        if (lane < nrib) {
+        if (lane < nrib || lane < handCount) {        // (entries of the lane's split list beyond what is left of it: back to zero)
             double* c = p.child + ((size_t)eg * p.stride + lane) * 4;
             c[0] = rib.sx; c[1] = rib.sy; c[2] = rib.ex; c[3] = rib.ey;
         }
@@ -784,7 +835,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
     if (!throwsRef) {
         if (nrib > PP_TSP_MAX && lane == 0) atomicOr(p.need_big, 1u);
         if (nrib > p.stride && lane == 0) rec->flags = flags | PPGPU_F_RIBBON_OVF;   // after the record store above
-        if (lane < nrib && lane < p.stride) {
+        if ((lane < nrib || lane < handCount) && lane < p.stride) {     // (lanes beyond nrib hold zeros: what is left of the lane's split list goes)
             double* c = p.child + ((size_t)eg * p.stride + lane) * 4;
             c[0] = rib.sx; c[1] = rib.sy; c[2] = rib.ex; c[3] = rib.ey;
         }
@@ -887,7 +938,8 @@ __global__ __launch_bounds__(PP_FINISH_THREADS) void pp_k_cover_finish(PPParams 
     const ppgpu_vertex* V = p.verts + vi;
     const bool cov = (S->cbits & PPGPU_EDGE_COVERAGE) != 0;
     const double wStart = S->wStart, wEnd = S->wEnd, speed = S->speed, length = S->length, rho = S->rho, rho_inv = S->rho_inv, qx = S->qx, qy = S->qy;
-    const double hi0 = S->p0, hi1 = S->hi1;
+    const double hi0 = S->p0, hi1 = S->hi1, segP1 = S->p1;
+    const int dubWord = S->type;
     const double srcT = V->time;
     const double endTime0 = fmin(p.horizon + 1e-12 + p.sst, wEnd);    // Edge.cpp:90
     const double endTime = st.endTime;
@@ -934,9 +986,9 @@ __global__ __launch_bounds__(PP_FINISH_THREADS) void pp_k_cover_finish(PPParams 
     // ---- end state (:177-178) and the pose `intermediate` stopped on
     double ix = V->x, iy = V->y, uth;
     bool ignored = false, perr = false;
-    if (lastIdx >= 0) pp_lane_pose(S, tg[lastIdx], wStart, speed, length, rho, rho_inv, qx, qy, hi0, hi1, ix, iy, uth, ignored);
+    if (lastIdx >= 0) pp_lane_pose(S, tg[lastIdx], wStart, speed, length, rho, rho_inv, qx, qy, hi0, hi1, segP1, dubWord, ix, iy, uth, ignored);
     double endX, endY;
-    pp_lane_pose(S, endTime, wStart, speed, length, rho, rho_inv, qx, qy, hi0, hi1, endX, endY, uth, perr);
+    pp_lane_pose(S, endTime, wStart, speed, length, rho, rho_inv, qx, qy, hi0, hi1, segP1, dubWord, endX, endY, uth, perr);
     if (perr) flags |= PPGPU_F_DUBINS_ERR;
     const double endHeading = pp_heading_from_yaw(pp_mod2pi(uth));
     // ---- cover the last little bit (:182-191): RibbonManager::cover(x, y, strict) over the list in order

@@ -273,7 +273,7 @@ __device__ __forceinline__ void pp_plan_skips_chunk(const PPParams& p, const PPE
         // not skipped: if the chunk before this one is, the sweep takes `lastHeading` from here
         double ux, uy, uth;
         pp_setup_seg_pose(S, segP, tpP, ux, uy, uth);
-        p.track_carry[(size_t)e * p.nch + chunk] = pp_heading_from_yaw(pp_mod2pi(uth));
+        p.track_eq[(size_t)e * p.nch + chunk] = (unsigned long long)__double_as_longlong(pp_heading_from_yaw(pp_mod2pi(uth)));   // (the sweep replaces it by the chunk's bits)
     }
     }
 }
@@ -400,7 +400,7 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
     // Chunks of 64 steps that provably touch neither a blocked cell nor an obstacle are not sampled at all (pp_k_plan_skips decided
     // which, one thread per chunk); the others go through the per-step code below, one step per lane.
     const unsigned char* skipb = p.track_skip ? p.track_skip + (size_t)e * p.nch : nullptr;
-    const double* carry = p.track_carry + (size_t)e * p.nch;
+    const double* carry = reinterpret_cast<const double*>(p.track_eq + (size_t)e * p.nch);   // (a chunk's word before the sweep gets to it)
     bool afterSkip = false, stop = false;
     for (int g0 = 0; !stop; g0 += PP_WAVE) {
         const unsigned sbits = (skipb && g0 + lane < p.nch) ? (unsigned)skipb[g0 + lane] : 0u;

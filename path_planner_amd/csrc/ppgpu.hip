@@ -115,6 +115,7 @@ struct ppgpu_ctx {
     DevBuf<ppgpu_edge_result> tmp_results;
     DevBuf<double> tmp_child, tmp_lengths, tmp_len_out, int_child;
     bool quiet_finish = true;           // env PPGPU_QUIET_FINISH=0: every edge's phase C stays with its wave
+    bool lane_split = true;             // env PPGPU_LANE_SPLIT=0: the wave makes every split itself (tests compare the two)
     bool lane_finish = true;            // env PPGPU_LANE_FINISH=0: every wave of the cover sweep finishes its own edges (tests compare the two)
     bool lane_heuristic = true;         // env PPGPU_LANE_HEURISTIC=0: large launches keep the wave-per-edge enumeration too (tests compare the two)
     long long prepass_min_edges = PP_PREPASS_MIN_EDGES;   // env PPGPU_PREPASS_MIN_EDGES overrides (tests run the prepasses on small launches too)
@@ -126,7 +127,6 @@ struct ppgpu_ctx {
     DevBuf<PPTrackSummary> track_summary;
     DevBuf<int2> track_far;
     DevBuf<unsigned char> track_skip;
-    DevBuf<double> track_carry;
     DevBuf<unsigned> need_big;          // [0] need_big, [1 + n] number of deferred edges with n ribbons (pp_k_deferred_list)
     DevBuf<unsigned> defer_list, live_list, hw_list;
     DevBuf<PPCoverState> cover_state;
@@ -194,6 +194,7 @@ int ppgpu_create(int device, ppgpu_ctx** out) {
     if (const char* lh = std::getenv("PPGPU_LANE_HEURISTIC")) c->lane_heuristic = std::atoi(lh) != 0;
     if (const char* qf = std::getenv("PPGPU_QUIET_FINISH")) c->quiet_finish = std::atoi(qf) != 0;
     if (const char* lf = std::getenv("PPGPU_LANE_FINISH")) c->lane_finish = std::atoi(lf) != 0;
+    if (const char* ls = std::getenv("PPGPU_LANE_SPLIT")) c->lane_split = std::atoi(ls) != 0;
     if (const char* sb = std::getenv("PPGPU_SLICE_BYTES")) {
         const long long v = std::atoll(sb);
         if (v > 0) c->slice_bytes = (size_t)v;
@@ -215,7 +216,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->ord_blockmin.release(); c->ord_blockcnt.release(); c->ord_bound.release(); c->ord_count.release();
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     c->setup.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
-    c->track_summary.release(); c->track_far.release(); c->track_skip.release(); c->track_carry.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->defer_list.release(); c->live_list.release(); c->hw_list.release(); c->cover_state.release(); c->work.release(); c->dstage_in.release(); c->dstage_out.release();
+    c->track_summary.release(); c->track_far.release(); c->track_skip.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->defer_list.release(); c->live_list.release(); c->hw_list.release(); c->cover_state.release(); c->work.release(); c->dstage_in.release(); c->dstage_out.release();
     if (c->pinned_counts) (void)hipHostFree(c->pinned_counts);
     if (c->stage_in) (void)hipHostFree(c->stage_in);
     if (c->stage_out) (void)hipHostFree(c->stage_out);
@@ -697,7 +698,7 @@ static void fill_params(ppgpu_ctx* c, PPParams& p) {
     p.cpf = g.collision_penalty_factor; p.tpf = g.time_penalty_factor;
     p.heuristic = g.heuristic; p.tsp_k = g.tsp_k; p.h_rho = g.heuristic_turning_radius;
     p.fuse_h = 0;
-    p.defer_h = 0; p.defer_list = nullptr; p.defer_count = nullptr; p.quiet_finish = 0; p.live_list = nullptr; p.live_count = nullptr; p.cover_state = nullptr; p.hw_list = nullptr; p.hw_count = nullptr;
+    p.lane_split = 0; p.defer_h = 0; p.defer_list = nullptr; p.defer_count = nullptr; p.quiet_finish = 0; p.live_list = nullptr; p.live_count = nullptr; p.cover_state = nullptr; p.hw_list = nullptr; p.hw_count = nullptr;
     p.grid = PPGrid{c->grid.p, c->rows, c->cols, c->wpr, c->res, c->res > 0 ? 1.0 / c->res : 0.0, c->rows > 0 ? c->grid_clear.p : nullptr};
     p.obst = c->obst.p; p.n_obst = c->n_obst; p.obst_model = c->obst_model;
     p.verts = c->verts.p; p.ribbons = c->ribbons.p; p.tgrid = c->tgrid.p; p.ng = c->ng; p.nverts = c->nverts;
@@ -848,7 +849,7 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
             (rc = c->track_eq.reserve(ws * p.nch, false, c->stream)) ||
             (rc = c->track_chunk_hits.reserve(ws * p.nch, false, c->stream)) ||
             (rc = c->track_summary.reserve(ws, false, c->stream)) || (rc = c->track_far.reserve(ws, false, c->stream)) ||
-            (rc = c->track_skip.reserve(ws * p.nch, false, c->stream)) || (rc = c->track_carry.reserve(ws * p.nch, false, c->stream)))
+            (rc = c->track_skip.reserve(ws * p.nch, false, c->stream)))
             return rc;
         if (p.n_obst > 0 && p.obst_model == PPGPU_OBST_GAUSSIAN &&
             ((rc = c->track_pen.reserve(ws * p.ngp, false, c->stream)) || (rc = c->track_chunk_pen.reserve(ws * p.nch, false, c->stream))))
@@ -860,7 +861,6 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     // both prepasses pay for themselves on large launches only: a planner round trip of a few hundred edges is latency-bound
     const bool big = total >= c->prepass_min_edges;
     p.track_skip = (big && !p.wedges && (c->rows == 0 || c->grid_clear.p) && p.ng >= PP_WAVE) ? c->track_skip.p : nullptr;
-    p.track_carry = c->track_carry.p;
     if (!big) p.track_far = nullptr;
     p.track_pen = c->track_pen.p; p.track_chunk_pen = c->track_chunk_pen.p;
     {
@@ -876,6 +876,7 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     p.defer_h = (p.fuse_h && big && PP_LANE_HEUR && c->lane_heuristic && total < (1ll << 32) &&
                  (p.heuristic == PPGPU_H_TSP_POINT_ALL || p.heuristic == PPGPU_H_TSP_POINT_K)) ? 1 : 0;
     p.quiet_finish = (p.track_far && c->quiet_finish) ? 1 : 0;
+    p.lane_split = (p.track_far && c->lane_split && !gaussianSweep) ? 1 : 0;
     if (p.track_far && total < (1ll << 32)) {
         int rc = c->live_list.reserve((size_t)slice * 2, false, c->stream);
         if (rc) return rc;

@@ -335,6 +335,57 @@ def test_lane_finish_is_the_wave_finish(torch_cuda, monkeypatch, heur):
     print(heur, "child ribbon counts (second world)", np.bincount(nr))
 
 
+def test_lane_split_is_the_wave_split(torch_cuda, monkeypatch):
+    """Large launches: the approach lane splits the one ribbon an edge enters itself and hands the wave the new list (in the edge's
+    child slot) with the corridor run already guessed, in long-run mode from its first window (round 4).  PPGPU_LANE_SPLIT=0 leaves
+    every split to the wave as before.  Same flags, ribbon counts and step counts; floating fields within the parity tolerance
+    (the two routes cut the same corridor crossing into different runs, whose moved endpoints agree to rounding) — on config 3
+    and on a world whose edges cross several ribbons — and both against the oracle."""
+    from path_planner_amd import api, workloads
+    from path_planner_amd.types import make_config, edge_pack
+    from path_planner_amd.workloads import root_vertex
+    import oracle as orc
+    from parity import compare_results
+    w = workloads.config3(n_samples=4096)
+    rng = np.random.default_rng(78)
+    cfg2 = make_config(start_state_time=2.0, heuristic=w.cfg.heuristic, tsp_k=w.cfg.tsp_k)
+    rib2 = np.asarray([[40 + 9 * i, 50 + 5 * (i % 3), 44 + 9 * i + 3 * (i % 2), 96 - 4 * (i % 4)] for i in range(4)], dtype=np.float64)
+    root2 = root_vertex(70.0, 30.0, 0.3, 2.5, 2.0, rib2)
+    n2 = 3000
+    sx, sy, sh = rng.uniform(20, 130, n2), rng.uniform(20, 130, n2), rng.uniform(0, 2 * np.pi, n2)
+    outs = []
+    for lanes in ("1", "0"):
+        monkeypatch.setenv("PPGPU_LANE_SPLIT", lanes)
+        monkeypatch.delenv("PPGPU_PREPASS_MIN_EDGES", raising=False)      # the production route of large launches
+        ctx = api.Context(0)
+        ctx.set_config(w.cfg); ctx.set_grid(w.grid, w.res); ctx.set_obstacles(w.obst); ctx.set_vertices(w.root(), w.ribbons4)
+        ctx.sampler_init(w.bounds6, w.seed, w.ribbons4)
+        n = ctx.sampler_add(w.n_samples)
+        a = _dense(torch_cuda, ctx, 1, n, 0xF, stride=10)
+        samples = ctx.get_samples()
+        ctx2 = api.Context(0)
+        ctx2.set_config(cfg2); ctx2.set_grid(None, 0.5); ctx2.set_obstacles(None); ctx2.set_vertices(root2, rib2)
+        ctx2.set_samples(sx, sy, sh)
+        b = _dense(torch_cuda, ctx2, 1, n2, 0xF, stride=10)
+        outs.append((a, b))
+    for k in range(2):
+        rep = compare_results(outs[0][k][0], outs[1][k][0], outs[0][k][1], outs[1][k][1])
+        print("lane split vs wave split, world", k, {x: rep[x] for x in ("n", "flags_equal", "n_info_mismatch", "worst_rel")})
+        assert rep["ok"], rep
+    # and the lane-split route against the oracle
+    world = orc.World(w.cfg, w.grid, w.res, w.obst)
+    ne = 4 * n
+    e = edge_pack(np.zeros(ne, dtype=np.uint64), np.repeat(np.arange(n), 4), np.tile(np.arange(4), n))
+    cpu, cchild = world.cost_edges(w.root(), w.ribbons4, samples[:, 0], samples[:, 1], samples[:, 2], e, stride=10, threads=8)
+    rep = compare_results(outs[0][0][0], cpu, outs[0][0][1], cchild)
+    assert rep["ok"], rep
+    world2 = orc.World(cfg2, None, 0.5, None)
+    e2 = edge_pack(np.zeros(4 * n2, dtype=np.uint64), np.repeat(np.arange(n2), 4), np.tile(np.arange(4), n2))
+    cpu2, cchild2 = world2.cost_edges(root2, rib2, sx, sy, sh, e2, stride=10, threads=8)
+    rep2 = compare_results(outs[0][1][0], cpu2, outs[0][1][1], cchild2)
+    assert rep2["ok"], rep2
+
+
 def test_sampler_largest_batch_and_tile_edges(torch_cuda):
     """The sampler's scans work in tiles (2 048 stream slots, 256 candidates per workgroup) and every workgroup adds up the tiles
     before it for itself: the largest batch one call takes (524 288 attempts: 1 536 slot tiles, 2 048 candidate workgroups), a batch
