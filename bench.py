@@ -184,13 +184,15 @@ def run_rank(args):
     d_key2 = torch.zeros(2, dtype=torch.int64, device=dev)
     kernel_events = []
 
-    def step(out=None):
-        out = d_res if out is None else out
+    def step_sample():
         ctx.sampler_init(w.bounds6, w.seed, w.ribbons4)
         lo, hi = sharding.shard_attempts(total_attempts, emu_rank, emu_world)   # this rank's slice of the iteration's batch
         if lo:
             ctx.sampler_skip(lo)
-        n = ctx.sampler_add(hi - lo)
+        return ctx.sampler_add(hi - lo)          # (the step's one host wait: the kept-sample count)
+
+    def step_cost(n, out=None):
+        out = d_res if out is None else out
         ne = 4 * n
         ctx.cost_edges_dense(0, 1, 0, n, 0xF, out.data_ptr())
         ctx.best_edge(ne, out.data_ptr(), d_key2.data_ptr(), goal_only=False, base=sharding.edge_index_base(emu_rank, max_edges))
@@ -204,6 +206,9 @@ def run_rank(args):
         elif use_comm:
             ctx.allreduce_best(d_key2.data_ptr())     # the one collective of the iteration: 16 B per rank over xGMI + local min
         return ne
+
+    def step(out=None):
+        return step_cost(step_sample(), out)
 
     def fence():
         if world > 1 or use_comm:
@@ -283,6 +288,48 @@ def run_rank(args):
     fence()
     if rank == 0:
         e2e_pipe_ms = 1e3 * (time.perf_counter() - t0) / n_e2e
+    # ... and with the copy of step i on an SDMA engine (ppgpu_copy_engine_read: hsa_amd_memory_async_copy) while step i + 1 runs.
+    # The hipMemcpyAsync of the two loops above runs as a blit KERNEL (__amd_rocclr_copyBuffer) whatever the SDMA settings say:
+    # tools/copy_engine_ab.sh, profiles/r04_copy_engine.txt.
+    e2e_sdma_ms, e2e_sdma_err = None, None
+    fence()
+    t0 = time.perf_counter()
+    for i in range(n_e2e):
+        if rank == 0 and e2e_sdma_err is None:
+            try:
+                b = i & 1
+                n_kept = step_sample()                       # (its host wait also means: the records of step i - 1 are complete)
+                # the bulk copy of step i - 1 is issued AFTER this step's small count read-back, not before: issued first it kept that
+                # read-back waiting behind 30 MB on the engine, and the step with it (2.53 ms per step that way)
+                if i > 0:
+                    ctx.copy_engine_read(hbufs[1 - b].data_ptr(), bufs[1 - b].data_ptr(), ne * RESULT_DTYPE.itemsize)
+                ne = step_cost(n_kept, bufs[b])
+            except Exception as e:                           # the bench line must not depend on this leg
+                e2e_sdma_err = repr(e)
+        else:
+            step()
+    if rank == 0 and e2e_sdma_err is None:
+        try:
+            ctx.synchronize()
+            ctx.copy_engine_read(hbufs[(n_e2e - 1) & 1].data_ptr(), bufs[(n_e2e - 1) & 1].data_ptr(), ne * RESULT_DTYPE.itemsize)   # the last step's records
+            ctx.copy_engine_wait()
+        except Exception as e:
+            e2e_sdma_err = repr(e)
+    fence()
+    copy_alone_ms = None
+    if rank == 0 and e2e_sdma_err is None:
+        e2e_sdma_ms = 1e3 * (time.perf_counter() - t0) / n_e2e
+        e2e_sdma_ok = bool(torch.equal(hbufs[(n_e2e - 1) & 1][: ne * RESULT_DTYPE.itemsize], bufs[(n_e2e - 1) & 1][: ne * RESULT_DTYPE.itemsize].cpu()))   # (after the clock)
+        # the two copies on their own (nothing else on the device): the blit kernel and the SDMA engine
+        nb = ne * RESULT_DTYPE.itemsize
+        tt = []
+        for _ in range(3):
+            t1 = time.perf_counter(); hbufs[0][:nb].copy_(bufs[0][:nb], non_blocking=True); stream.synchronize(); tt.append(time.perf_counter() - t1)
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter(); ctx.copy_engine_read(hbufs[0].data_ptr(), bufs[0].data_ptr(), nb); ctx.copy_engine_wait(); ts.append(time.perf_counter() - t1)
+        copy_alone_ms = {"bytes": nb, "hipMemcpyAsync_blit_kernel_ms": 1e3 * min(tt), "copy_engine_sdma_ms": 1e3 * min(ts),
+                         "GBps": {"blit": nb / min(tt) / 1e9, "sdma": nb / min(ts) / 1e9}}
 
     if rank == 0:
         solve_ms, pose_ms, cover_ms, heur_ms = [float(x) for x in np.mean(np.array(kernel_events), axis=0)]
@@ -348,9 +395,13 @@ def run_rank(args):
             "ms_per_step_p99": float(np.percentile(step_ms, 99)),
             "e2e_ms_per_step": e2e_ms,
             "e2e_pipelined_ms_per_step": e2e_pipe_ms,
+            "e2e_copy_engine_ms_per_step": e2e_sdma_ms,
+            "records_copy_alone": copy_alone_ms,
+            **({"e2e_copy_engine_error": e2e_sdma_err} if e2e_sdma_err else {"e2e_copy_engine_bytes_verified": e2e_sdma_ok}),
             "e2e_note": f"rank 0, {n_e2e} further steps after the timed region, each followed by the D2H copy of its records "
                         f"({n_edges_launch * RESULT_DTYPE.itemsize / 1e6:.1f} MB) into pinned host memory; pipelined: the copy of step i on a second stream "
-                        f"while step i + 1 runs (two record buffers); never part of value",
+                        f"while step i + 1 runs (two record buffers) - hipMemcpyAsync runs as a blit kernel on the CUs here; copy_engine: the same "
+                        f"overlap with the copy on an SDMA engine (ppgpu_copy_engine_read); never part of value",
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,

@@ -201,6 +201,13 @@ int ppgpu_last_cover_edges(ppgpu_ctx* ctx, int64_t* n_edges);
 int ppgpu_device_alloc(ppgpu_ctx* ctx, uint64_t bytes, void** d_out);
 int ppgpu_device_free(ppgpu_ctx* ctx, void* d_ptr);
 int ppgpu_device_read(ppgpu_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes);
+/* The records' way home while the next batch is being costed (SURVEY.md 8 e: "overlap D2H with the next batch"): an asynchronous
+ * device-to-host copy on an SDMA engine (hsa_amd_memory_async_copy) instead of on the CUs — hipMemcpyAsync into pinned memory runs
+ * as a blit kernel on this stack and takes wave slots from the fp64-bound costing kernels.  The caller makes sure the source is
+ * complete (ppgpu_synchronize) and that h_pinned_dst is pinned host memory (hipHostMalloc, torch pin_memory).  One copy in flight
+ * per handle: a second call first waits for the first; ppgpu_copy_engine_wait blocks until the copy has landed. */
+int ppgpu_copy_engine_read(ppgpu_ctx* ctx, void* h_pinned_dst, const void* d_src, uint64_t bytes);
+int ppgpu_copy_engine_wait(ppgpu_ctx* ctx);
 
 /* ---------------------------------------------------------------- world state */
 

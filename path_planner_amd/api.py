@@ -42,6 +42,8 @@ def _load():
         "ppgpu_device_alloc": (C.c_int, [vp, u64, C.POINTER(vp)]),
         "ppgpu_device_free": (C.c_int, [vp, vp]),
         "ppgpu_device_read": (C.c_int, [vp, vp, vp, u64]),
+        "ppgpu_copy_engine_read": (C.c_int, [vp, vp, vp, u64]),
+        "ppgpu_copy_engine_wait": (C.c_int, [vp]),
         "ppgpu_heuristic_host": (C.c_int, [vp, i32, vp, vp, vp, vp, vp]),
         "ppgpu_expand_capacity": (C.c_int64, [i32, i32]),
         "ppgpu_expand_host": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, C.POINTER(C.c_int64), vp, vp, vp, i32]),
@@ -200,6 +202,12 @@ class Context:
         tot = C.c_int64()
         self._ck(LIB.ppgpu_sampler_add(self._h, int(n_attempts), C.byref(tot)), "ppgpu_sampler_add")
         return tot.value
+
+    def copy_engine_read(self, h_pinned_ptr, d_ptr, nbytes):
+        self._ck(LIB.ppgpu_copy_engine_read(self._h, int(h_pinned_ptr), int(d_ptr), int(nbytes)), "ppgpu_copy_engine_read")
+
+    def copy_engine_wait(self):
+        self._ck(LIB.ppgpu_copy_engine_wait(self._h), "ppgpu_copy_engine_wait")
 
     def growth_stats(self):
         n, sec = C.c_uint64(), C.c_double()

@@ -158,6 +158,9 @@ struct ppgpu_ctx {
     void* stage_out = nullptr; size_t stage_out_cap = 0;
     DevBuf<unsigned long long> gather;
     void* comm = nullptr;               // ncclComm_t owned by the handle (ppgpu_comm_init_rank / ppgpu_comm_init_all)
+    // ppgpu_copy_engine_read: the HSA agents of this device and of the host, the completion signal of the copy in flight
+    unsigned long long hsa_gpu = 0, hsa_cpu = 0, hsa_signal = 0;
+    bool copy_pending = false;
 };
 
 static int require_cfg(ppgpu_ctx* c) {
@@ -165,6 +168,9 @@ static int require_cfg(ppgpu_ctx* c) {
     if (!c->have_cfg) return fail(PPGPU_ESTATE, "ppgpu_set_config must be called first");
     return PPGPU_OK;
 }
+
+static void ppgpu_copy_engine_release(ppgpu_ctx* c);      // (further down, with the HSA entry points)
+extern "C" int ppgpu_copy_engine_wait(ppgpu_ctx* c);
 
 extern "C" {
 
@@ -208,6 +214,8 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)ppgpu_comm_destroy(c);
+    if (c->copy_pending) (void)ppgpu_copy_engine_wait(c);
+    ppgpu_copy_engine_release(c);
     c->grid.release(); c->grid_clear.release(); c->grid_rowclear.release(); c->obst.release(); c->verts.release(); c->ribbons.release(); c->tgrid.release();
     c->sx.release(); c->sy.release(); c->sh.release(); c->samp_ribbons.release(); c->samp_pos.release();
     c->s_bytes.release(); c->s_u64.release(); c->s_u32a.release(); c->s_u32b.release(); c->s_cand.release();
@@ -1422,6 +1430,103 @@ extern "C" int ppgpu_comm_abort(ppgpu_ctx* c) {
     c->comm = nullptr;
     const int rc = r.comm_abort ? r.comm_abort(comm) : r.comm_destroy(comm);
     if (rc != 0) return rccl_fail(r, "ncclCommAbort", rc);
+    return PPGPU_OK;
+}
+
+// ------------------------------------------------------------------------------ records home on a copy engine
+// hipMemcpyAsync from device memory into pinned host memory runs as a blit KERNEL on this stack (__amd_rocclr_copyBuffer in every
+// rocprofv3 kernel trace of bench.py's end-to-end loops, with HSA_ENABLE_SDMA=1 and with GPU_BLIT_ENGINE_TYPE=2 alike): 30 MB of
+// records take 0.62 ms of wave slots beside fp64-bound kernels.  hsa_amd_memory_async_copy puts the same copy on an SDMA engine.  The
+// HSA runtime is the one HIP itself runs on (same soname: the loader hands back the instance already in the process).
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+namespace {
+struct HsaApi {
+    decltype(&hsa_iterate_agents) iterate_agents = nullptr;
+    decltype(&hsa_agent_get_info) agent_get_info = nullptr;
+    decltype(&hsa_signal_create) signal_create = nullptr;
+    decltype(&hsa_signal_destroy) signal_destroy = nullptr;
+    decltype(&hsa_signal_store_relaxed) signal_store_relaxed = nullptr;
+    decltype(&hsa_signal_wait_scacquire) signal_wait_scacquire = nullptr;
+    decltype(&hsa_amd_memory_async_copy) memory_async_copy = nullptr;
+    std::string error;
+    bool ok = false;
+};
+const HsaApi& hsa_api() {
+    static HsaApi a;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* lib = dlopen("libhsa-runtime64.so.1", RTLD_NOW);
+        if (!lib) lib = dlopen("libhsa-runtime64.so", RTLD_NOW);
+        if (!lib) { a.error = std::string("cannot load libhsa-runtime64.so.1: ") + dlerror(); return; }
+        a.iterate_agents = (decltype(a.iterate_agents))dlsym(lib, "hsa_iterate_agents");
+        a.agent_get_info = (decltype(a.agent_get_info))dlsym(lib, "hsa_agent_get_info");
+        a.signal_create = (decltype(a.signal_create))dlsym(lib, "hsa_signal_create");
+        a.signal_destroy = (decltype(a.signal_destroy))dlsym(lib, "hsa_signal_destroy");
+        a.signal_store_relaxed = (decltype(a.signal_store_relaxed))dlsym(lib, "hsa_signal_store_relaxed");
+        a.signal_wait_scacquire = (decltype(a.signal_wait_scacquire))dlsym(lib, "hsa_signal_wait_scacquire");
+        a.memory_async_copy = (decltype(a.memory_async_copy))dlsym(lib, "hsa_amd_memory_async_copy");
+        if (!a.iterate_agents || !a.agent_get_info || !a.signal_create || !a.signal_destroy || !a.signal_store_relaxed || !a.signal_wait_scacquire || !a.memory_async_copy) {
+            a.error = "libhsa-runtime64 lacks one of the entry points ppgpu_copy_engine_read needs";
+            return;
+        }
+        a.ok = true;
+    });
+    return a;
+}
+struct AgentScan { const HsaApi* api; int want_gpu; int seen_gpu; hsa_agent_t gpu, cpu; bool have_gpu, have_cpu; };
+hsa_status_t scan_agent(hsa_agent_t agent, void* data) {
+    AgentScan* s = (AgentScan*)data;
+    hsa_device_type_t type;
+    if (s->api->agent_get_info(agent, HSA_AGENT_INFO_DEVICE, &type) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    if (type == HSA_DEVICE_TYPE_CPU && !s->have_cpu) { s->cpu = agent; s->have_cpu = true; }
+    if (type == HSA_DEVICE_TYPE_GPU) {
+        if (s->seen_gpu == s->want_gpu) { s->gpu = agent; s->have_gpu = true; }
+        s->seen_gpu++;
+    }
+    return HSA_STATUS_SUCCESS;
+}
+}  // namespace
+
+static void ppgpu_copy_engine_release(ppgpu_ctx* c) {
+    if (!c->hsa_signal) return;
+    hsa_signal_t sig; sig.handle = c->hsa_signal;
+    (void)hsa_api().signal_destroy(sig);
+    c->hsa_signal = 0;
+}
+
+extern "C" int ppgpu_copy_engine_wait(ppgpu_ctx* c) {
+    if (!c) return fail(PPGPU_EINVAL, "copy_engine_wait: null context");
+    if (!c->copy_pending) return PPGPU_OK;
+    const HsaApi& a = hsa_api();
+    hsa_signal_t sig; sig.handle = c->hsa_signal;
+    // (the signal starts at 1; the copy engine takes it to 0, or below on an error)
+    const hsa_signal_value_t v = a.signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
+    c->copy_pending = false;
+    if (v < 0) return fail(PPGPU_EHIP, "copy_engine_wait: the copy engine reported an error");
+    return PPGPU_OK;
+}
+
+extern "C" int ppgpu_copy_engine_read(ppgpu_ctx* c, void* h_pinned_dst, const void* d_src, uint64_t bytes) {
+    if (!c || !h_pinned_dst || !d_src || bytes == 0) return fail(PPGPU_EINVAL, "copy_engine_read: bad arguments");
+    const HsaApi& a = hsa_api();
+    if (!a.ok) return fail(PPGPU_EHIP, a.error);
+    int rc;
+    if (c->copy_pending && (rc = ppgpu_copy_engine_wait(c))) return rc;          // one copy in flight per handle
+    if (!c->hsa_signal) {
+        AgentScan s{&a, c->device, 0, {}, {}, false, false};
+        if (a.iterate_agents(scan_agent, &s) != HSA_STATUS_SUCCESS || !s.have_gpu || !s.have_cpu)
+            return fail(PPGPU_EHIP, "copy_engine_read: cannot find the HSA agents of device " + std::to_string(c->device) + " and of the host");
+        hsa_signal_t sig;
+        if (a.signal_create(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return fail(PPGPU_EHIP, "copy_engine_read: hsa_signal_create failed");
+        c->hsa_gpu = s.gpu.handle; c->hsa_cpu = s.cpu.handle; c->hsa_signal = sig.handle;
+    }
+    hsa_signal_t sig; sig.handle = c->hsa_signal;
+    hsa_agent_t gpu, cpu; gpu.handle = c->hsa_gpu; cpu.handle = c->hsa_cpu;
+    a.signal_store_relaxed(sig, 1);
+    const hsa_status_t st = a.memory_async_copy(h_pinned_dst, cpu, d_src, gpu, (size_t)bytes, 0, nullptr, sig);
+    if (st != HSA_STATUS_SUCCESS) return fail(PPGPU_EHIP, "copy_engine_read: hsa_amd_memory_async_copy failed (status " + std::to_string((int)st) + "): is the destination pinned host memory?");
+    c->copy_pending = true;
     return PPGPU_OK;
 }
 
