@@ -622,7 +622,7 @@ def plan_level(cycles, cpu_baseline=True):
                   "node_regrowths": r["node_regrowths"], "device_growths": r["device_growths"], "worst_cycle": r["worst_cycle"]}
         plan = {"seam": "Planner::plan (pp/src/planner/Planner.h:50-51): GpuAStarPlanner, one GPU",
                 "expansions_per_s": r["expansions_per_s_inside_plan"], "edges_per_s": r["edges_per_s_inside_plan"],
-                "note": "inside plan() the search is sequential: each round trip costs the <= 40 edges of up to 16 open vertices, so the plan-level "
+                "note": "inside plan() the search is sequential: each round trip costs the <= 40 edges of each of up to 64 open vertices (two round trips in flight), so the plan-level "
                         "edge rate is bound by round-trip latency, two orders of magnitude below the batch rate (`value`)"}
         if cpu_baseline:
             import numpy as np

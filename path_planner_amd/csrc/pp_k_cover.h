@@ -215,6 +215,11 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
     const PPEdgeSetupBody* S = p.setup + p.ws_base + (valid ? e : 0);
     int2 out; out.x = 0; out.y = 0;                 // {first event of the wave, (last event before it) + 1 | PP_FAR_* bits}
     int splitInfo = 0;
+#ifdef PP_DBG_PHASES               // tools/cover_phases.py: the lane's cycles before / inside / after its event loop, and its events
+    const long long apT0 = (long long)__builtin_readcyclecounter();
+    long long apT1 = apT0, apT2 = apT0;
+    int apEvents = 0;
+#endif
     const unsigned sflags = S->sflags;
     const int dubType = S->type;
     // do all lanes of this wave start from the same open vertex?
@@ -251,10 +256,16 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
             int nearBudget = PP_LANE_NEAR_MAX;
             const bool covEdge = (S->cbits & PPGPU_EDGE_COVERAGE) != 0;
             // a piece short enough to be erased makes every event a real one (Ribbon::covered is checked wherever the vehicle is)
+#ifdef PP_DBG_PHASES
+            apT1 = (long long)__builtin_readcyclecounter();
+#endif
             while (!tiny) {
                 if (k >= limit) break;
                 const double t = tg[k];
                 if (!(t < endTime0)) break;
+#ifdef PP_DBG_PHASES
+                apEvents++;
+#endif
                 double dist = (t - wStart) * speed;                                     // DubinsWrapper.cpp:36
                 if (dist < 0 || dist > length) dist = dist - 1e-5;                      // EDUBPARAM retry, :39-42
                 if (dist < 0 || dist > length) { handOver = true; break; }              // the wavefront's code flags the error
@@ -336,12 +347,26 @@ __global__ __launch_bounds__(PP_APPROACH_THREADS, PP_APPROACH_MIN_WAVES) void pp
                 k = k + pp_event_stride(D, p.inc_d, p.inv_inc_d, p.ng) + 1;
             }
             out.x = k; out.y = (lastEv + 1) | splitInfo;
+#ifdef PP_DBG_PHASES
+            apT2 = (long long)__builtin_readcyclecounter();
+#endif
             if (!handOver && k >= limit && p.quiet_finish &&
                 pp_finish_quiet_edge(p, S, V, p.ws_base + e, pp_edge_position(p, p.e_base + e), limit, lastEv, oneVertex ? rpU : rp, tg, s_rec + (size_t)threadIdx.x * PP_REC_STRIDE, oneVertex))
                 out.x = PP_FAR_DONE;
         }
     }
     if (valid) p.track_far[p.ws_base + e] = out;
+#ifdef PP_DBG_PHASES
+    {
+        const long long apT3 = (long long)__builtin_readcyclecounter();
+        const double wPro = pp_wave_max((double)(apT1 - apT0)), wLoop = pp_wave_max((double)(apT2 - apT1)), wFin = pp_wave_max((double)(apT3 - apT2));
+        const double wEv = pp_wave_max((double)apEvents);
+        if (valid && out.x == PP_FAR_DONE) {
+            double* st = s_rec + (size_t)threadIdx.x * PP_REC_STRIDE;
+            st[12] = wPro; st[13] = wLoop * 4294967296.0 + (double)(apT2 - apT1); st[14] = -1.0 - wFin; st[15] = wEv * 1e6 + (double)apEvents;
+        }
+    }
+#endif
     {
         // the records of this wave's quiet edges, from LDS: lanes 16g .. 16g+15 store the 16 doubles of record 4 it + g
         const int lane = threadIdx.x & 63, wbase = (int)threadIdx.x - lane;
@@ -452,6 +477,14 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
 #else
 #define PP_CNT(x)
 #endif
+#ifdef PP_DBG_PHASES               // (with PP_DBG_COUNTS) shader cycles per part of the event loop instead of the counts, tools/cover_phases.py
+    long long phWin = 0, phCont = 0, phGen = 0, phRun = 0, phLoop = 0, phT = 0;
+#define PP_PH_START() (phT = (long long)__builtin_readcyclecounter())
+#define PP_PH_END(acc) (acc += (long long)__builtin_readcyclecounter() - phT)
+#else
+#define PP_PH_START()
+#define PP_PH_END(acc)
+#endif
 #ifdef PP_DBG_TRACE
 #define PP_TRACE(...) do { if (eg == (long long)(PP_DBG_TRACE) && lane == 0) printf(__VA_ARGS__); } while (0)
 #else
@@ -503,6 +536,9 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
 
     // ---- phase B: coverage events among steps [0, limit)
     if (!throwsRef) {
+#ifdef PP_DBG_PHASES
+        const long long phLoop0 = (long long)__builtin_readcyclecounter();
+#endif
         bool ended = false;
         int cont = handCont, contPiece = handPiece;   // 1 / 2: the last window ended inside a corridor / quiet run (of piece contPiece); + 4: it was
                                             // one run from end to end (a long run is worth trying)
@@ -516,6 +552,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
             const int stride = ((cont & 4) != 0 && longStride > 1 && base + 2 * longStride < limit) ? longStride : 1;
             PP_TRACE("[wave] window at %d stride %d (limit %d, lastEv %d, nrib %d)\n", base, stride, limit, lastEv, nrib);
             PP_CNT(dbgWindows++);
+            PP_PH_START();
             const int k = base + lane * stride;
             const double t = (k < p.ng) ? tg[k] : INFINITY;
             // the poses of the window, recomputed with the pose sweep's own arithmetic (pp_window_pose)
@@ -552,6 +589,7 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
             const int climit = (stride == 1) ? ((limit - base) < PP_WAVE ? (limit - base) : PP_WAVE) : __popcll(__ballot(k < limit));
             bool runFailed = false, quietFailed = false;
             bool tryQuiet = false;              // a corridor run has just ended inside this window
+            PP_PH_END(phWin);
             while (true) {
                 const int j = nextEvent - base;
                 if (j >= climit) break;
@@ -567,11 +605,13 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                     const int kind = cont & 3;
                     PP_CNT(if (kind == 1) dbgCorr++; else dbgQuiet++);
                     // a long run: margins of the travel between two samples
+                    PP_PH_START();
                     const double ell = (stride > 1) ? ((double)stride * PP_STEP_LEN() + 1e-6) : 0.0;
                     const double span = (stride > 1) ? 64.0 * ell : runSpan;
                     if (kind == 1) L = pp_corridor_run(rib, nrib, w, contPiece, contMoveEnd, q.x, q.y, stepOk, coverMask, 0, span, nsx, nsy, ell, ell / PP_SF64(rho));
                     else L = pp_quiet_run(rib, nrib, w, q.x, q.y, stepOk, coverAny, 0, span, ell, ell / PP_SF64(rho));
                     PP_TRACE("[wave]   continued run (kind %d, stride %d) from %d: L %d\n", kind, stride, base, L);
+                    PP_PH_END(phCont);
                     if (L > 0) {
                         if (kind == 1 && lane == contPiece) {
                             if (contMoveEnd) { rib.ex = nsx; rib.ey = nsy; } else { rib.sx = nsx; rib.sy = nsy; }
@@ -597,7 +637,9 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                 double D;                                             // Edge.cpp:158-161
                 int adv;
                 PP_CNT(dbgGeneric++);
+                PP_PH_START();
                 nrib = pp_ribbons_event(rib, nrib, w, xj, yj, ((coverMask >> j) & 1ull) != 0ull, lds, D, adv);
+                PP_PH_END(phGen);
                 PP_CNT(if (adv == -3) dbgFar++; else if (adv == -2) dbgNoChange++; else if (adv >= 0) dbgInPlace++);
                 PP_TRACE("[wave]   event %d: adv %d D %.17g nrib %d cover %d x %.17g y %.17g\n", base + j, adv, D, nrib, (int)((coverMask >> j) & 1ull), xj, yj);
                 if (nrib > PP_WAVE) { nrib = PP_WAVE; flags |= PPGPU_F_RIBBON_OVF | PPGPU_F_RIBBON_LOST; }
@@ -619,7 +661,9 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                     double nsx, nsy;
                     const bool moveEnd = (adv & 0x100) != 0;
                     const int piece = adv & 0xff;
+                    PP_PH_START();
                     const int L = pp_corridor_run(rib, nrib, w, piece, moveEnd, q.x, q.y, (lane < climit) & (t < endTime), coverMask, j + 1, runSpan, nsx, nsy);
+                    PP_PH_END(phRun);
                     PP_CNT(dbgCorr++; dbgCorrLen += L);
                     runFailed = (L == 0) && !guessed;      // do not keep paying for attempts that do not start
                     PP_TRACE("[wave]   corridor run from %d: L %d\n", base + j + 1, L);
@@ -636,7 +680,9 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                 }
                 else if (adv == -2 && D == 0 && nrib > 0 && j + 1 < climit && !quietFailed) {
                     // inside a corridor, nothing changed: the following steps are very likely the same kind of event
+                    PP_PH_START();
                     const int L = pp_quiet_run(rib, nrib, w, q.x, q.y, (lane < climit) & (t < endTime), coverMask, j + 1, runSpan);
+                    PP_PH_END(phRun);
                     PP_CNT(dbgQuiet++; dbgQuietLen += L);
                     PP_TRACE("[wave]   quiet run from %d: L %d\n", base + j + 1, L);
                     quietFailed = (L == 0);
@@ -658,6 +704,9 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
                 nextEvent = base + j + m + 1;
             }
         }
+#ifdef PP_DBG_PHASES
+        phLoop = (long long)__builtin_readcyclecounter() - phLoop0;
+#endif
     }
 
     // ---- the rest is scalar work per edge: pp_k_cover_finish does it with one lane per edge, from what this wave knows now
@@ -817,7 +866,12 @@ __device__ __forceinline__ void pp_cover_sweep_edge(const PPParams& p, const lon
             case 9: v = g; break;
             case 10: v = h; break;
             case 11: v = g + h; break;
-#ifdef PP_DBG_COUNTS
+#if defined(PP_DBG_PHASES)
+            case 12: v = (double)phLoop; break;
+            case 13: v = (double)phWin * 4294967296.0 + (double)phGen; break;
+            case 14: v = (double)phCont; break;
+            default: v = (double)phRun; break;
+#elif defined(PP_DBG_COUNTS)
             case 12: v = (double)dbgRestFar * 1e9 + (double)dbgFar * 1e6 + (double)dbgNoChange * 1e3 + (double)dbgInPlace; break;
             case 13: v = (double)dbgWindows * 1e6 + (double)dbgGeneric; break;
             case 14: v = (double)dbgCorr * 1e6 + (double)dbgCorrLen; break;

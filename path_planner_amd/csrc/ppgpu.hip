@@ -28,8 +28,8 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
             return fail(PPGPU_EHIP, std::string(#call) + ": " + hipGetErrorString(_e));            \
     } while (0)
 
-// Workspace of one costing slice: PPEdgeSetup + what the pose sweep leaves for the cover sweep, (384 + 2 * ngp + 12 * nch + 16)
-// bytes per edge (~3.7 KB per edge for a 1 500-step horizon: 0.9 GB for the 236 140 edges of the bench step; the Gaussian
+// Workspace of one costing slice: PPEdgeSetup + what the pose sweep leaves for the cover sweep, (256 + 2 * ngp + 12 * nch + 16)
+// bytes per edge (~3.6 KB per edge for a 1 500-step horizon: 0.9 GB for the 236 140 edges of the bench step; the Gaussian
 // obstacle model adds 8 bytes per step).  A launch whose workspace
 // would exceed PP_SLICE_BYTES runs as consecutive slices.  (Running slice i's cover sweep next to slice i+1's pose sweep
 // on a second stream was measured and gains nothing: both sweeps are bound by fp64 VALU issue.)

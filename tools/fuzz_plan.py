@@ -30,6 +30,7 @@ from path_planner_amd import workloads
 from path_planner_amd.types import make_config, H_MAX_DISTANCE, H_TSP_POINT_ALL, H_TSP_POINT_K
 from test_gpu_host_planner import _write_map, _scenario, _run_cli, _compare, CLI
 import oracle as orc
+DEVICES = [int(x) for x in os.environ["FUZZ_DEVICES"].split()] if os.environ.get("FUZZ_DEVICES") else None   # e.g. "0 0": two contexts (round trips in flight) on device 0
 
 
 def judge(host, st, plan):
@@ -57,7 +58,7 @@ def judge(host, st, plan):
 def edge_dumps(w, sc, mp, t0, dt, calls, init, world, prev=None, start=None):
     """Every costed edge each search consumes, in consumption order, 16 numbers per edge: source state (5), Dubins parameters
     (3), word, radius, coverage flag, infeasible, true cost, g, h, end time.  Host: PPAMD_DUMP_EDGES; oracle: dump_edges."""
-    _scenario(w, sc, mp, t0, dt, calls, init, speculation=1, prev=prev, start=start)
+    _scenario(w, sc, mp, t0, dt, calls, init, speculation=1, prev=prev, start=start, devices=DEVICES)
     dump = sc + ".edges"
     subprocess.run([CLI, sc], capture_output=True, text=True, timeout=300, env=dict(os.environ, PPAMD_DUMP_EDGES=dump))
     H = np.loadtxt(dump).reshape(-1, 16)
@@ -202,7 +203,7 @@ def one_round(rng, rid, d, verbose=True):
     out = []
 
     def run(which, t_start, prev, start):
-        _scenario(w, sc, mp, t_start, dt, calls, init, speculation=spec, prev=prev, start=start)
+        _scenario(w, sc, mp, t_start, dt, calls, init, speculation=spec, prev=prev, start=start, devices=DEVICES)
         host = _run_cli(sc)
         rc, st, plan, _, _ = world.plan(w.ribbons4, w.start5 if start is None else start, calls * dt, t_start, dt, initial_samples=init, prev11=prev)
         if rc != 0 or "exception" in host:
