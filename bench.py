@@ -354,7 +354,10 @@ def run_rank(args):
         per_kernel = None
         sweep_hbm = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")   # written from separate rocprofv3 --pmc passes (tools/traffic.sh)
-        if os.path.exists(tp):
+        # the PMC passes ran the default per-GPU workload (config 3: 65 536 attempts per step): their per-launch figures say nothing
+        # about a --strong slice or another batch size
+        counters_apply = (not args.strong) and args.batch == 65536
+        if counters_apply and os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
                 # the counters describe THIS run only if the kernel sources are still the ones they were measured on
@@ -373,7 +376,7 @@ def run_rank(args):
         # stamped with the kernel sources it was measured on
         valu = None
         vp = os.path.join(ROOT, "profiles", "valu.json")
-        if os.path.exists(vp):
+        if counters_apply and os.path.exists(vp):
             try:
                 vj = json.load(open(vp))
                 if vj.get("kernel_sources_sha256") != kernel_sources_sha256():
@@ -423,9 +426,11 @@ def run_rank(args):
                                         "hardware utilisation and can exceed 1 - valu_issue_frac (counters) is the utilisation figure",
                          "valu_issue_frac": (valu or {}).get("valu_issue_frac"),
                          "executed_to_model_flops": ((valu["executed_lane_ops_per_launch"] / (flops_per_edge * n_edges_launch)) if valu else None),
-                         "valu_is": ("profiles/valu.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES ... on these kernel sources, tools/valu.sh): "
-                                     "valu_issue_frac = sum over the costing kernels of SQ_ACTIVE_INST_VALU / (4 SIMDs x SQ_BUSY_CU_CYCLES); executed = "
-                                     "SQ_INSTS_VALU x 64 lanes, an upper bound of the lanes doing arithmetic" if valu else "null: no VALU counter pass on these kernel sources (tools/valu.sh)"),
+                         "valu_is": ("profiles/valu.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU and, in its own pass, GRBM_GUI_ACTIVE on these kernel sources, "
+                                     "tools/valu.sh): valu_issue_frac = sum over the costing kernels of SQ_ACTIVE_INST_VALU x 4 (the counter counts quad-cycles) / "
+                                     "(1 024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); executed = SQ_INSTS_VALU x 64 lanes, an upper bound of the lanes doing arithmetic"
+                                     if valu else ("null: no VALU counter pass on these kernel sources (tools/valu.sh)" if counters_apply else
+                                                   "null: the PMC passes measured the default per-GPU workload (config 3), not this one")),
                          "valu_per_kernel": (valu or {}).get("kernels"),
                          "algorithmic_flops_per_edge": flops_per_edge,
                          "kernel": "the costing launch (pp_k_solve_edges .. pp_k_heuristic_lanes); dominant kernel pp_k_cover_sweep (kernel_ms includes pp_k_cover_finish, which ends its edges one lane each)",
@@ -438,7 +443,8 @@ def run_rank(args):
                                          "pp_k_heuristic_listed) + pp_k_heuristic_big; the four add up to the launch",
                          "traffic": traffic,
                          "traffic_is": ("PMC bytes per costing launch from profiles/traffic.json, measured on these kernel sources"
-                                        if traffic is not None else "null: no PMC pass on these kernel sources (tools/traffic.sh)"),
+                                        if traffic is not None else ("null: no PMC pass on these kernel sources (tools/traffic.sh)" if counters_apply else
+                                                                    "null: the PMC passes measured the default per-GPU workload (config 3), not this one")),
                          "hbm": {"bound": "hbm", "achieved": hbm_model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_model_gbs / HBM_PEAK_GBS,
                                  "achieved_is": "algorithmic bytes per edge (model, SURVEY 8d) x edges of the launch / launch_ms",
                                  "algorithmic_bytes_per_edge": bytes_per_edge, "algorithmic_bytes_per_launch": alg_bytes_launch,

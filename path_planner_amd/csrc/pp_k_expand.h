@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
     __shared__ double cd[PP_ORD_CAP];        // 96 KB of the CU's 160 KB LDS: distance and list position (later sample index); the lengths
     __shared__ int ci[PP_ORD_CAP];           // stay in the list in memory and are fetched by position when the replay gets there
     __shared__ double inner[PP_ORD_INNER];
-    __shared__ int nInner, nKept;
+    __shared__ int nInner, nKept, fallbackVerdict;
     __shared__ double threshold;
     const int vr = blockIdx.x, r = vr & 1;
     const int tid = (int)threadIdx.x;
@@ -431,9 +431,8 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
 #ifdef PP_DBG_ORD
     tk3 = wall_clock64();
 #endif
-    if (tid >= PP_WAVE) return;
-    // the replay (wave 0)
-    const int lane = tid;
+    // the replay (wave 0; the other waves wait for its verdict: a list that has to fall back is selected by the whole workgroup)
+    const int lane = tid & (PP_WAVE - 1);
     PPOrdHeap h;
     h.cost = INFINITY; h.len = INFINITY; h.idx = -1;
     int hsize = 0;
@@ -453,7 +452,7 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
         }
         return ok;
     };
-    if (!fallback) {
+    if (!fallback && tid < PP_WAVE) {
         for (int base = 0; base < Mk && !stopped && !unsafeFiltered; base += PP_WAVE) {
             const int c = base + lane;
             const bool have = c < Mk;
@@ -502,11 +501,17 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
     tk4 = wall_clock64();
     if (lane == 0 && vr < 4) printf("[ord] vr %d M %d inner %d kept %d exact %d | filter %lld keep %lld sort %lld replay %lld (x10ns)\n", vr, M, nInner, Mk, nexact, tk1 - tk0, tk2 - tk1, tk3 - tk2, tk4 - tk3);
 #endif
-    if (fallback || unsafeFiltered) {
+    if (tid == 0) fallbackVerdict = (fallback || unsafeFiltered) ? 1 : 0;
+    __syncthreads();
+    if (!fallbackVerdict) {
+        if (tid < PP_WAVE && lane < k) out[lane] = (lane < hsize) ? h.idx : -1;      // the heap array, front to back
+        return;
+    }
+    {
         // keep what a plain selection gives: the k cheapest of the list, ascending by (length, sample); only the push order is lost
-        if (lane == 0) atomicAdd(fallbacks, 1u);
+        if (tid == 0) atomicAdd(fallbacks, 1u);
 #ifdef PP_DBG_ORD
-        if (lane == 0) printf("[ord] FALLBACK vr %d: k %d M %d cap %lld kept %d unsafeFiltered %d hsize %d | U %g dq %g inner %d threshold %g\n", vr, k, M, g_cap, Mk, (int)unsafeFiltered, hsize, U, dq, nInner, threshold);
+        if (tid == 0) printf("[ord] FALLBACK vr %d: k %d M %d cap %lld kept %d unsafeFiltered %d hsize %d | U %g dq %g inner %d threshold %g\n", vr, k, M, g_cap, Mk, (int)unsafeFiltered, hsize, U, dq, nInner, threshold);
 #endif
         // More candidates within the bound than the list holds (M > g_cap: slots beyond it were dropped in the order the atomics
         // happened to arrive): the truncated list is not a set anyone can name, so the selection runs over the vertex's whole row
@@ -514,13 +519,52 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
         const bool fullRow = (long long)M > g_cap;
         const long long Mc = fullRow ? ns : (long long)M;
         const double* row = lengths + (size_t)(vr >> 1) * (size_t)ns * 2 + r;
+        // Round 4: ONE pass by the whole workgroup instead of k passes by one wavefront (a late-mission round trip over 2.5 million
+        // samples whose lists all fell back took 200 ms and overran the planner's deadline by 145 ms).  U, the k-th smallest block
+        // minimum of this row, bounds the k-th smallest length from above, and every sample not longer than U is in the list when
+        // the list is whole (its distance is at most its length): the winners are among the entries with length <= U — usually a
+        // few dozen — which go to LDS and are ranked there.
+        __syncthreads();
+        if (tid == 0) nKept = 0;
+        __syncthreads();
+        for (long long c = tid; c < Mc; c += 256) {
+            const double l = fullRow ? row[2 * c] : gl[c];
+            if (!(l >= 0) || l > U) continue;
+            const int slot = atomicAdd(&nKept, 1);
+            if (slot < PP_ORD_CAP) { cd[slot] = l; ci[slot] = fullRow ? (int)c : gv[c]; }
+        }
+        __syncthreads();
+        const int Ms = nKept;
+        if (Ms <= PP_ORD_CAP) {
+            if (tid >= PP_WAVE) return;
+            double prevL = -INFINITY; int prevI = -1;
+            for (int j = 0; j < k; j++) {
+                double bl = INFINITY; int bi = 0x7fffffff;
+                for (int c = lane; c < Ms; c += PP_WAVE) {
+                    const double l = cd[c];
+                    const int i = ci[c];
+                    const bool after = (l > prevL) || (l == prevL && i > prevI);
+                    if (after && (l < bl || (l == bl && i < bi))) { bl = l; bi = i; }
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double l2 = __shfl_xor(bl, o, PP_WAVE); const int i2 = __shfl_xor(bi, o, PP_WAVE);
+                    if (l2 < bl || (l2 == bl && i2 < bi)) { bl = l2; bi = i2; }
+                }
+                if (lane == 0) out[j] = (bi == 0x7fffffff) ? -1 : bi;
+                prevL = bl; prevI = bi;
+                if (bi == 0x7fffffff) { for (int jj = j + 1 + lane; jj < k; jj += PP_WAVE) out[jj] = -1; break; }
+            }
+            return;
+        }
+        // more than PP_ORD_CAP entries within U (thousands of exactly equal lengths): k successive minimum scans of the source, by the
+        // whole workgroup (cd / ci as the reduction's scratch)
         double prevL = -INFINITY; int prevI = -1;
         for (int j = 0; j < k; j++) {
             double bl = INFINITY; int bi = 0x7fffffff;
-            for (long long c = lane; c < Mc; c += PP_WAVE) {
+            for (long long c = tid; c < Mc; c += 256) {
                 const double l = fullRow ? row[2 * c] : gl[c];
                 const int i = fullRow ? (int)c : gv[c];
-                if (fullRow && !(l >= 0)) continue;
+                if (!(l >= 0)) continue;
                 const bool after = (l > prevL) || (l == prevL && i > prevI);
                 if (after && (l < bl || (l == bl && i < bi))) { bl = l; bi = i; }
             }
@@ -528,13 +572,18 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
                 const double l2 = __shfl_xor(bl, o, PP_WAVE); const int i2 = __shfl_xor(bi, o, PP_WAVE);
                 if (l2 < bl || (l2 == bl && i2 < bi)) { bl = l2; bi = i2; }
             }
-            if (lane == 0) out[j] = (bi == 0x7fffffff) ? -1 : bi;
+            __syncthreads();
+            if (lane == 0) { cd[tid >> 6] = bl; ci[tid >> 6] = bi; }
+            __syncthreads();
+            for (int w = 0; w < 4; w++) {
+                const double l2 = cd[w]; const int i2 = ci[w];
+                if (w == 0 || l2 < bl || (l2 == bl && i2 < bi)) { bl = l2; bi = i2; }
+            }
+            if (tid == 0) out[j] = (bi == 0x7fffffff) ? -1 : bi;
             prevL = bl; prevI = bi;
-            if (bi == 0x7fffffff) { for (int jj = j + 1 + lane; jj < k; jj += PP_WAVE) out[jj] = -1; break; }
+            if (bi == 0x7fffffff) { for (int jj = j + 1 + tid; jj < k; jj += 256) out[jj] = -1; break; }
         }
-        return;
     }
-    if (lane < k) out[lane] = (lane < hsize) ? h.idx : -1;      // the heap array, front to back
 }
 
 // ------------------------------------------------------------------------------------------

@@ -61,6 +61,7 @@ public:
             unsigned long DeviceGrowths = 0;  // device / pinned buffers the device library grew inside the call (ppgpu_growth_stats) ...
             double DeviceGrowthMs = 0;        // ... and what that took
             unsigned long RoundTrips = 0;
+            double PickMs = 0, MaxPickMs = 0;  // choosing the open vertices of the round trips (pickBatch): total and the longest single walk
             bool GridUploaded = false;        // the occupancy grid went to the device in this call (false: the device already held this map)
         } Budget;
     };
@@ -146,16 +147,22 @@ public:
         if (doubling.seconds <= 0) return 0;
         return doubling.seconds * std::max(1.0, attempts / std::max(1.0, doubling.samples)) * 1.15 + 1e-4;
     }
+    // How far a round trip overran its prediction, remembered for a while (round 4: one trip in a few hundred takes 0.8-3 ms longer
+    // than any of the eight before it scaled to its sample count would suggest — children with long ribbon lists whose heuristic one
+    // wavefront enumerates, a second pass at a larger child stride — and when it happened to be a cycle's last the cycle ended
+    // 0.05-0.4 ms late): the largest excess seen, decaying by 0.1 % per round trip (half of it is left four cycles later), at most 3 ms.
+    double tailExcess = 0;
+    void noteExcess(double seconds) { tailExcess = std::max(tailExcess * 0.999, std::min(seconds, 3e-3)); }
     // What the guard keeps clear of the deadline on top of its predictions, so that "before" holds and not "at": half a
-    // millisecond (the return path: tracing the plan, the caller's clock read), or twice the spread of the recent round trips
-    // if that is more.
+    // millisecond (the return path: tracing the plan, the caller's clock read), or twice the spread of the recent round trips,
+    // or the remembered excess above, whichever is largest.
     double guardMargin() const {
         double n = 0, sum = 0, sq = 0;
         for (const Observed& o : trips)
             if (o.seconds > 0) { n += 1; sum += o.seconds; sq += o.seconds * o.seconds; }
         double sigma = 0;
         if (n >= 2) { const double mean = sum / n; sigma = std::sqrt(std::max(0.0, sq / n - mean * mean)); }
-        return std::max(5e-4, 2 * sigma);
+        return std::max(std::max(5e-4, 2 * sigma), tailExcess);
     }
     // The search tree's node array lives HERE between plan() calls (a planner takes it at the start of plan() and hands it back,
     // emptied, when it is destroyed): its capacity — and its pages — survive the cycle.  Measured in round 4 (Stats::Budget): a
@@ -229,7 +236,7 @@ private:
     void dropBatch(Batch* b);
     void drainInFlight();
     GpuContext& freeContext();
-    void pickBatch(int source, std::vector<int>& batch) const;
+    void pickBatch(int source, std::vector<int>& batch);
     double m_EndTime = 0;                  // the deadline of this plan() call, on the injected clock
     int costEdgeList(const std::vector<uint64_t>& edges, int maxParentRibbons, std::vector<::ppgpu_edge_result>& res, std::vector<double>& child);
     Node makeChild(int source, unsigned cfgBits, const ::ppgpu_edge_result& r, const double* childRibbons, int stride);

@@ -637,6 +637,7 @@ void GpuAStarPlanner::harvestBatch(Batch* bp, bool keep) {
     }
     noteOperation(1, b.started, b.predicted, b.took);
     b.ctx->noteTrip(b.samples, b.took);
+    if (b.predicted > 0) m_Ctx->noteExcess(b.took - b.predicted);     // (the guard's margin is the first context's)
     m_Stats.EdgesCosted += b.edgesCosted;
     if (!keep) return;                         // costed against a sample set that is no longer the search's
     Lap lap(3);
@@ -692,7 +693,17 @@ GpuContext& GpuAStarPlanner::freeContext() {
 // (a small heap of heap positions) the entries come out in non-decreasing f, so the walk touches about as many entries as it
 // returns — round 3 scanned and partially sorted the whole list (100 000+ entries late in a cycle: up to 40 of a cycle's 100 ms).
 // Ties in f are taken smallest node index first, as before: the walk goes on through every entry that ties with the last one taken.
-void GpuAStarPlanner::pickBatch(int source, std::vector<int>& batch) const {
+// Two cuts bound the walk (round 4: one cycle in a few hundred spent 76 ms of its 100 in a single walk — late in a search tens of
+// thousands of goals sit in the list at exactly f = horizon, few open vertices are better, and the walk went through the whole
+// plateau looking for the rest of its batch): an entry worse than a goal the walk has already passed is never expanded in this pass
+// (aStar returns when that goal is popped), so the walk ends there; and it visits at most 16 x the batch + 1 024 entries.  Either way
+// the batch is smaller, which changes when arithmetic happens, never what is pushed.
+void GpuAStarPlanner::pickBatch(int source, std::vector<int>& batch) {
+    const double pick0 = HostProfile::now();
+    struct PickTimer {
+        Stats::BudgetTrace& b; double t0;
+        ~PickTimer() { const double ms = 1e3 * (HostProfile::now() - t0); b.PickMs += ms; b.MaxPickMs = std::max(b.MaxPickMs, ms); }
+    } pickTimer{m_Stats.Budget, pick0};
     batch.clear();
     if (source >= 0) batch.push_back(source);          // -1: a prefetch batch, nobody is waiting for any of it
     const size_t want = (size_t)std::max(0, m_Config.speculation() - (source >= 0 ? 1 : 0));
@@ -702,14 +713,19 @@ void GpuAStarPlanner::pickBatch(int source, std::vector<int>& batch) const {
     std::vector<Entry> frontier;
     frontier.emplace_back(m_Nodes[m_Queue[0]].f(), 0);
     std::vector<std::pair<double, int>> cand;                 // (f, node)
-    double lastF = 0;
+    double lastF = 0, goalF = INFINITY;
+    size_t visited = 0;
+    const size_t maxVisited = 16 * want + 1024;
     while (!frontier.empty()) {
         std::pop_heap(frontier.begin(), frontier.end(), worse);
         const Entry e = frontier.back();
         frontier.pop_back();
         if (cand.size() >= want && e.first > lastF) break;    // everything left is worse than what is already taken
+        if (e.first > goalF || ++visited > maxVisited) break; // ... or than a goal already in the list; or the walk has gone far enough
         const int v = m_Queue[e.second];
-        if (!m_Speculated.count(v) && !m_InFlightOf.count(v) && !goalCondition(m_Nodes[v])) { cand.emplace_back(e.first, v); lastF = std::max(lastF, e.first); }
+        const bool goal = goalCondition(m_Nodes[v]);
+        if (goal) goalF = std::min(goalF, e.first);
+        if (!goal && !m_Speculated.count(v) && !m_InFlightOf.count(v)) { cand.emplace_back(e.first, v); lastF = std::max(lastF, e.first); }
         for (size_t c = 2 * e.second + 1; c <= 2 * e.second + 2 && c < m_Queue.size(); c++) {
             frontier.emplace_back(m_Nodes[m_Queue[c]].f(), c);
             std::push_heap(frontier.begin(), frontier.end(), worse);

@@ -1033,6 +1033,78 @@ def test_expand_order_with_more_candidates_than_the_list_holds(torch_cuda):
             assert idx[0, r].tolist() == want.tolist(), (attempt, r)
 
 
+def test_expand_order_fallback_with_thousands_of_equal_lengths(torch_cuda):
+    """Round 4: the fallback selects in one pass over the entries not longer than the bound.  When more of them tie than its LDS list
+    holds (here 20 000 and 70 000 copies of one pose: every length equal, the second also more than the candidate list holds) it
+    scans the source k times with the whole workgroup: ascending (length, sample) = the k lowest sample indices."""
+    from path_planner_amd import api, workloads
+    w = workloads.config1()
+    x0, y0 = float(w.start5[0]), float(w.start5[1])
+    k = 9
+    for n in (20000, 70000):
+        ctx = api.Context(0)
+        ctx.set_config(w.cfg); ctx.set_grid(None, 0.0); ctx.set_obstacles(None)
+        ctx.set_vertices(w.root(), w.ribbons4)
+        ctx.set_samples(np.full(n, x0 + 60.0), np.full(n, y0 + 25.0), np.full(n, 1.0))
+        idx, fb = ctx.expand_order(1, k)
+        assert fb == 2, (n, fb)
+        for r in range(2):
+            assert idx[0, r].tolist() == list(range(k)), (n, r, idx[0, r])
+        # ... and a few cheaper samples among them are found first, in ascending length
+        xs = np.full(n, x0 + 60.0); ys = np.full(n, y0 + 25.0); hs = np.full(n, 1.0)
+        near = [n - 5, 17, n // 2]
+        for j, i in enumerate(near):
+            xs[i] = x0 + 10.0 + j; ys[i] = y0; hs[i] = float(w.start5[2])
+        ctx.set_samples(xs, ys, hs)
+        d_len = torch_cuda.zeros(n * 2, dtype=torch_cuda.float64, device="cuda:0")
+        torch_cuda.cuda.synchronize()
+        ctx.dubins_lengths(0, 1, d_len.data_ptr()); ctx.synchronize()
+        ln = d_len.cpu().numpy().reshape(n, 2)
+        idx, fb = ctx.expand_order(1, k)
+        for r in range(2):
+            want = np.lexsort((np.arange(n), ln[:, r]))[:k]
+            assert idx[0, r].tolist() == want.tolist(), (n, r)
+
+
+def test_a_round_trip_whose_lists_all_fall_back_stays_cheap(torch_cuda):
+    """Round 4: 64 open vertices over a million samples on one circle around them (every list has more candidates inside its bound
+    than it holds: all 128 fall back to the whole row of lengths).  One wavefront scanning the row k times took 200 ms for such a
+    round trip in a late-mission replan cycle and overran the planner's deadline; one pass by the workgroup must not."""
+    import time
+    from path_planner_amd import api, workloads
+    from path_planner_amd.types import VERTEX_DTYPE
+    w = workloads.config1()
+    ctx = api.Context(0)
+    ctx.set_config(w.cfg); ctx.set_grid(None, 0.0); ctx.set_obstacles(None)
+    nv, n, k = 64, 1 << 20, 9
+    root = w.root()
+    v = np.zeros(nv, dtype=VERTEX_DTYPE)
+    for i in range(nv):
+        v[i] = root[0]
+        v[i]["heading"] = 2 * np.pi * i / nv
+        v[i]["ribbon_offset"] = 0
+    ctx.set_vertices(v, w.ribbons4)
+    rng = np.random.default_rng(4)
+    a = rng.uniform(0, 2 * np.pi, n)
+    x0, y0 = float(w.start5[0]), float(w.start5[1])
+    ctx.set_samples(x0 + 100.0 * np.cos(a), y0 + 100.0 * np.sin(a), rng.uniform(0, 2 * np.pi, n))
+    idx, fb = ctx.expand_order(nv, k)              # (first call: buffers)
+    assert fb == 2 * nv
+    t0 = time.perf_counter()
+    idx2, fb2 = ctx.expand_order(nv, k)
+    ms = (time.perf_counter() - t0) * 1e3
+    assert fb2 == 2 * nv and (idx2 == idx).all()
+    assert ms < 60.0, ms                           # lengths of 64 x 1 M pairs + one pass over them: ~10 ms; the k-pass scan by one wave: > 100
+    # spot check against the lengths themselves
+    d_len = torch_cuda.zeros(n * 2, dtype=torch_cuda.float64, device="cuda:0")
+    torch_cuda.cuda.synchronize()
+    ctx.dubins_lengths(5, 1, d_len.data_ptr()); ctx.synchronize()
+    ln = d_len.cpu().numpy().reshape(n, 2)
+    for r in range(2):
+        want = np.lexsort((np.arange(n), ln[:, r]))[:k]
+        assert idx[5, r].tolist() == want.tolist(), r
+
+
 def test_slow_edges_crawling_along_ribbons(torch_cuda):
     """The cover sweep's long runs (one sample every few steps once a corridor / quiet run has filled a window): slow coverage edges
     (0.5 m/s: one centimetre per collision-check step) from a vertex standing at the start of a ribbon, heading along it, to
