@@ -125,6 +125,7 @@ public:
     // run `job` on this context's thread; wait() blocks until it has finished and rethrows what it threw
     void run(std::function<void()> job);
     void wait();
+    bool idle();               // no job of run() is running (its result, or what it threw, is waiting for wait())
 
     // What this device's recent round trips and sample doublings took (wall seconds), kept with the context so that the first
     // cycle of a new planner already knows: the deadline guard (PlannerConfig::deadlineGuard) predicts the next one from them.
@@ -231,6 +232,7 @@ private:
     std::unordered_map<int, Batch*> m_InFlightOf;          // open vertex -> the round trip that is costing its children
     void packBatch(Batch& b) const;
     static void runBatch(Batch& b, int k);
+    void harvestFinished();
     void submitBatch(std::shared_ptr<Batch> b, GpuContext& ctx);
     void harvestBatch(Batch* b, bool keep);
     void dropBatch(Batch* b);

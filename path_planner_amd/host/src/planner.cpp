@@ -138,6 +138,11 @@ void GpuContext::wait() {
     }
 }
 
+bool GpuContext::idle() {
+    std::lock_guard<std::mutex> lock(m_Mutex);
+    return !m_Busy;
+}
+
 void TripBlock::reserve(size_t nEdges, size_t childDoubles) {
     if (nEdges > edgeCap) {
         edges.reset(new uint64_t[nEdges]);
@@ -655,6 +660,17 @@ void GpuAStarPlanner::harvestBatch(Batch* bp, bool keep) {
     for (int i = 0; i < M; i++) m_Speculated[b.sources[i]] = std::move(out[i]);
 }
 
+// Round trips that are over but that nobody has asked for yet (a prefetch batch none of whose vertices the search has popped): their
+// children join m_Speculated and their contexts are free again.  Without this such a batch held its context for the rest of the
+// cycle (round 4: late-mission cycles ran on one of their two contexts from 2 ms on).
+void GpuAStarPlanner::harvestFinished() {
+    for (size_t i = 0; i < m_InFlight.size();) {
+        Batch* b = m_InFlight[i].get();
+        if (b->threaded && b->ctx->idle()) harvestBatch(b, true);     // (erases it from m_InFlight)
+        else i++;
+    }
+}
+
 void GpuAStarPlanner::dropBatch(Batch* bp) {
     for (int v : bp->sources) m_InFlightOf.erase(v);
     for (auto it = m_InFlight.begin(); it != m_InFlight.end(); ++it)
@@ -739,8 +755,11 @@ bool GpuAStarPlanner::expand(int source) {
     visualizeVertex(source, "vertex", true);
     auto it = m_Speculated.find(source);
     if (it == m_Speculated.end()) {
-        auto flying = m_InFlightOf.find(source);
-        if (flying == m_InFlightOf.end()) {
+        harvestFinished();
+        auto flying = m_Speculated.count(source) ? m_InFlightOf.end() : m_InFlightOf.find(source);
+        if (m_Speculated.count(source)) {
+            // (a finished prefetch batch just brought it)
+        } else if (flying == m_InFlightOf.end()) {
             GpuContext& ctx = freeContext();           // (may harvest a batch: the source can be among its vertices now)
             if (!m_Speculated.count(source)) {
                 std::shared_ptr<Batch> b(new Batch());
