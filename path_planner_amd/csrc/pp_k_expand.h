@@ -224,41 +224,129 @@ __device__ __forceinline__ void pp_ord_pop(PPOrdHeap& h, int n) {
 //   pp_k_expand_candidates  thread per (vertex, sample): the samples the scan can visit — valid, distance <= U — appended to the
 //                           (vertex, radius) list {distance, index, length} with one atomic per wavefront;
 //   pp_k_expand_order       workgroup per (vertex, radius): sort the list by (distance, index), replay (above).
-__global__ __launch_bounds__(256) void pp_k_lengths_minima(const ppgpu_vertex* verts, const double* sx, const double* sy, const double* sh, long long ns,
-                                                           double rho, double rho_cov, double inc_d, double* out, double* blockmin, int* blockcnt) {
-    __shared__ double m0[4], m1[4];
-    __shared__ int nv[4];
-    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+// Round 4: Dubins lengths only for the samples that can matter.  The k winners of a (vertex, radius) are not longer than ANY k
+// lengths one cares to compute, and a sample's Euclidean distance never exceeds its Dubins length — so a PROBE of the first
+// PP_PROBE samples (the generator draws uniformly in the box, every prefix is spread like the whole) gives a bound Ub, and only the
+// samples within Ub of the vertex — about a seventh of the set at the planner's sample counts — get their two lengths.  Round 3
+// solved both Dubins problems for every (vertex, sample) pair: 97 us of every planner round trip for lengths 85 % of which nothing
+// ever looked at.  Same winners, same push order: any upper bound of the k-th smallest length serves (pp_k_expand_bound then
+// tightens it from the near samples' own block minima as before).
+//   pp_k_expand_probe   thread per (vertex, probe sample): its lengths; per radius the minimum of every 32 consecutive probe samples
+//   pp_k_expand_near    thread per (vertex, sample): Ub = the k-th smallest of the vertex's 32 group minima per radius (k different
+//                       samples are not longer than it; +inf when fewer than k groups hold a valid sample, or k > 32: then every
+//                       valid sample is "near" — the exhaustive path, as before); farther than the increment
+//                       (SamplingBasedPlanner.cpp:111) and within the larger of the two bounds -> the vertex's near list (one
+//                       atomic per workgroup; order arbitrary)
+//   pp_k_near_lengths   thread per (vertex, near slot): both Dubins lengths, per 256 slots the smallest of each radius
+#define PP_PROBE 1024
+#define PP_PROBE_GROUPS (PP_PROBE / 32)      // minima of 32 probe samples each: the k-th smallest of them bounds the k-th smallest length
+// thread per (vertex, probe sample): (PP_PROBE / 256, nv) workgroups
+__global__ __launch_bounds__(256) void pp_k_expand_probe(const ppgpu_vertex* verts, const double* sx, const double* sy, const double* sh, long long ns,
+                                                         double rho, double rho_cov, double inc_d, int two_radii, double* probe_min, int* near_count) {
     const int v = blockIdx.y;
-    double l0 = -1, l1 = -1;
+    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+    const ppgpu_vertex* V = verts + v;
+    const double ax = V->x, ay = V->y, ayaw = pp_yaw(V->heading);
+    double b0 = INFINITY, b1 = INFINITY;
     if (s < ns) {
-        const ppgpu_vertex* V = verts + v;
-        const double ax = V->x, ay = V->y, ayaw = pp_yaw(V->heading);
         const double bx = sx[s], by = sy[s], byaw = pp_yaw(sh[s]);
         if (sqrt((ax - bx) * (ax - bx) + (ay - by) * (ay - by)) > inc_d) {   // State::distanceTo, SamplingBasedPlanner.cpp:111
             PPDubins d;
             pp_dubins_shortest(ax, ay, ayaw, bx, by, byaw, rho, d);
-            l0 = pp_dubins_length(d, rho);
-            pp_dubins_shortest(ax, ay, ayaw, bx, by, byaw, rho_cov, d);
-            l1 = pp_dubins_length(d, rho_cov);
+            b0 = pp_dubins_length(d, rho);
+            if (two_radii) {
+                pp_dubins_shortest(ax, ay, ayaw, bx, by, byaw, rho_cov, d);
+                b1 = pp_dubins_length(d, rho_cov);
+            }
         }
-        double2 o; o.x = l0; o.y = l1;
-        reinterpret_cast<double2*>(out)[(size_t)v * ns + s] = o;
     }
+    // the minimum of each half wavefront (32 consecutive probe samples)
+    for (int o = 16; o > 0; o >>= 1) {
+        b0 = fmin(b0, __shfl_xor(b0, o, PP_WAVE));
+        b1 = fmin(b1, __shfl_xor(b1, o, PP_WAVE));
+    }
+    if ((threadIdx.x & 31) == 0) {
+        const int g = (int)(blockIdx.x * 8 + (threadIdx.x >> 5));
+        probe_min[((size_t)v * 2 + 0) * PP_PROBE_GROUPS + g] = b0;
+        probe_min[((size_t)v * 2 + 1) * PP_PROBE_GROUPS + g] = two_radii ? b1 : b0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) near_count[v] = 0;
+}
+// the k-th smallest of a (vertex, radius)'s PP_PROBE_GROUPS group minima (ties ranked by group): +inf when fewer than k are finite.
+// Every lane gets the value (lanes 0 .. PP_PROBE_GROUPS - 1 hold one group each).
+__device__ __forceinline__ double pp_probe_bound(const double* probe_min, int v, int r, int k) {
+    const int lane = pp_lane();
+    const double x = (lane < PP_PROBE_GROUPS) ? probe_min[((size_t)v * 2 + r) * PP_PROBE_GROUPS + lane] : INFINITY;
+    int rank = 0;
+    for (int i = 0; i < PP_PROBE_GROUPS; i++) {
+        const double y = pp_readlane(x, i);
+        rank += ((y < x) | ((y == x) & (i < lane))) ? 1 : 0;
+    }
+    const unsigned long long hit = __ballot((x < INFINITY) & (rank == k - 1));
+    return hit ? pp_readlane(x, __ffsll((long long)hit) - 1) : INFINITY;
+}
+__global__ __launch_bounds__(256) void pp_k_expand_near(const ppgpu_vertex* verts, const double* sx, const double* sy, long long ns, double inc_d,
+                                                        const double* probe_min, int k, int* near_idx, int* near_count) {
+    __shared__ int wcount[4], wbase[4];
+    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y, w = (int)(threadIdx.x >> 6), lane = pp_lane();
+    // (every wavefront ranks the vertex's 2 x 32 group minima for itself: cheaper than a launch that does it once)
+    const double Ub = (k <= PP_PROBE_GROUPS) ? fmax(pp_probe_bound(probe_min, v, 0, k), pp_probe_bound(probe_min, v, 1, k)) : INFINITY;
+    bool take = false;
+    if (s < ns) {
+        const double vx = verts[v].x, vy = verts[v].y;
+        const double d = sqrt((vx - sx[s]) * (vx - sx[s]) + (vy - sy[s]) * (vy - sy[s]));
+        take = (d > inc_d) && !(d > Ub * (1.0 + 1e-9));
+    }
+    const unsigned long long m = __ballot(take);
+    if (lane == 0) wcount[w] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        int base = tot ? atomicAdd(&near_count[v], tot) : 0;
+        for (int i = 0; i < 4; i++) { wbase[i] = base; base += wcount[i]; }
+    }
+    __syncthreads();
+    if (take) near_idx[(size_t)v * (size_t)ns + (size_t)(wbase[w] + __popcll(m & ((1ull << lane) - 1ull)))] = (int)s;
+}
+__global__ __launch_bounds__(256) void pp_k_near_lengths(const ppgpu_vertex* verts, const double* sx, const double* sy, const double* sh, long long ns,
+                                                         const int* near_idx, const int* near_count, double rho, double rho_cov, int two_radii,
+                                                         double* out, double* blockmin, int* blockcnt) {
+    __shared__ double m0[4], m1[4];
+    const int v = blockIdx.y;
+    const int n = near_count[v];
+    const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
+    if ((long long)blockIdx.x * 256 >= (long long)n) return;            // (whole workgroups beyond the vertex's list)
+    double l0 = -1, l1 = -1;
+    if (slot < n) {
+        const ppgpu_vertex* V = verts + v;
+        const double ax = V->x, ay = V->y, ayaw = pp_yaw(V->heading);
+        const int s = near_idx[(size_t)v * (size_t)ns + (size_t)slot];
+        const double bx = sx[s], by = sy[s], byaw = pp_yaw(sh[s]);
+        PPDubins d;
+        pp_dubins_shortest(ax, ay, ayaw, bx, by, byaw, rho, d);
+        l0 = pp_dubins_length(d, rho);
+        pp_dubins_shortest(ax, ay, ayaw, bx, by, byaw, rho_cov, d);
+        l1 = pp_dubins_length(d, rho_cov);
+        double2 o; o.x = l0; o.y = l1;
+        reinterpret_cast<double2*>(out)[(size_t)v * (size_t)ns + (size_t)slot] = o;
+    }
+    (void)two_radii;
     const double a0 = pp_wave_min(l0 >= 0 ? l0 : INFINITY), a1 = pp_wave_min(l1 >= 0 ? l1 : INFINITY);
-    const int cnt = __popcll(__ballot(l0 >= 0));
     const int w = (int)(threadIdx.x >> 6);
-    if (pp_lane() == 0) { m0[w] = a0; m1[w] = a1; nv[w] = cnt; }
+    if (pp_lane() == 0) { m0[w] = a0; m1[w] = a1; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const size_t b = (size_t)v * gridDim.x + blockIdx.x;
         blockmin[2 * b] = fmin(fmin(m0[0], m0[1]), fmin(m0[2], m0[3]));
         blockmin[2 * b + 1] = fmin(fmin(m1[0], m1[1]), fmin(m1[2], m1[3]));
-        blockcnt[b] = nv[0] + nv[1] + nv[2] + nv[3];
+        const long long left = (long long)n - (long long)blockIdx.x * 256;
+        blockcnt[b] = (int)(left < 256 ? left : 256);
     }
 }
 #define PP_BOUND_CAP 512             // values the bound kernel ranks: block minima, merged into groups of consecutive blocks when there are more
-__global__ __launch_bounds__(256) void pp_k_expand_bound(const double* blockmin, const int* blockcnt, int nblk, int k, double* bound, int* cand_count) {
+// (nblk_row: blocks per vertex the arrays are laid out for; near_count: the vertex's own list length — only its blocks were written)
+__global__ __launch_bounds__(256) void pp_k_expand_bound(const double* blockmin, const int* blockcnt, int nblk_row, const int* near_count, int k, double* bound, int* cand_count) {
     __shared__ double vals[PP_BOUND_CAP];
     __shared__ int valid;
     __shared__ double U;
@@ -266,14 +354,15 @@ __global__ __launch_bounds__(256) void pp_k_expand_bound(const double* blockmin,
     const int tid = (int)threadIdx.x;
     if (tid == 0) { valid = 0; U = INFINITY; cand_count[vr] = 0; }
     __syncthreads();
+    const int nblk = (near_count[v] + 255) / 256;
     const int per = (nblk + PP_BOUND_CAP - 1) / PP_BOUND_CAP;            // blocks per ranked value
-    const int nval = (nblk + per - 1) / per;
+    const int nval = per > 0 ? (nblk + per - 1) / per : 0;
     int c = 0;
     for (int j = tid; j < nval; j += 256) {
         double m = INFINITY;
         for (int b = j * per; b < (j + 1) * per && b < nblk; b++) {
-            m = fmin(m, blockmin[2 * ((size_t)v * nblk + b) + r]);
-            c += blockcnt[(size_t)v * nblk + b];
+            m = fmin(m, blockmin[2 * ((size_t)v * nblk_row + b) + r]);
+            c += blockcnt[(size_t)v * nblk_row + b];
         }
         vals[j] = m;
     }
@@ -293,15 +382,19 @@ __global__ __launch_bounds__(256) void pp_k_expand_bound(const double* blockmin,
     if (tid == 0) bound[vr] = U;
 }
 __global__ __launch_bounds__(256) void pp_k_expand_candidates(const double* lengths, const ppgpu_vertex* verts, const double* sx, const double* sy,
-                                                              long long ns, int two_radii, const double* bound, double* g_key, int* g_val, double* g_len,
-                                                              long long g_cap, int* cand_count) {
+                                                              long long ns, const int* near_idx, const int* near_count, int two_radii, const double* bound,
+                                                              double* g_key, int* g_val, double* g_len, long long g_cap, int* cand_count) {
     __shared__ int wcount[2][4], wbase[2][4];
-    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
     const int v = blockIdx.y, w = (int)(threadIdx.x >> 6), lane = pp_lane();
+    const int n = near_count[v];
+    if ((long long)blockIdx.x * 256 >= (long long)n) return;            // (whole workgroups beyond the vertex's near list)
+    const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
     double l0 = -1, l1 = -1, d = 0;
-    if (s < ns) {
-        const double2 L = reinterpret_cast<const double2*>(lengths)[(size_t)v * ns + s];
+    int s = 0;
+    if (slot < n) {
+        const double2 L = reinterpret_cast<const double2*>(lengths)[(size_t)v * (size_t)ns + (size_t)slot];
         l0 = L.x; l1 = L.y;
+        s = near_idx[(size_t)v * (size_t)ns + (size_t)slot];
         const double vx = verts[v].x, vy = verts[v].y;
         d = sqrt((sx[s] - vx) * (sx[s] - vx) + (sy[s] - vy) * (sy[s] - vy));       // State::distanceTo of the sample to the source
     }
@@ -326,17 +419,18 @@ __global__ __launch_bounds__(256) void pp_k_expand_candidates(const double* leng
     __syncthreads();
     for (int r = 0; r < nr; r++) {
         if (!take[r]) continue;
-        const long long slot = wbase[r][w] + __popcll(m[r] & ((1ull << lane) - 1ull));
-        if (slot < g_cap) {
-            const size_t at = (size_t)(2 * v + r) * g_cap + slot;
-            g_key[at] = d; g_val[at] = (int)s; g_len[at] = r ? l1 : l0;
+        const long long at_slot = wbase[r][w] + __popcll(m[r] & ((1ull << lane) - 1ull));
+        if (at_slot < g_cap) {
+            const size_t at = (size_t)(2 * v + r) * g_cap + at_slot;
+            g_key[at] = d; g_val[at] = s; g_len[at] = r ? l1 : l0;
         }
     }
 }
 #define PP_ORD_INNER 1024            // candidates of the inner ring whose costs set the filter threshold
 __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, double max_speed, double tpf, int two_radii, const double* bound,
                                                          const double* g_key, const int* g_val, const double* g_len, long long g_cap,
-                                                         const int* cand_count, const double* lengths, int* out_idx, unsigned* fallbacks) {
+                                                         const int* cand_count, const double* lengths, const int* near_idx, const int* near_count,
+                                                         int* out_idx, unsigned* fallbacks) {
     __shared__ double cd[PP_ORD_CAP];        // 96 KB of the CU's 160 KB LDS: distance and list position (later sample index); the lengths
     __shared__ int ci[PP_ORD_CAP];           // stay in the list in memory and are fetched by position when the replay gets there
     __shared__ double inner[PP_ORD_INNER];
@@ -514,11 +608,12 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
         if (tid == 0) printf("[ord] FALLBACK vr %d: k %d M %d cap %lld kept %d unsafeFiltered %d hsize %d | U %g dq %g inner %d threshold %g\n", vr, k, M, g_cap, Mk, (int)unsafeFiltered, hsize, U, dq, nInner, threshold);
 #endif
         // More candidates within the bound than the list holds (M > g_cap: slots beyond it were dropped in the order the atomics
-        // happened to arrive): the truncated list is not a set anyone can name, so the selection runs over the vertex's whole row
-        // of lengths instead (-1 = closer than the increment, never a candidate: SamplingBasedPlanner.cpp:111)
+        // happened to arrive): the truncated list is not a set anyone can name, so the selection runs over the vertex's whole near
+        // list instead (every sample within the probe bound, which is not below U: nothing that can win is missing from it)
         const bool fullRow = (long long)M > g_cap;
-        const long long Mc = fullRow ? ns : (long long)M;
+        const long long Mc = fullRow ? (long long)near_count[vr >> 1] : (long long)M;
         const double* row = lengths + (size_t)(vr >> 1) * (size_t)ns * 2 + r;
+        const int* rowIdx = near_idx + (size_t)(vr >> 1) * (size_t)ns;
         // Round 4: ONE pass by the whole workgroup instead of k passes by one wavefront (a late-mission round trip over 2.5 million
         // samples whose lists all fell back took 200 ms and overran the planner's deadline by 145 ms).  U, the k-th smallest block
         // minimum of this row, bounds the k-th smallest length from above, and every sample not longer than U is in the list when
@@ -531,7 +626,7 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
             const double l = fullRow ? row[2 * c] : gl[c];
             if (!(l >= 0) || l > U) continue;
             const int slot = atomicAdd(&nKept, 1);
-            if (slot < PP_ORD_CAP) { cd[slot] = l; ci[slot] = fullRow ? (int)c : gv[c]; }
+            if (slot < PP_ORD_CAP) { cd[slot] = l; ci[slot] = fullRow ? rowIdx[c] : gv[c]; }
         }
         __syncthreads();
         const int Ms = nKept;
@@ -563,7 +658,7 @@ __global__ __launch_bounds__(256) void pp_k_expand_order(long long ns, int k, do
             double bl = INFINITY; int bi = 0x7fffffff;
             for (long long c = tid; c < Mc; c += 256) {
                 const double l = fullRow ? row[2 * c] : gl[c];
-                const int i = fullRow ? (int)c : gv[c];
+                const int i = fullRow ? rowIdx[c] : gv[c];
                 if (!(l >= 0)) continue;
                 const bool after = (l > prevL) || (l == prevL && i > prevI);
                 if (after && (l < bl || (l == bl && i < bi))) { bl = l; bi = i; }

@@ -149,8 +149,8 @@ struct ppgpu_ctx {
     int max_vertex_ribbons = 0;
     DevBuf<int> tmp_idx;
     DevBuf<double> ord_key;             // pp_k_expand_order: candidate scratch beyond what LDS holds, push-order output, fallback counter
-    DevBuf<int> ord_val, ord_idx, ord_blockcnt, ord_count;
-    DevBuf<double> ord_len, ord_blockmin, ord_bound;
+    DevBuf<int> ord_val, ord_idx, ord_blockcnt, ord_count, near_idx, near_count;   // (near_*: the samples within a vertex's probe bound, pp_k_expand_near)
+    DevBuf<double> ord_len, ord_blockmin, ord_bound, probe_bound;
     DevBuf<unsigned> ord_fallbacks;
     unsigned long long order_fallbacks = 0;   // (vertex, radius) lists of ppgpu_expand_host / ppgpu_expand_order that fell back to ascending length
     DevBuf<unsigned char> dstage_in, dstage_out;            // device ends of ppgpu_expand_host's single upload / download
@@ -221,7 +221,7 @@ int ppgpu_destroy(ppgpu_ctx* c) {
     c->s_bytes.release(); c->s_u64.release(); c->s_u32a.release(); c->s_u32b.release(); c->s_cand.release();
     c->tmp_edges.release(); c->tmp_wedges.release(); c->partial.release(); c->tmp_results.release(); c->tmp_child.release();
     c->ord_key.release(); c->ord_val.release(); c->ord_idx.release(); c->ord_fallbacks.release(); c->ord_len.release();
-    c->ord_blockmin.release(); c->ord_blockcnt.release(); c->ord_bound.release(); c->ord_count.release();
+    c->ord_blockmin.release(); c->ord_blockcnt.release(); c->ord_bound.release(); c->ord_count.release(); c->near_idx.release(); c->near_count.release(); c->probe_bound.release();
     c->tmp_lengths.release(); c->tmp_len_out.release(); c->tmp_idx.release(); c->gather.release(); c->int_child.release();
     c->setup.release(); c->track_hits.release(); c->track_eq.release(); c->track_chunk_hits.release();
     c->track_summary.release(); c->track_far.release(); c->track_skip.release(); c->track_pen.release(); c->track_chunk_pen.release(); c->need_big.release(); c->defer_list.release(); c->live_list.release(); c->hw_list.release(); c->cover_state.release(); c->work.release(); c->dstage_in.release(); c->dstage_out.release();
@@ -300,7 +300,8 @@ int ppgpu_reserve_samples(ppgpu_ctx* c, int64_t max_samples, int32_t max_vertice
         (rc = c->s_cand.reserve((size_t)524288 * 3, false, st)) || (rc = c->s_bytes.reserve(nq + 64, false, st)) || (rc = c->s_u32a.reserve(nq + 64, false, st)) ||
         (rc = c->tmp_lengths.reserve(nv * ns * 2, false, st)) ||
         (rc = c->ord_key.reserve(nv * 2 * cap, false, st)) || (rc = c->ord_val.reserve(nv * 2 * cap, false, st)) || (rc = c->ord_len.reserve(nv * 2 * cap, false, st)) ||
-        (rc = c->ord_blockmin.reserve(nv * nblk * 2, false, st)) || (rc = c->ord_blockcnt.reserve(nv * nblk, false, st)))
+        (rc = c->ord_blockmin.reserve(nv * nblk * 2, false, st)) || (rc = c->ord_blockcnt.reserve(nv * nblk, false, st)) ||
+        (rc = c->near_idx.reserve(nv * ns, false, st)) || (rc = c->near_count.reserve(nv, false, st)) || (rc = c->probe_bound.reserve(nv * 2 * PP_PROBE_GROUPS, false, st)))
         return rc;
     return PPGPU_OK;
 }
@@ -755,8 +756,9 @@ int ppgpu_select_nearest(ppgpu_ctx* c, int32_t v0, int32_t nv, int32_t k, int32_
     return PPGPU_OK;
 }
 
-// The k winners of every (vertex, radius) of vertices [0, nv) in the reference's push order -> c->ord_idx, and both Dubins lengths
-// of every (vertex, sample) -> c->tmp_lengths: lengths + block minima, bound, candidate lists, sort + replay (pp_kernels.h).
+// The k winners of every (vertex, radius) of vertices [0, nv) in the reference's push order -> c->ord_idx: probe bound, near list,
+// lengths of the near samples + block minima (-> c->tmp_lengths, one double2 per near slot), bound, candidate lists, sort + replay
+// (pp_k_expand.h).
 // Asynchronous; *c->ord_fallbacks.p counts lists that kept ascending length.
 static int launch_expand_order(ppgpu_ctx* c, int nv, int k, bool zero_fallbacks = true) {
     const long long ns = c->n_samples;
@@ -769,19 +771,25 @@ static int launch_expand_order(ppgpu_ctx* c, int nv, int k, bool zero_fallbacks 
         (rc = c->ord_len.reserve((size_t)nv * 2 * cap, false, c->stream)) || (rc = c->ord_idx.reserve((size_t)nv * 2 * k, false, c->stream)) ||
         (rc = c->ord_fallbacks.reserve(1, false, c->stream)) || (rc = c->ord_blockmin.reserve((size_t)nv * nblk * 2, false, c->stream)) ||
         (rc = c->ord_blockcnt.reserve((size_t)nv * nblk, false, c->stream)) || (rc = c->ord_bound.reserve((size_t)nv * 2, false, c->stream)) ||
-        (rc = c->ord_count.reserve((size_t)nv * 2, false, c->stream)))
+        (rc = c->ord_count.reserve((size_t)nv * 2, false, c->stream)) || (rc = c->near_idx.reserve((size_t)nv * ns, false, c->stream)) ||
+        (rc = c->near_count.reserve((size_t)nv, false, c->stream)) || (rc = c->probe_bound.reserve((size_t)nv * 2 * PP_PROBE_GROUPS, false, c->stream)))
         return rc;
     if (zero_fallbacks) HIP_TRY(hipMemsetAsync(c->ord_fallbacks.p, 0, sizeof(unsigned), c->stream));      // (ppgpu_expand_host: its unpack kernel does it)
     const int two_radii = (c->cfg.coverage_turning_radius != c->cfg.turning_radius) ? 1 : 0;
-    hipLaunchKernelGGL(pp_k_lengths_minima, dim3((unsigned)nblk, (unsigned)nv), dim3(256), 0, c->stream, c->verts.p, c->sx.p, c->sy.p, c->sh.p, ns,
-                       c->cfg.turning_radius, c->cfg.coverage_turning_radius, c->cfg.collision_checking_increment, c->tmp_lengths.p,
+    hipLaunchKernelGGL(pp_k_expand_probe, dim3((unsigned)(PP_PROBE / 256), (unsigned)nv), dim3(256), 0, c->stream, c->verts.p, c->sx.p, c->sy.p, c->sh.p, ns,
+                       c->cfg.turning_radius, c->cfg.coverage_turning_radius, c->cfg.collision_checking_increment, two_radii, c->probe_bound.p, c->near_count.p);
+    hipLaunchKernelGGL(pp_k_expand_near, dim3((unsigned)nblk, (unsigned)nv), dim3(256), 0, c->stream, c->verts.p, c->sx.p, c->sy.p, ns,
+                       c->cfg.collision_checking_increment, c->probe_bound.p, k, c->near_idx.p, c->near_count.p);
+    hipLaunchKernelGGL(pp_k_near_lengths, dim3((unsigned)nblk, (unsigned)nv), dim3(256), 0, c->stream, c->verts.p, c->sx.p, c->sy.p, c->sh.p, ns,
+                       c->near_idx.p, c->near_count.p, c->cfg.turning_radius, c->cfg.coverage_turning_radius, two_radii, c->tmp_lengths.p,
                        c->ord_blockmin.p, c->ord_blockcnt.p);
-    hipLaunchKernelGGL(pp_k_expand_bound, dim3((unsigned)(nv * 2)), dim3(256), 0, c->stream, c->ord_blockmin.p, c->ord_blockcnt.p, nblk, k,
+    hipLaunchKernelGGL(pp_k_expand_bound, dim3((unsigned)(nv * 2)), dim3(256), 0, c->stream, c->ord_blockmin.p, c->ord_blockcnt.p, nblk, c->near_count.p, k,
                        c->ord_bound.p, c->ord_count.p);
     hipLaunchKernelGGL(pp_k_expand_candidates, dim3((unsigned)nblk, (unsigned)nv), dim3(256), 0, c->stream, c->tmp_lengths.p, c->verts.p, c->sx.p,
-                       c->sy.p, ns, two_radii, c->ord_bound.p, c->ord_key.p, c->ord_val.p, c->ord_len.p, cap, c->ord_count.p);
+                       c->sy.p, ns, c->near_idx.p, c->near_count.p, two_radii, c->ord_bound.p, c->ord_key.p, c->ord_val.p, c->ord_len.p, cap, c->ord_count.p);
     hipLaunchKernelGGL(pp_k_expand_order, dim3((unsigned)(nv * 2)), dim3(256), 0, c->stream, ns, k, c->cfg.max_speed, c->cfg.time_penalty_factor,
-                       two_radii, c->ord_bound.p, c->ord_key.p, c->ord_val.p, c->ord_len.p, cap, c->ord_count.p, c->tmp_lengths.p, c->ord_idx.p, c->ord_fallbacks.p);
+                       two_radii, c->ord_bound.p, c->ord_key.p, c->ord_val.p, c->ord_len.p, cap, c->ord_count.p, c->tmp_lengths.p, c->near_idx.p,
+                       c->near_count.p, c->ord_idx.p, c->ord_fallbacks.p);
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;
 }

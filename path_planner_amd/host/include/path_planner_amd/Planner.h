@@ -8,6 +8,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -61,6 +62,7 @@ public:
             unsigned long DeviceGrowths = 0;  // device / pinned buffers the device library grew inside the call (ppgpu_growth_stats) ...
             double DeviceGrowthMs = 0;        // ... and what that took
             unsigned long RoundTrips = 0;
+            double MaxWakeMs = 0;             // the longest a context's thread took to start a round trip handed to it
             double PickMs = 0, MaxPickMs = 0;  // choosing the open vertices of the round trips (pickBatch): total and the longest single walk
             bool GridUploaded = false;        // the occupancy grid went to the device in this call (false: the device already held this map)
         } Budget;
@@ -186,6 +188,8 @@ private:
     std::condition_variable m_Wake;
     std::function<void()> m_Job;
     bool m_Busy = false, m_Quit = false;
+    std::atomic<bool> m_Running{false};    // run() .. the end of its job (wait() polls it for a while before it sleeps)
+    std::atomic<bool> m_Posted{false};     // a job is waiting (what the thread polls for a millisecond after each job before it sleeps)
     std::exception_ptr m_Error;
     void serve();
 };
