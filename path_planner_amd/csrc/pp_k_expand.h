@@ -285,34 +285,49 @@ __device__ __forceinline__ double pp_probe_bound(const double* probe_min, int v,
     const unsigned long long hit = __ballot((x < INFINITY) & (rank == k - 1));
     return hit ? pp_readlane(x, __ffsll((long long)hit) - 1) : INFINITY;
 }
+#define PP_NEAR_PER 8            // samples per thread of pp_k_expand_near (a workgroup ranks the probe minima once for 2 048 samples)
 __global__ __launch_bounds__(256) void pp_k_expand_near(const ppgpu_vertex* verts, const double* sx, const double* sy, long long ns, double inc_d,
                                                         const double* probe_min, int k, int* near_idx, int* near_count) {
-    __shared__ int wcount[4], wbase[4];
-    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+    __shared__ int wcount[PP_NEAR_PER][4], wbase[PP_NEAR_PER][4];
+    __shared__ double s_Ub;
     const int v = blockIdx.y, w = (int)(threadIdx.x >> 6), lane = pp_lane();
-    // (every wavefront ranks the vertex's 2 x 32 group minima for itself: cheaper than a launch that does it once)
-    const double Ub = (k <= PP_PROBE_GROUPS) ? fmax(pp_probe_bound(probe_min, v, 0, k), pp_probe_bound(probe_min, v, 1, k)) : INFINITY;
-    bool take = false;
-    if (s < ns) {
-        const double vx = verts[v].x, vy = verts[v].y;
-        const double d = sqrt((vx - sx[s]) * (vx - sx[s]) + (vy - sy[s]) * (vy - sy[s]));
-        take = (d > inc_d) && !(d > Ub * (1.0 + 1e-9));
+    if (w == 0) {
+        const double u = (k <= PP_PROBE_GROUPS) ? fmax(pp_probe_bound(probe_min, v, 0, k), pp_probe_bound(probe_min, v, 1, k)) : INFINITY;
+        if (lane == 0) s_Ub = u;
     }
-    const unsigned long long m = __ballot(take);
-    if (lane == 0) wcount[w] = __popcll(m);
+    __syncthreads();
+    const double Ub = s_Ub;
+    const double vx = verts[v].x, vy = verts[v].y;
+    const long long s0 = (long long)blockIdx.x * (256 * PP_NEAR_PER) + threadIdx.x;
+    bool take[PP_NEAR_PER];
+    unsigned long long m[PP_NEAR_PER];
+#pragma unroll
+    for (int j = 0; j < PP_NEAR_PER; j++) {
+        const long long s = s0 + (long long)j * 256;
+        take[j] = false;
+        if (s < ns) {
+            const double d = sqrt((vx - sx[s]) * (vx - sx[s]) + (vy - sy[s]) * (vy - sy[s]));
+            take[j] = (d > inc_d) && !(d > Ub * (1.0 + 1e-9));
+        }
+        m[j] = __ballot(take[j]);
+        if (lane == 0) wcount[j][w] = __popcll(m[j]);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        int tot = 0;
+        for (int j = 0; j < PP_NEAR_PER; j++) for (int i = 0; i < 4; i++) tot += wcount[j][i];
         int base = tot ? atomicAdd(&near_count[v], tot) : 0;
-        for (int i = 0; i < 4; i++) { wbase[i] = base; base += wcount[i]; }
+        for (int j = 0; j < PP_NEAR_PER; j++) for (int i = 0; i < 4; i++) { wbase[j][i] = base; base += wcount[j][i]; }
     }
     __syncthreads();
-    if (take) near_idx[(size_t)v * (size_t)ns + (size_t)(wbase[w] + __popcll(m & ((1ull << lane) - 1ull)))] = (int)s;
+#pragma unroll
+    for (int j = 0; j < PP_NEAR_PER; j++)
+        if (take[j]) near_idx[(size_t)v * (size_t)ns + (size_t)(wbase[j][w] + __popcll(m[j] & ((1ull << lane) - 1ull)))] = (int)(s0 + (long long)j * 256);
 }
+#define PP_NEAR_GROUP 32
 __global__ __launch_bounds__(256) void pp_k_near_lengths(const ppgpu_vertex* verts, const double* sx, const double* sy, const double* sh, long long ns,
                                                          const int* near_idx, const int* near_count, double rho, double rho_cov, int two_radii,
                                                          double* out, double* blockmin, int* blockcnt) {
-    __shared__ double m0[4], m1[4];
     const int v = blockIdx.y;
     const int n = near_count[v];
     const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -332,16 +347,19 @@ __global__ __launch_bounds__(256) void pp_k_near_lengths(const ppgpu_vertex* ver
         reinterpret_cast<double2*>(out)[(size_t)v * (size_t)ns + (size_t)slot] = o;
     }
     (void)two_radii;
-    const double a0 = pp_wave_min(l0 >= 0 ? l0 : INFINITY), a1 = pp_wave_min(l1 >= 0 ? l1 : INFINITY);
-    const int w = (int)(threadIdx.x >> 6);
-    if (pp_lane() == 0) { m0[w] = a0; m1[w] = a1; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const size_t b = (size_t)v * gridDim.x + blockIdx.x;
-        blockmin[2 * b] = fmin(fmin(m0[0], m0[1]), fmin(m0[2], m0[3]));
-        blockmin[2 * b + 1] = fmin(fmin(m1[0], m1[1]), fmin(m1[2], m1[3]));
-        const long long left = (long long)n - (long long)blockIdx.x * 256;
-        blockcnt[b] = (int)(left < 256 ? left : 256);
+    // the smallest length of every PP_NEAR_GROUP consecutive slots (a half wavefront): what pp_k_expand_bound ranks.  (Groups of 256,
+    // as for the whole sample set in round 3, leave a near list of a thousand samples with fewer groups than k: no bound at all.)
+    double a0 = l0 >= 0 ? l0 : INFINITY, a1 = l1 >= 0 ? l1 : INFINITY;
+    for (int o = PP_NEAR_GROUP / 2; o > 0; o >>= 1) {
+        a0 = fmin(a0, __shfl_xor(a0, o, PP_WAVE));
+        a1 = fmin(a1, __shfl_xor(a1, o, PP_WAVE));
+    }
+    if ((threadIdx.x & (PP_NEAR_GROUP - 1)) == 0) {
+        const size_t b = ((size_t)v * gridDim.x + blockIdx.x) * (256 / PP_NEAR_GROUP) + (threadIdx.x / PP_NEAR_GROUP);
+        blockmin[2 * b] = a0;
+        blockmin[2 * b + 1] = a1;
+        const long long left = (long long)n - slot;
+        blockcnt[b] = (int)(left < PP_NEAR_GROUP ? (left > 0 ? left : 0) : PP_NEAR_GROUP);
     }
 }
 #define PP_BOUND_CAP 512             // values the bound kernel ranks: block minima, merged into groups of consecutive blocks when there are more
@@ -354,7 +372,7 @@ __global__ __launch_bounds__(256) void pp_k_expand_bound(const double* blockmin,
     const int tid = (int)threadIdx.x;
     if (tid == 0) { valid = 0; U = INFINITY; cand_count[vr] = 0; }
     __syncthreads();
-    const int nblk = (near_count[v] + 255) / 256;
+    const int nblk = (near_count[v] + PP_NEAR_GROUP - 1) / PP_NEAR_GROUP;
     const int per = (nblk + PP_BOUND_CAP - 1) / PP_BOUND_CAP;            // blocks per ranked value
     const int nval = per > 0 ? (nblk + per - 1) / per : 0;
     int c = 0;

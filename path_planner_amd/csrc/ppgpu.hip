@@ -300,7 +300,7 @@ int ppgpu_reserve_samples(ppgpu_ctx* c, int64_t max_samples, int32_t max_vertice
         (rc = c->s_cand.reserve((size_t)524288 * 3, false, st)) || (rc = c->s_bytes.reserve(nq + 64, false, st)) || (rc = c->s_u32a.reserve(nq + 64, false, st)) ||
         (rc = c->tmp_lengths.reserve(nv * ns * 2, false, st)) ||
         (rc = c->ord_key.reserve(nv * 2 * cap, false, st)) || (rc = c->ord_val.reserve(nv * 2 * cap, false, st)) || (rc = c->ord_len.reserve(nv * 2 * cap, false, st)) ||
-        (rc = c->ord_blockmin.reserve(nv * nblk * 2, false, st)) || (rc = c->ord_blockcnt.reserve(nv * nblk, false, st)) ||
+        (rc = c->ord_blockmin.reserve(nv * nblk * 2 * (256 / PP_NEAR_GROUP), false, st)) || (rc = c->ord_blockcnt.reserve(nv * nblk * (256 / PP_NEAR_GROUP), false, st)) ||
         (rc = c->near_idx.reserve(nv * ns, false, st)) || (rc = c->near_count.reserve(nv, false, st)) || (rc = c->probe_bound.reserve(nv * 2 * PP_PROBE_GROUPS, false, st)))
         return rc;
     return PPGPU_OK;
@@ -769,8 +769,8 @@ static int launch_expand_order(ppgpu_ctx* c, int nv, int k, bool zero_fallbacks 
     if ((rc = c->tmp_lengths.reserve((size_t)nv * ns * 2, false, c->stream)) ||
         (rc = c->ord_key.reserve((size_t)nv * 2 * cap, false, c->stream)) || (rc = c->ord_val.reserve((size_t)nv * 2 * cap, false, c->stream)) ||
         (rc = c->ord_len.reserve((size_t)nv * 2 * cap, false, c->stream)) || (rc = c->ord_idx.reserve((size_t)nv * 2 * k, false, c->stream)) ||
-        (rc = c->ord_fallbacks.reserve(1, false, c->stream)) || (rc = c->ord_blockmin.reserve((size_t)nv * nblk * 2, false, c->stream)) ||
-        (rc = c->ord_blockcnt.reserve((size_t)nv * nblk, false, c->stream)) || (rc = c->ord_bound.reserve((size_t)nv * 2, false, c->stream)) ||
+        (rc = c->ord_fallbacks.reserve(1, false, c->stream)) || (rc = c->ord_blockmin.reserve((size_t)nv * nblk * 2 * (256 / PP_NEAR_GROUP), false, c->stream)) ||
+        (rc = c->ord_blockcnt.reserve((size_t)nv * nblk * (256 / PP_NEAR_GROUP), false, c->stream)) || (rc = c->ord_bound.reserve((size_t)nv * 2, false, c->stream)) ||
         (rc = c->ord_count.reserve((size_t)nv * 2, false, c->stream)) || (rc = c->near_idx.reserve((size_t)nv * ns, false, c->stream)) ||
         (rc = c->near_count.reserve((size_t)nv, false, c->stream)) || (rc = c->probe_bound.reserve((size_t)nv * 2 * PP_PROBE_GROUPS, false, c->stream)))
         return rc;
@@ -778,12 +778,12 @@ static int launch_expand_order(ppgpu_ctx* c, int nv, int k, bool zero_fallbacks 
     const int two_radii = (c->cfg.coverage_turning_radius != c->cfg.turning_radius) ? 1 : 0;
     hipLaunchKernelGGL(pp_k_expand_probe, dim3((unsigned)(PP_PROBE / 256), (unsigned)nv), dim3(256), 0, c->stream, c->verts.p, c->sx.p, c->sy.p, c->sh.p, ns,
                        c->cfg.turning_radius, c->cfg.coverage_turning_radius, c->cfg.collision_checking_increment, two_radii, c->probe_bound.p, c->near_count.p);
-    hipLaunchKernelGGL(pp_k_expand_near, dim3((unsigned)nblk, (unsigned)nv), dim3(256), 0, c->stream, c->verts.p, c->sx.p, c->sy.p, ns,
+    hipLaunchKernelGGL(pp_k_expand_near, dim3((unsigned)((ns + 256 * PP_NEAR_PER - 1) / (256 * PP_NEAR_PER)), (unsigned)nv), dim3(256), 0, c->stream, c->verts.p, c->sx.p, c->sy.p, ns,
                        c->cfg.collision_checking_increment, c->probe_bound.p, k, c->near_idx.p, c->near_count.p);
     hipLaunchKernelGGL(pp_k_near_lengths, dim3((unsigned)nblk, (unsigned)nv), dim3(256), 0, c->stream, c->verts.p, c->sx.p, c->sy.p, c->sh.p, ns,
                        c->near_idx.p, c->near_count.p, c->cfg.turning_radius, c->cfg.coverage_turning_radius, two_radii, c->tmp_lengths.p,
                        c->ord_blockmin.p, c->ord_blockcnt.p);
-    hipLaunchKernelGGL(pp_k_expand_bound, dim3((unsigned)(nv * 2)), dim3(256), 0, c->stream, c->ord_blockmin.p, c->ord_blockcnt.p, nblk, c->near_count.p, k,
+    hipLaunchKernelGGL(pp_k_expand_bound, dim3((unsigned)(nv * 2)), dim3(256), 0, c->stream, c->ord_blockmin.p, c->ord_blockcnt.p, nblk * (256 / PP_NEAR_GROUP), c->near_count.p, k,
                        c->ord_bound.p, c->ord_count.p);
     hipLaunchKernelGGL(pp_k_expand_candidates, dim3((unsigned)nblk, (unsigned)nv), dim3(256), 0, c->stream, c->tmp_lengths.p, c->verts.p, c->sx.p,
                        c->sy.p, ns, c->near_idx.p, c->near_count.p, two_radii, c->ord_bound.p, c->ord_key.p, c->ord_val.p, c->ord_len.p, cap, c->ord_count.p);

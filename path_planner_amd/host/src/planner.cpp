@@ -814,7 +814,11 @@ bool GpuAStarPlanner::expand(int source) {
                     }
                     if (p->sources.empty()) break;
                     GpuContext& pc = freeContext();
-                    if (m_Config.deadlineGuard() && now() + pc.predictTrip((double)m_NumSamples) >= m_EndTime - m_Ctx->guardMargin()) break;
+                    // (a prefetch shares the device with the round trips already in flight: at worst it ends after all of them, one
+                    // predicted round trip each — with eight contexts and no such allowance a cycle's last prefetches queued up behind one
+                    // another and the drain at the end of the loop took 6 ms)
+                    if (m_Config.deadlineGuard() &&
+                        now() + pc.predictTrip((double)m_NumSamples) * (double)(m_InFlight.size() + 1) >= m_EndTime - m_Ctx->guardMargin()) break;
                     submitBatch(std::move(p), pc);
                 }
                 harvestBatch(mine, true);
