@@ -62,6 +62,7 @@ public:
             unsigned long DeviceGrowths = 0;  // device / pinned buffers the device library grew inside the call (ppgpu_growth_stats) ...
             double DeviceGrowthMs = 0;        // ... and what that took
             unsigned long RoundTrips = 0;
+            unsigned long StrideRetries = 0;  // round trips repeated because a child's ribbon list did not fit the stride they were costed with
             double MaxWakeMs = 0;             // the longest a context's thread took to start a round trip handed to it
             double PickMs = 0, MaxPickMs = 0;  // choosing the open vertices of the round trips (pickBatch): total and the longest single walk
             bool GridUploaded = false;        // the occupancy grid went to the device in this call (false: the device already held this map)
@@ -250,6 +251,7 @@ private:
     void noteOperation(int kind, double startedAt, double predicted, double actual);
     double m_PlanEntry = 0;                // steady-clock time of plan()'s entry
     bool m_DeadlineStop = false;           // aStar() stopped on the deadline guard: the big loop ends too
+    int m_StrideFloor = 0;                 // child-ribbon stride a round trip of this plan() had to be repeated with: later ones start there
     int aStar(double endTime);
     void addSamples(long n);
     int depth(int v) const;

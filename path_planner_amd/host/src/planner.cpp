@@ -577,6 +577,7 @@ struct GpuAStarPlanner::Batch {
     std::vector<ppgpu_vertex> verts;
     std::vector<double> pool, nearest;
     int maxParent = 0;
+    int strideFloor = 0, strideUsed = 0, retries = 0;      // (the child stride earlier round trips of this plan() needed; what this one ended with)
     GpuContext* ctx = nullptr;
     bool threaded = false;                 // running on ctx's thread (wait() before anything else touches ctx)
     // filled by run()
@@ -619,7 +620,7 @@ void GpuAStarPlanner::runBatch(Batch& b, int k) {
     ppgpu_ctx* h = ctx.handle();
     const int M = (int)b.sources.size();
     const int64_t cap = ppgpu_expand_capacity(M, k);
-    int stride = std::min(kRibbonStride, b.maxParent + 6);
+    int stride = std::min(kRibbonStride, std::max(b.maxParent + 6, b.strideFloor));
     b.started = HostProfile::now();
     for (;;) {
         b.block = ctx.takeTripBlock((size_t)cap, (size_t)cap * stride * 4);      // (the call fills the first n entries; nothing is read beyond them)
@@ -629,13 +630,18 @@ void GpuAStarPlanner::runBatch(Batch& b, int k) {
                               b.block->edges.get(), res, b.block->child.get(), stride) != PPGPU_OK)
             throw std::runtime_error(std::string("ppgpu_expand_host: ") + ppgpu_last_error());
         b.edgesCosted += (unsigned long)b.n;
-        bool retry = false;
+        // some child does not fit: again with room for the longest list the records report (round 4: the second pass used to go straight
+        // to the device's per-vertex capacity of 64 — 5 MB of child slots to download for 2 500 edges — and such a trip took 5-9 ms where
+        // its neighbours took 0.6: the largest under-predictions of the deadline guard)
+        int need = 0;
         if (stride < kRibbonStride)
-            for (int64_t i = 0; i < b.n && !retry; i++)
-                retry = (res[i].flags & PPGPU_F_RIBBON_OVF) && (int)((res[i].info >> 8) & 0xff) > stride;
-        if (!retry) break;
-        stride = kRibbonStride;       // some child does not fit: again at the device's full per-vertex capacity
+            for (int64_t i = 0; i < b.n; i++)
+                if (res[i].flags & PPGPU_F_RIBBON_OVF) need = std::max(need, (int)((res[i].info >> 8) & 0xff));
+        if (need <= stride) break;
+        stride = std::min(kRibbonStride, need + 2);
+        b.retries++;
     }
+    b.strideUsed = stride;
     b.took = HostProfile::now() - b.started;
 }
 
@@ -644,6 +650,7 @@ void GpuAStarPlanner::submitBatch(std::shared_ptr<Batch> bp, GpuContext& ctx) {
     Batch& b = *bp;
     b.ctx = &ctx;
     b.samples = (double)m_NumSamples;
+    b.strideFloor = m_StrideFloor;
     b.predicted = ctx.predictTrip(b.samples);
     packBatch(b);
     const int k = m_Config.branchingFactor();
@@ -673,6 +680,7 @@ void GpuAStarPlanner::harvestBatch(Batch* bp, bool keep) {
         b.ctx->wait();                         // rethrows what the round trip threw
     }
     noteOperation(1, b.started, b.predicted, b.took);
+    if (b.retries > 0) { m_StrideFloor = std::max(m_StrideFloor, b.strideUsed); m_Stats.Budget.StrideRetries += (unsigned long)b.retries; }
     if (b.threaded) m_Stats.Budget.MaxWakeMs = std::max(m_Stats.Budget.MaxWakeMs, 1e3 * (b.started - b.posted));
     b.ctx->noteTrip(b.samples, b.took);
     if (b.predicted > 0) m_Ctx->noteExcess(b.took - b.predicted);     // (the guard's margin is the first context's)
@@ -925,6 +933,7 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
     m_Speculated.clear();
     drainInFlight();
     m_NumSamples = 0;
+    m_StrideFloor = 0;
     m_DeadlineStop = false;
     ppgpu_ctx* h = m_Ctx->handle();
     uint64_t growthsBefore = 0;

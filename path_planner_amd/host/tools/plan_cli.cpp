@@ -179,12 +179,12 @@ int main(int argc, char** argv) {
                                  "\"loop_end_ms\": %.3f, \"total_ms\": %.3f, \"last_op\": %d, \"last_op_start_ms\": %.3f, \"last_op_predicted_ms\": %.3f, "
                                  "\"last_op_actual_ms\": %.3f, \"margin_ms\": %.3f, \"max_trip_ms\": %.3f, \"worst_under_prediction_ms\": %.3f, \"node_regrowths\": %lu, "
                                  "\"node_regrowth_ms\": %.3f, \"device_growths\": %lu, \"device_growth_ms\": %.3f, \"grid_uploaded\": %s, \"pick_ms\": %.3f, \"max_pick_ms\": %.3f, "
-                                 "\"order_fallbacks\": %lu, \"max_wake_ms\": %.3f}\n",
+                                 "\"order_fallbacks\": %lu, \"max_wake_ms\": %.3f, \"stride_retries\": %lu}\n",
                                  cyc, wall.back(), (unsigned long)st.Iterations, st.FirstGoalIteration, (unsigned long)st.Samples, (unsigned long)st.Expanded,
                                  (unsigned long)st.EdgesCosted, b.RoundTrips, (unsigned long)st.DeadlineStops, st.Plan.empty() ? "true" : "false", startHit ? "true" : "false",
                                  b.PrologueMs, b.LoopEndMs, b.TotalMs, b.LastOpKind, b.LastOpStartMs, b.LastOpPredictedMs, b.LastOpActualMs, b.MarginMs, b.MaxTripMs,
                                  b.WorstUnderPredictionMs, b.NodeRegrowths, b.NodeRegrowthMs, b.DeviceGrowths, b.DeviceGrowthMs, b.GridUploaded ? "true" : "false", b.PickMs, b.MaxPickMs,
-                                 (unsigned long)st.OrderFallbacks, b.MaxWakeMs);
+                                 (unsigned long)st.OrderFallbacks, b.MaxWakeMs, b.StrideRetries);
                 if (cyc > 0 && wall.back() >= 1e3 * timeRemaining)      // late: what was the cycle doing when the budget ran out?
                     std::fprintf(stderr, "[replan] cycle %d LATE: %.3f ms of %.1f | loop left at %.3f, last op kind %d started %.3f predicted %.3f took %.3f (margin %.3f) | "
                                  "max trip %.3f, worst under-prediction %.3f | node regrowths %lu (%.3f ms), device growths %lu (%.3f ms), prologue %.3f | picks %.3f ms (longest %.3f), "
