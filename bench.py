@@ -217,8 +217,11 @@ def run_rank(args):
 
     for _ in range(args.warmup):
         step()
-    fence()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    import gc
+    gc.collect()
+    gc.disable()                     # (the timed steps are driven from Python: no collector pause inside the timed region)
+    fence()
     t0 = time.perf_counter()
     edges = 0
     marks[0].record(stream)
@@ -227,6 +230,7 @@ def run_rank(args):
         marks[k + 1].record(stream)
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     step_ms = np.array([marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)])
     # (solve, pose, cover, heuristic) ms of the last timed steps' launches, from the HIP events the library recorded between its
     # kernels on this stream inside the timed region (a ring of 8 sets: read back here, so no step waited for its own events)

@@ -1457,6 +1457,7 @@ struct HsaApi {
     decltype(&hsa_signal_store_relaxed) signal_store_relaxed = nullptr;
     decltype(&hsa_signal_wait_scacquire) signal_wait_scacquire = nullptr;
     decltype(&hsa_amd_memory_async_copy) memory_async_copy = nullptr;
+    decltype(&hsa_amd_pointer_info) pointer_info = nullptr;
     std::string error;
     bool ok = false;
 };
@@ -1474,7 +1475,8 @@ const HsaApi& hsa_api() {
         a.signal_store_relaxed = (decltype(a.signal_store_relaxed))dlsym(lib, "hsa_signal_store_relaxed");
         a.signal_wait_scacquire = (decltype(a.signal_wait_scacquire))dlsym(lib, "hsa_signal_wait_scacquire");
         a.memory_async_copy = (decltype(a.memory_async_copy))dlsym(lib, "hsa_amd_memory_async_copy");
-        if (!a.iterate_agents || !a.agent_get_info || !a.signal_create || !a.signal_destroy || !a.signal_store_relaxed || !a.signal_wait_scacquire || !a.memory_async_copy) {
+        a.pointer_info = (decltype(a.pointer_info))dlsym(lib, "hsa_amd_pointer_info");
+        if (!a.iterate_agents || !a.agent_get_info || !a.signal_create || !a.signal_destroy || !a.signal_store_relaxed || !a.signal_wait_scacquire || !a.memory_async_copy || !a.pointer_info) {
             a.error = "libhsa-runtime64 lacks one of the entry points ppgpu_copy_engine_read needs";
             return;
         }
@@ -1523,8 +1525,19 @@ extern "C" int ppgpu_copy_engine_read(ppgpu_ctx* c, void* h_pinned_dst, const vo
     if (c->copy_pending && (rc = ppgpu_copy_engine_wait(c))) return rc;          // one copy in flight per handle
     if (!c->hsa_signal) {
         AgentScan s{&a, c->device, 0, {}, {}, false, false};
-        if (a.iterate_agents(scan_agent, &s) != HSA_STATUS_SUCCESS || !s.have_gpu || !s.have_cpu)
-            return fail(PPGPU_EHIP, "copy_engine_read: cannot find the HSA agents of device " + std::to_string(c->device) + " and of the host");
+        if (a.iterate_agents(scan_agent, &s) != HSA_STATUS_SUCCESS || !s.have_cpu)
+            return fail(PPGPU_EHIP, "copy_engine_read: cannot find the HSA agent of the host");
+        // the GPU agent is the one that OWNS the source allocation (a HIP device ordinal is not an index into HSA's agent list once
+        // HIP_VISIBLE_DEVICES reorders or masks devices)
+        hsa_amd_pointer_info_t info;
+        std::memset(&info, 0, sizeof(info));
+        info.size = sizeof(info);
+        if (a.pointer_info(d_src, &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || info.type == HSA_EXT_POINTER_TYPE_UNKNOWN)
+            return fail(PPGPU_EHIP, "copy_engine_read: the source is not a device allocation HSA knows");
+        hsa_device_type_t owner_type;
+        if (a.agent_get_info(info.agentOwner, HSA_AGENT_INFO_DEVICE, &owner_type) != HSA_STATUS_SUCCESS || owner_type != HSA_DEVICE_TYPE_GPU)
+            return fail(PPGPU_EHIP, "copy_engine_read: the source allocation is not owned by a GPU agent");
+        s.gpu = info.agentOwner; s.have_gpu = true;
         hsa_signal_t sig;
         if (a.signal_create(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return fail(PPGPU_EHIP, "copy_engine_read: hsa_signal_create failed");
         c->hsa_gpu = s.gpu.handle; c->hsa_cpu = s.cpu.handle; c->hsa_signal = sig.handle;
