@@ -131,16 +131,47 @@ __global__ __launch_bounds__(PP_H_WPB * 64) void pp_k_heuristic_dubins(PPParams 
     for (PP_EACH_EDGE(e, 4, PP_Q_HEUR, p.n_edges, PP_Q_CHUNK_HEUR))
         pp_heuristic_edge<true, PP_TSP_MAX>(p, e, lds_all[wave]);
 }
-// TspPointRobotNoSplitKRibbons on child lists of 9..12 ribbons (rare: a vertex whose ribbons were split many times)
+// TspPointRobotNoSplitKRibbons on child lists of 9..12 ribbons (rare: a vertex whose ribbons were split many times).  A whole
+// WORKGROUP of sixteen wavefronts per such edge (round 4): every wave builds the same tables and takes every sixteenth pass of 64
+// prefixes, the smallest of their minima is the minimum (exact, as in pp_k_heuristic_listed).  One wave per edge took a
+// millisecond per edge — up to two million prefixes — and in a planner round trip, where such an edge comes alone, that
+// millisecond was the round trip's: the deadline guard's largest under-predictions.
 #define PP_BIG_GRID 1024
-__global__ __launch_bounds__(PP_H_WPB * 64) void pp_k_heuristic_big(PPParams p) {
-    __shared__ double lds_all[PP_H_WPB][PPTsp<PP_TSP_MAX_BIG>::LDS];
+#define PP_BIG_WPB 16
+__global__ __launch_bounds__(PP_BIG_WPB * 64) void pp_k_heuristic_big(PPParams p) {
+    __shared__ double lds_all[PP_BIG_WPB][PPTsp<PP_TSP_MAX_BIG>::LDS];
+    __shared__ double s_part[PP_BIG_WPB];
     if (pp_const_i32(p.need_big)[0] == 0) return;            // almost always: no child list beyond 8 ribbons in this launch
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // a modest grid whose waves stride over the edges (ppgpu.hip: at most PP_BIG_GRID workgroups): the launch that finds nothing to do —
-    // nearly every one — used to start a workgroup per four edges to learn it, 14 us at config 3
-    for (long long e = (long long)blockIdx.x * PP_H_WPB + wave; e < p.n_edges; e += (long long)gridDim.x * PP_H_WPB)
-        pp_heuristic_edge<false, PP_TSP_MAX_BIG>(p, e, lds_all[wave]);
+    const int lane = pp_lane();
+    double* pts = lds_all[wave];
+    const bool tsp = p.heuristic != PPGPU_H_MAX_DISTANCE;
+    // a modest grid whose workgroups stride over the edges (ppgpu.hip: at most PP_BIG_GRID workgroups)
+    for (long long e = (long long)blockIdx.x; e < p.n_edges; e += (long long)gridDim.x) {
+        ppgpu_edge_result* rec = p.out + e;
+        const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)rec->flags);
+        if (flags & PPGPU_F_THROWS) continue;
+        const int nrib = (int)((__builtin_amdgcn_readfirstlane((int)rec->info) >> 8) & 0xff);
+        if (!(tsp && nrib <= p.stride && pp_tsp_big_ok(p.heuristic, p.tsp_k, nrib))) continue;      // (pp_heuristic_edge's own gate for this pass)
+        const double endX = rec->end_x, endY = rec->end_y, g = rec->g;
+        if (lane == 0) { pts[0] = endX; pts[1] = endY; }
+        if (lane < nrib) {
+            const double* c = p.child + ((size_t)e * p.stride + lane) * 4;
+            pts[2 * (1 + 2 * lane)] = c[0]; pts[2 * (1 + 2 * lane) + 1] = c[1];
+            pts[2 * (2 + 2 * lane)] = c[2]; pts[2 * (2 + 2 * lane) + 1] = c[3];
+        }
+        pp_wave_lds_fence();
+        const double part = pp_h_point_from_pts<PP_TSP_MAX_BIG>(p.heuristic, p.tsp_k, p.ribw, pts, nrib, (unsigned)wave, (unsigned)PP_BIG_WPB);
+        if (lane == 0) s_part[wave] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double hdist = s_part[0];
+            for (int w = 1; w < PP_BIG_WPB; w++) hdist = fmin(hdist, s_part[w]);
+            const double h = hdist / p.max_speed * p.tpf;
+            rec->h = h; rec->f = g + h;
+        }
+        __syncthreads();
+    }
 }
 
 // The edges pp_k_cover_finish listed (a TSP enumeration of 7 or 8 child ribbons: up to 32 768 leaves): Vertex::computeApproxToGo from

@@ -991,8 +991,8 @@ static int launch_cost(ppgpu_ctx* c, PPParams& p) {
     // child lists of 9..12 ribbons under the K variant: a second pass that touches only those edges (the others cost it one
     // 8-byte read each)
     if (p.heuristic == PPGPU_H_TSP_POINT_K) {
-        const long long need = (total + PP_H_WPB - 1) / PP_H_WPB;
-        hipLaunchKernelGGL(pp_k_heuristic_big, dim3((unsigned)(need < PP_BIG_GRID ? need : PP_BIG_GRID)), dim3(PP_H_WPB * 64), 0, c->stream, p);
+        const long long need = total;                 // (a workgroup per edge, striding)
+        hipLaunchKernelGGL(pp_k_heuristic_big, dim3((unsigned)(need < PP_BIG_GRID ? need : PP_BIG_GRID)), dim3(PP_BIG_WPB * 64), 0, c->stream, p);
     }
     if (forked) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     c->last_launch_edges = total; c->last_launch_packed = p.live_list != nullptr;
@@ -1130,7 +1130,8 @@ int ppgpu_heuristic_host(ppgpu_ctx* c, int32_t n, const double* poses3, const in
     const dim3 grid((unsigned)((n + PP_H_WPB - 1) / PP_H_WPB)), block(PP_H_WPB * 64);   // n is small: never more than fits
     if (p.heuristic == PPGPU_H_TSP_DUBINS_ALL || p.heuristic == PPGPU_H_TSP_DUBINS_K) hipLaunchKernelGGL(pp_k_heuristic_dubins, grid, block, 0, c->stream, p);
     else hipLaunchKernelGGL(pp_k_heuristic, grid, block, 0, c->stream, p);
-    if (p.heuristic == PPGPU_H_TSP_POINT_K) hipLaunchKernelGGL(pp_k_heuristic_big, grid, block, 0, c->stream, p);
+    if (p.heuristic == PPGPU_H_TSP_POINT_K)
+        hipLaunchKernelGGL(pp_k_heuristic_big, dim3((unsigned)(n < PP_BIG_GRID ? n : PP_BIG_GRID)), dim3(PP_BIG_WPB * 64), 0, c->stream, p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(rec.data(), c->tmp_results.p, rec.size() * sizeof(ppgpu_edge_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

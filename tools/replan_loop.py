@@ -15,7 +15,7 @@ init = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
 spec = int(sys.argv[4]) if len(sys.argv) > 4 and int(sys.argv[4]) > 0 else None
 streams = int(sys.argv[5]) if len(sys.argv) > 5 else 2       # device contexts (HIP streams) on the one GPU
 w = workloads.config3()
-w.obst = workloads.obstacles(32, 3, 204.8, time=float(w.start5[4]))      # uniform in the map: no free disc around the start
+w.obst = workloads.obstacles(32, int(os.environ.get("REPLAN_OBST_SEED", "3")), 204.8, time=float(w.start5[4]))      # uniform in the map: no free disc around the start
 with tempfile.TemporaryDirectory() as d:
     mp = os.path.join(d, "grid.map"); _write_map(w.grid, w.res, mp)
     sc = os.path.join(d, "s.txt")
