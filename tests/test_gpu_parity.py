@@ -876,14 +876,15 @@ def test_allreduce_best_on_a_one_rank_communicator(torch_cuda):
 def test_heuristic_host_matches_oracle(torch_cuda):
     """ppgpu_heuristic_host = Vertex::computeApproxToGo for a pose and its ribbons, all five heuristics, against
     RibbonManager::approximateDistanceUntilDone as restated in the oracle (bit-identical for the point-robot heuristics: the
-    arithmetic is sqrt, +, -, fmin, fmax only)."""
+    arithmetic is sqrt, +, -, fmin, fmax only).  Lists of 9 to 11 ribbons under the K variant go through pp_k_heuristic_big: sixteen
+    wavefronts per list with the exact branch-and-bound cut (round 4) against the oracle's exhaustive recursion."""
     import oracle as orc
     from path_planner_amd import api
     from path_planner_amd.types import make_config, H_MAX_DISTANCE, H_TSP_POINT_ALL, H_TSP_POINT_K, H_TSP_DUBINS_ALL, H_TSP_DUBINS_K, F_RIBBON_OVF
     rng = np.random.default_rng(8)
     orc.O.ppo_set_ribbon_width(2.0)
     try:
-        for heur, K, nmax in ((H_MAX_DISTANCE, 2, 40), (H_TSP_POINT_ALL, 2, 6), (H_TSP_POINT_K, 1, 9), (H_TSP_POINT_K, 2, 9), (H_TSP_POINT_K, 3, 8),
+        for heur, K, nmax in ((H_MAX_DISTANCE, 2, 40), (H_TSP_POINT_ALL, 2, 6), (H_TSP_POINT_K, 1, 9), (H_TSP_POINT_K, 2, 9), (H_TSP_POINT_K, 3, 8), (H_TSP_POINT_K, 2, 11),
                               (H_TSP_DUBINS_ALL, 2, 4), (H_TSP_DUBINS_K, 2, 4)):
             cfg = make_config(heuristic=heur, tsp_k=K, ribbon_width=2.0, max_speed=2.0, heuristic_turning_radius=6.0)
             ctx = api.Context(0)

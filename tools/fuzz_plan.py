@@ -219,6 +219,13 @@ def one_round(rng, rid, d, verbose=True):
             ok, why = classify_tie(*edge_dumps(w, sc, mp, t_start, dt, calls, init, world, prev=prev, start=start), same_length=not counts)
             why = (counts + " " + why).strip()
             v = "tie" if ok else "MISMATCH"
+        elif v.startswith("plan_f:"):
+            # another plan of ANOTHER cost: inside a budget of clock calls two searches that part at an explained tie go on to expand
+            # different vertices and may end with different incumbents.  Accepted only when the edge dumps agree up to a divergence of
+            # one of the explained kinds (classify_tie); reported with both costs
+            ok, why2 = classify_tie(*edge_dumps(w, sc, mp, t_start, dt, calls, init, world, prev=prev, start=start), same_length=False)
+            why = v + " | " + why2
+            v = "tie" if ok else "MISMATCH"
         elif v != "ok":
             why, v = v, "MISMATCH"
         out.append((which, v, why))
