@@ -336,8 +336,8 @@ void GpuAStarPlanner::pushVertexQueue(int vi) {   // SamplingBasedPlanner.cpp:7-
     if (v.h == -1) throw std::runtime_error("Fetching unset approx to go (h)");
     if (m_Best >= 0 && m_Nodes[m_Best].f() < v.f()) return;
     if (m_Best >= 0 && m_Nodes[m_Best].f() == v.f() && goalCondition(v)) return;
-    m_Queue.push_back(vi);
-    std::push_heap(m_Queue.begin(), m_Queue.end(), [&](int a, int b) { return m_Nodes[a].f() > m_Nodes[b].f(); });
+    m_Queue.push_back(QEntry{v.f(), vi});
+    std::push_heap(m_Queue.begin(), m_Queue.end(), [](const QEntry& a, const QEntry& b) { return a.f > b.f; });
     visualizeVertex(vi, "vertex", false);
     m_Stats.Generated++;
 }
@@ -411,8 +411,8 @@ void GpuAStarPlanner::visualizeSamples() {   // AStarPlanner.cpp:103-108: every 
 
 int GpuAStarPlanner::popVertexQueue() {   // :21-27
     if (m_Queue.empty()) throw std::out_of_range("Trying to pop an empty vertex queue");
-    std::pop_heap(m_Queue.begin(), m_Queue.end(), [&](int a, int b) { return m_Nodes[a].f() > m_Nodes[b].f(); });
-    int r = m_Queue.back();
+    std::pop_heap(m_Queue.begin(), m_Queue.end(), [](const QEntry& a, const QEntry& b) { return a.f > b.f; });
+    int r = m_Queue.back().v;
     m_Queue.pop_back();
     return r;
 }
@@ -768,7 +768,7 @@ void GpuAStarPlanner::pickBatch(int source, std::vector<int>& batch) {
     typedef std::pair<double, size_t> Entry;                  // (f, position in m_Queue)
     auto worse = [](const Entry& a, const Entry& b) { return a.first > b.first; };
     std::vector<Entry> frontier;
-    frontier.emplace_back(m_Nodes[m_Queue[0]].f(), 0);
+    frontier.emplace_back(m_Queue[0].f, 0);
     std::vector<std::pair<double, int>> cand;                 // (f, node)
     double lastF = 0, goalF = INFINITY;
     size_t visited = 0;
@@ -779,12 +779,12 @@ void GpuAStarPlanner::pickBatch(int source, std::vector<int>& batch) {
         frontier.pop_back();
         if (cand.size() >= want && e.first > lastF) break;    // everything left is worse than what is already taken
         if (e.first > goalF || ++visited > maxVisited) break; // ... or than a goal already in the list; or the walk has gone far enough
-        const int v = m_Queue[e.second];
+        const int v = m_Queue[e.second].v;
         const bool goal = goalCondition(m_Nodes[v]);
         if (goal) goalF = std::min(goalF, e.first);
         if (!goal && !m_Speculated.count(v) && !m_InFlightOf.count(v)) { cand.emplace_back(e.first, v); lastF = std::max(lastF, e.first); }
         for (size_t c = 2 * e.second + 1; c <= 2 * e.second + 2 && c < m_Queue.size(); c++) {
-            frontier.emplace_back(m_Nodes[m_Queue[c]].f(), c);
+            frontier.emplace_back(m_Queue[c].f, c);
             std::push_heap(frontier.begin(), frontier.end(), worse);
         }
     }
@@ -999,7 +999,7 @@ Planner::Stats GpuAStarPlanner::plan(const RibbonManager& ribbonManager, const S
                 const unsigned long gen = m_Stats.Generated;
                 costStateEdges(lastPlanEnd, t, c, si);
                 m_Queue.resize(q);   // connect + computeTrueCost only: the reference does not push here
-                std::make_heap(m_Queue.begin(), m_Queue.end(), [&](int a, int b) { return m_Nodes[a].f() > m_Nodes[b].f(); });
+                std::make_heap(m_Queue.begin(), m_Queue.end(), [](const QEntry& a, const QEntry& b) { return a.f > b.f; });
                 m_Stats.Generated = gen;
             } else {
                 ppgpu_wrapper_edge we{};
