@@ -228,6 +228,10 @@ private:
     struct Costed {
         std::shared_ptr<TripBlock> block;     // the round trip that costed them
         size_t first = 0, count = 0;          // this vertex's edges: [first, first + count) of the block, in push order
+        // children built ahead while the planner's thread waited for a round trip (prebuildWhileWaiting): kids[i] is edge first + i's
+        // child vertex, complete, where ready[i] is set; the others are left to expand() (never pushed, or the planner's own judgement)
+        std::vector<Node> kids;
+        std::vector<unsigned char> ready;
     };
     std::unordered_map<int, Costed> m_Speculated;
 
@@ -251,6 +255,8 @@ private:
     double m_EndTime = 0;                  // the deadline of this plan() call, on the injected clock
     int costEdgeList(const std::vector<uint64_t>& edges, int maxParentRibbons, std::vector<::ppgpu_edge_result>& res, std::vector<double>& child);
     Node makeChild(int source, unsigned cfgBits, const ::ppgpu_edge_result& r, const double* childRibbons, int stride);
+    void fillChild(Node& c, int source, unsigned cfgBits, const ::ppgpu_edge_result& r, const double* childRibbons) const;
+    void prebuildWhileWaiting(GpuContext& busy);
     void addNode(Node&& n);                // m_Nodes.push_back that counts and times reallocations (Stats::Budget)
     void noteOperation(int kind, double startedAt, double predicted, double actual);
     double m_PlanEntry = 0;                // steady-clock time of plan()'s entry

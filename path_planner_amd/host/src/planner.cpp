@@ -477,8 +477,19 @@ GpuAStarPlanner::Node GpuAStarPlanner::makeChild(int source, unsigned cfgBits, c
     if ((r.flags & (PPGPU_F_DUBINS_ERR | PPGPU_F_RIBBON_LOST)) || ((r.flags & PPGPU_F_RIBBON_OVF) && !hostHeuristic))
         throw std::runtime_error("Edge cost evaluation exceeded a device capacity (flags " + std::to_string(r.flags) + ", child ribbons " +
                                  std::to_string(nChild) + ", parent ribbons " + std::to_string(m_Nodes[source].ribbons.count()) + ")");
-    const Node& src = m_Nodes[source];
     Node c;
+    fillChild(c, source, cfgBits, r, childRibbons);
+    if (hostHeuristic) {       // Vertex::computeApproxToGo (Vertex.cpp:49-64): the child's heading goes where the callee says yaw
+        c.h = c.ribbons.approximateDistanceUntilDone(c.state.x(), c.state.y(), c.state.heading()) / m_Config.maxSpeed() * kTimePenaltyFactor;
+        m_Stats.HostHeuristics++;
+    }
+    return c;
+}
+
+// the child vertex of one costed edge, from its record (nothing here throws or counts: prebuildWhileWaiting uses it too)
+void GpuAStarPlanner::fillChild(Node& c, int source, unsigned cfgBits, const ppgpu_edge_result& r, const double* childRibbons) const {
+    const Node& src = m_Nodes[source];
+    const int nChild = (int)((r.info >> 8) & 0xff);
     c.parent = source;
     c.state = State(r.end_x, r.end_y, r.end_heading, r.end_speed, r.end_time);
     c.coverageAllowed = (cfgBits & PPGPU_EDGE_COVERAGE) != 0;
@@ -489,10 +500,6 @@ GpuAStarPlanner::Node GpuAStarPlanner::makeChild(int source, unsigned cfgBits, c
     c.h = r.h;
     c.ribbons = RibbonManager(src.ribbons.heuristic(), src.ribbons.turningRadius(), src.ribbons.k());   // the parent's settings; its list is replaced below
     c.ribbons.assign(childRibbons, nChild, r.coverage_completed_time);
-    if (hostHeuristic) {       // Vertex::computeApproxToGo (Vertex.cpp:49-64): the child's heading goes where the callee says yaw
-        c.h = c.ribbons.approximateDistanceUntilDone(c.state.x(), c.state.y(), c.state.heading()) / m_Config.maxSpeed() * kTimePenaltyFactor;
-        m_Stats.HostHeuristics++;
-    }
     DubinsPath p;
     p.qi[0] = src.state.x(); p.qi[1] = src.state.y(); p.qi[2] = src.state.yaw();
     p.param[0] = r.param[0]; p.param[1] = r.param[1]; p.param[2] = r.param[2];
@@ -500,7 +507,48 @@ GpuAStarPlanner::Node GpuAStarPlanner::makeChild(int source, unsigned cfgBits, c
     p.type = (DubinsPathType)(r.info & 0xff);
     c.wrapper.fill(p, r.end_speed, src.state.time());
     if (!c.infeasible && r.end_time < c.wrapper.getEndTime()) c.wrapper.updateEndTime(r.end_time);   // Edge.cpp:179
-    return c;
+}
+
+// While the planner's thread waits for a round trip it has nothing to do: it builds, ahead of their parents' expansion, the children
+// of the open vertices whose edges are already costed, best f first — the ones the search pops next.  expand() then only moves them
+// into the tree and pushes them.  (Round 4: a cycle was 47 ms of such waits and 28 ms of building and pushing.  Building ALL costed
+// children on the context threads was measured first and lost: five times the children, on threads the round trips need.)
+void GpuAStarPlanner::prebuildWhileWaiting(GpuContext& busy) {
+    static const bool off = std::getenv("PPAMD_NO_PREBUILD") != nullptr;      // (A/B switch)
+    if (off || m_Config.visualizations() || m_Queue.empty()) return;
+    // the open vertices with costed children, in pop order: the same best-first walk of the heap array as pickBatch
+    typedef std::pair<double, size_t> Entry;
+    auto worse = [](const Entry& a, const Entry& b) { return a.first > b.first; };
+    std::vector<Entry> frontier;
+    frontier.emplace_back(m_Queue[0].f, 0);
+    size_t visited = 0;
+    while (!frontier.empty() && visited < 256) {
+        if (busy.idle()) return;
+        std::pop_heap(frontier.begin(), frontier.end(), worse);
+        const Entry e = frontier.back();
+        frontier.pop_back();
+        visited++;
+        for (size_t c = 2 * e.second + 1; c <= 2 * e.second + 2 && c < m_Queue.size(); c++) {
+            frontier.emplace_back(m_Queue[c].f, c);
+            std::push_heap(frontier.begin(), frontier.end(), worse);
+        }
+        const int v = m_Queue[e.second].v;
+        auto it = m_Speculated.find(v);
+        if (it == m_Speculated.end() || !it->second.ready.empty() || it->second.count == 0) continue;
+        Costed& cs = it->second;
+        const TripBlock& blk = *cs.block;
+        const ppgpu_edge_result* records = reinterpret_cast<const ppgpu_edge_result*>(blk.records.get());
+        cs.kids.resize(cs.count);
+        cs.ready.assign(cs.count, 0);
+        for (size_t i = 0; i < cs.count; i++) {
+            const size_t eidx = cs.first + i;
+            const ppgpu_edge_result& r = records[eidx];
+            // left to expand(): a record that is never pushed, one the planner throws on, one whose heuristic it computes itself
+            if (r.flags & (PPGPU_F_INFEASIBLE | PPGPU_F_THROWS | PPGPU_F_DUBINS_ERR | PPGPU_F_RIBBON_LOST | PPGPU_F_RIBBON_OVF)) continue;
+            fillChild(cs.kids[i], v, (unsigned)(blk.edges[eidx] >> 56), r, blk.child.get() + eidx * (size_t)blk.stride * 4);
+            cs.ready[i] = 1;
+        }
+    }
 }
 
 // ppgpu_cost_edges_host with a child-ribbon stride sized for the parents at hand: children rarely carry more than a few
@@ -677,6 +725,7 @@ void GpuAStarPlanner::harvestBatch(Batch* bp, bool keep) {
     for (int v : b.sources) m_InFlightOf.erase(v);
     if (b.threaded) {
         Lap lap(2);
+        if (keep) prebuildWhileWaiting(*b.ctx);
         b.ctx->wait();                         // rethrows what the round trip threw
     }
     noteOperation(1, b.started, b.predicted, b.took);
@@ -837,7 +886,7 @@ bool GpuAStarPlanner::expand(int source) {
         it = m_Speculated.find(source);
         if (it == m_Speculated.end()) throw std::runtime_error("GpuAStarPlanner: a round trip came back without the vertex it was started for");
     }
-    const Costed costed = std::move(it->second);
+    Costed costed = std::move(it->second);
     m_Speculated.erase(it);
     Lap lapPush(4);
     const bool watch = m_Config.visualizations();
@@ -855,7 +904,9 @@ bool GpuAStarPlanner::expand(int source) {
         const bool truncated = (r.flags & PPGPU_F_RIBBON_OVF) && (int)((r.info >> 8) & 0xff) > blk.stride;
         const bool plainInfeasible = (r.flags & PPGPU_F_INFEASIBLE) && !(r.flags & (PPGPU_F_THROWS | PPGPU_F_DUBINS_ERR | PPGPU_F_RIBBON_LOST)) && !truncated;
         if (plainInfeasible && !watch) continue;
-        addNode(makeChild(source, cfgBits, r, blk.child.get() + e * (size_t)blk.stride * 4, blk.stride));
+        const size_t ki = e - costed.first;
+        if (ki < costed.ready.size() && costed.ready[ki]) addNode(std::move(costed.kids[ki]));      // built while the planner waited
+        else addNode(makeChild(source, cfgBits, r, blk.child.get() + e * (size_t)blk.stride * 4, blk.stride));
         visualizeTrajectory(m_Nodes.back());   // in the reference each edge streams its sweep, then its vertex is pushed
         pushVertexQueue((int)m_Nodes.size() - 1);
     }
