@@ -65,6 +65,13 @@ static const double kTimePenaltyFactor = 1;       // Edge::timePenaltyFactor() (
 static const double kCollisionPenaltyFactor = 600;  // Edge::collisionPenaltyFactor() (Edge.h:151)
 static const double kHostMargin = 1e-4;           // seconds the guarded search loop stops short of the deadline (tracing the plan, statistics, the return)
 static const int kRibbonStride = 64;              // child ribbon capacity per edge = the device's per-vertex limit
+// What the deadline guard allows a round trip on top of its prediction when some open vertex of the batch carries a long ribbon list: its
+// children may carry one ribbon more, and the K-ribbon heuristic of a 9-12-ribbon list is enumerated by pp_k_heuristic_big — 0.08, 0.4 and
+// 2 ms per list of 10, 11 and 12 ribbons (tools/big_heuristic_time.py), in a trip that otherwise takes 0.6 ms.  Such trips were the guard's
+// largest under-predictions (round 4: two cycles of a hundred at 101.4 ms late in the mission, when the lists are long).
+static double heavyListAllowance(int maxParentRibbons) {
+    return maxParentRibbons >= 11 ? 3.0e-3 : maxParentRibbons == 10 ? 1.0e-3 : maxParentRibbons == 9 ? 0.5e-3 : maxParentRibbons == 8 ? 0.25e-3 : 0.0;
+}
 static const size_t kNodeArenaMin = 1u << 20;     // nodes the search tree has room for before its first node arrives (250 MB of address space, touched as used;
                                                   // a 100 ms cycle of config 5 makes 250 000 - 300 000 of them)
 
@@ -625,6 +632,7 @@ struct GpuAStarPlanner::Batch {
     std::vector<ppgpu_vertex> verts;
     std::vector<double> pool, nearest;
     int maxParent = 0;
+    double heavy = 0;                      // heavyListAllowance of the batch (part of `predicted`)
     int strideFloor = 0, strideUsed = 0, retries = 0;      // (the child stride earlier round trips of this plan() needed; what this one ended with)
     GpuContext* ctx = nullptr;
     bool threaded = false;                 // running on ctx's thread (wait() before anything else touches ctx)
@@ -699,7 +707,7 @@ void GpuAStarPlanner::submitBatch(std::shared_ptr<Batch> bp, GpuContext& ctx) {
     b.ctx = &ctx;
     b.samples = (double)m_NumSamples;
     b.strideFloor = m_StrideFloor;
-    b.predicted = ctx.predictTrip(b.samples);
+    b.predicted = ctx.predictTrip(b.samples) + b.heavy;
     packBatch(b);
     const int k = m_Config.branchingFactor();
     for (int v : b.sources) m_InFlightOf[v] = &b;
@@ -731,7 +739,7 @@ void GpuAStarPlanner::harvestBatch(Batch* bp, bool keep) {
     noteOperation(1, b.started, b.predicted, b.took);
     if (b.retries > 0) { m_StrideFloor = std::max(m_StrideFloor, b.strideUsed); m_Stats.Budget.StrideRetries += (unsigned long)b.retries; }
     if (b.threaded) m_Stats.Budget.MaxWakeMs = std::max(m_Stats.Budget.MaxWakeMs, 1e3 * (b.started - b.posted));
-    b.ctx->noteTrip(b.samples, b.took);
+    if (b.heavy == 0) b.ctx->noteTrip(b.samples, b.took);      // (a trip with long lists says nothing about the ordinary ones)
     if (b.predicted > 0) m_Ctx->noteExcess(b.took - b.predicted);     // (the guard's margin is the first context's)
     m_Stats.EdgesCosted += b.edgesCosted;
     if (!keep) return;                         // costed against a sample set that is no longer the search's
@@ -859,7 +867,12 @@ bool GpuAStarPlanner::expand(int source) {
                 }
                 // the deadline guard once more, with the clock as it stands now that the batch is chosen (only when the guard is on: a
                 // counting clock must see the reference's call sequence)
-                if (m_Config.deadlineGuard() && now() + ctx.predictTrip((double)m_NumSamples) >= m_EndTime - m_Ctx->guardMargin()) return false;
+                {
+                    int mp = 0;
+                    for (int v : b->sources) mp = std::max(mp, m_Nodes[v].ribbons.count());
+                    b->heavy = heavyListAllowance(mp);
+                }
+                if (m_Config.deadlineGuard() && now() + ctx.predictTrip((double)m_NumSamples) + b->heavy >= m_EndTime - m_Ctx->guardMargin()) return false;
                 Batch* mine = b.get();
                 submitBatch(std::move(b), ctx);
                 // while that one runs: the other contexts take the next-best open vertices (prefetch)
@@ -870,12 +883,17 @@ bool GpuAStarPlanner::expand(int source) {
                         pickBatch(-1, p->sources);
                     }
                     if (p->sources.empty()) break;
+                    {
+                        int mp = 0;
+                        for (int v : p->sources) mp = std::max(mp, m_Nodes[v].ribbons.count());
+                        p->heavy = heavyListAllowance(mp);
+                    }
                     GpuContext& pc = freeContext();
                     // (a prefetch shares the device with the round trips already in flight: at worst it ends after all of them, one
                     // predicted round trip each — with eight contexts and no such allowance a cycle's last prefetches queued up behind one
                     // another and the drain at the end of the loop took 6 ms)
                     if (m_Config.deadlineGuard() &&
-                        now() + pc.predictTrip((double)m_NumSamples) * (double)(m_InFlight.size() + 1) >= m_EndTime - m_Ctx->guardMargin()) break;
+                        now() + (pc.predictTrip((double)m_NumSamples) + p->heavy) * (double)(m_InFlight.size() + 1) >= m_EndTime - m_Ctx->guardMargin()) break;
                     submitBatch(std::move(p), pc);
                 }
                 harvestBatch(mine, true);
