@@ -400,6 +400,7 @@ def run_rank(args):
             "ms_per_step": 1e3 * t / args.steps,
             "ms_per_step_median": float(np.median(step_ms)),
             "ms_per_step_p99": float(np.percentile(step_ms, 99)),
+            "ms_per_step_slowest": {"ms": float(step_ms.max()), "index": int(step_ms.argmax())},     # (which timed step, by stream events)
             "e2e_ms_per_step": e2e_ms,
             "e2e_pipelined_ms_per_step": e2e_pipe_ms,
             "e2e_copy_engine_ms_per_step": e2e_sdma_ms,
