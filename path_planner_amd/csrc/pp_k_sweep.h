@@ -55,12 +55,9 @@ __device__ __forceinline__ PPCurveHot pp_curve_hot(const PPEdgeSetup* S) {
     h.qx = PP_SF64(qx); h.qy = PP_SF64(qy);
     return h;
 }
-// needXY = false (wave-uniform; the pose sweep, on a chunk pp_k_plan_skips found clear of the grid and of every obstacle but could not skip —
-// the heading bits of a chunk that straddles a junction have to be sampled): only the yaw is wanted, the same expression without
-// the sine and cosine the position needs; x and y come back as 0.
 template <bool TAB = false>
 __device__ __forceinline__ void pp_window_pose(const PPEdgeSetup* S, const PPCurveHot& c, int& cur, PPSeg& cs, double t, double tFirst, bool valid,
-                                               double& x, double& y, double& uth, bool& dubErr, bool needXY = true) {
+                                               double& x, double& y, double& uth, bool& dubErr) {
     // lanes past the end of the sweep redo lane 0's step (benign arithmetic, uniform control flow); the caller masks them
     const double tl = valid ? t : tFirst;
     double dist = (tl - c.wStart) * c.speed;                          // DubinsWrapper.cpp:36
@@ -80,28 +77,14 @@ __device__ __forceinline__ void pp_window_pose(const PPEdgeSetup* S, const PPCur
         const int lastSeg = __builtin_amdgcn_readlane(mine, 63 - __clzll((long long)__ballot(valid)));
         if (__ballot(mine != firstSeg) != 0ull) {
             // the window straddles a junction: every lane takes its own segment's constants from memory
-            if (needXY) pp_setup_seg_pose<TAB>(S, mine, tprime, ux, uy, uth);
-            else {
-                const int gtype = pp_word_seg_type(PP_SI32(type), mine);
-                const double tt = (tprime - pp_seg_o1(mine, hi0)) - pp_seg_o2(mine, PP_SF64(p1));
-                const double bth = S->seg[mine].bth;
-                uth = (gtype == 1) ? (0.0 + bth) : ((gtype == 0) ? (tt + bth) : (-tt + bth));      // pp_curve_seg's own yaw expressions
-                ux = 0.0; uy = 0.0;
-            }
+            pp_setup_seg_pose<TAB>(S, mine, tprime, ux, uy, uth);
         } else {
             uniformSeg = true;
             if (cur != firstSeg) { cur = firstSeg; cs = pp_seg_load_uniform(&S->seg[cur], cur, hi0, PP_SF64(p1), hi1, PP_SI32(type)); }
         }
         if (cur != lastSeg && !uniformSeg) { cur = lastSeg; cs = pp_seg_load_uniform(&S->seg[cur], cur, hi0, PP_SF64(p1), hi1, PP_SI32(type)); }
     }
-    if (uniformSeg) {
-        if (needXY) pp_curve_seg<TAB>(cs.type, (tprime - cs.o1) - cs.o2, cs.bx, cs.by, cs.bth, cs.sb, cs.cb, ux, uy, uth);
-        else {
-            const double tt = (tprime - cs.o1) - cs.o2;
-            uth = (cs.type == 1) ? (0.0 + cs.bth) : ((cs.type == 0) ? (tt + cs.bth) : (-tt + cs.bth));
-            ux = 0.0; uy = 0.0;
-        }
-    }
+    if (uniformSeg) pp_curve_seg<TAB>(cs.type, (tprime - cs.o1) - cs.o2, cs.bx, cs.by, cs.bth, cs.sb, cs.cb, ux, uy, uth);
     x = ux * c.rho + c.qx;
     y = uy * c.rho + c.qy;
 }
@@ -445,9 +428,7 @@ __device__ __forceinline__ void pp_pose_sweep_edge(const PPParams& p, const long
             int hits = 0;
             {
                 double uth;
-                // (clear of the grid and of the obstacles by the planner's tests: the chunk is only here for its heading bits)
-                const bool needXY = !(gridClear && (obstClear || !anyObstacle));
-                pp_window_pose(S, hot, cur, cs, t, tFirst, valid, x, y, uth, dubErr, needXY);
+                pp_window_pose(S, hot, cur, cs, t, tFirst, valid, x, y, uth, dubErr);
                 // the heading itself (:47) only matters for "unchanged since the last step" (Edge.cpp:159), which only matters
                 // on edges that may not cover while turning
                 heading = cov ? 0.0 : pp_heading_from_yaw(pp_mod2pi(uth));
