@@ -215,12 +215,12 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     import gc
     gc.collect()
     gc.disable()                     # (the timed steps are driven from Python: no collector pause inside the timed region)
+    for _ in range(args.warmup):     # (straight into the timed region: nothing between the warm-up and the fence lets the device go idle)
+        step()
     fence()
     t0 = time.perf_counter()
     edges = 0
