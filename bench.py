@@ -225,7 +225,15 @@ def run_rank(args):
     t0 = time.perf_counter()
     edges = 0
     marks[0].record(stream)
+    # the library's HIP events between its kernels (six per costing launch: what roofline.kernels_ms is read from) are recorded in
+    # the LAST eight timed steps only — each record is ~7 us of idle device between two kernels; PP_BENCH_EVENTS=all records them in
+    # every step, =0 in none
+    ev_mode = os.environ.get("PP_BENCH_EVENTS", "last8")
+    timed_from = 0 if ev_mode == "all" else (args.steps if ev_mode == "0" else max(0, args.steps - 8))
+    ctx.enable_timing(timed_from == 0)
     for k in range(args.steps):
+        if k == timed_from and k > 0:
+            ctx.enable_timing(True)
         edges += step()
         marks[k + 1].record(stream)
     fence()
@@ -234,8 +242,12 @@ def run_rank(args):
     step_ms = np.array([marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)])
     # (solve, pose, cover, heuristic) ms of the last timed steps' launches, from the HIP events the library recorded between its
     # kernels on this stream inside the timed region (a ring of 8 sets: read back here, so no step waited for its own events)
-    for back in range(min(args.steps, 8)):
+    for back in range(min(args.steps - timed_from, 8)):
         kernel_events.append(ctx.past_timing(back))
+    ctx.enable_timing(True)
+    if not kernel_events:                                   # (PP_BENCH_EVENTS=0: one launch after the clock has stopped, for the breakdown)
+        step(); ctx.synchronize()
+        kernel_events.append(ctx.past_timing(0))
 
     tot = torch.tensor([float(edges), elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world > 1 or use_comm:
@@ -442,7 +454,7 @@ def run_rank(args):
                          "launch_ms": launch_ms, "kernel_ms": kern_ms, "edges_in_kernel": cover_edges,
                          "kernels_ms": {"pp_k_solve_edges": solve_ms, "pp_k_plan_skips+pp_k_pose_sweep": pose_ms, "pp_k_cover_sweep+pp_k_cover_finish": cover_ms,
                                         "others": heur_ms},
-                         "kernels_note": "HIP events between the kernels of each costing launch of the timed region (last 8 steps); "
+                         "kernels_note": "HIP events between the kernels of each costing launch of the timed region's last 8 steps (recorded in those steps only: a record is ~7 us of idle device between two kernels); "
                                          "'others' = pp_k_approach_events (finishes the edges whose coverage state machine has nothing to do: "
                                          "edges_in_kernel is what is left for the cover sweep) + pp_k_deferred_list + pp_k_heuristic_lanes (beside it, on a second stream, "
                                          "pp_k_heuristic_listed) + pp_k_heuristic_big; the four add up to the launch",
