@@ -102,7 +102,10 @@ struct ppgpu_ctx {
     // sampler (StateGenerator) state
     PPSamplerState sampler{};
     DevBuf<double> samp_ribbons;
-    DevBuf<unsigned long long> samp_pos;           // [0] stream position (pair slots consumed), [1] sticky chain error, [2..3] report of the last add (pp_k_sampler_advance)
+    DevBuf<unsigned long long> samp_pos;           // groups of 8 words: [0] stream position (pair slots consumed), [1] sticky chain error, [2..3] report of the last
+                                                   // add (pp_k_sampler_advance).  ppgpu_sampler_init moves on to the next group — all zero: "position 0, no error" —
+                                                   // and zeroes the whole array again when it wraps: a fresh generator costs no launch of its own
+    int samp_group = -1;
     unsigned long long* pinned_counts = nullptr;   // 64 bytes of pinned host memory for the sampler's count read-backs
     std::vector<double> samp_ribbons_host;   // what samp_ribbons holds (ppgpu_sampler_init skips the upload of an unchanged table)
     DevBuf<unsigned char> s_bytes;      // scan / compaction scratch
@@ -567,9 +570,13 @@ int ppgpu_sampler_init(ppgpu_ctx* c, const double* b6, uint64_t seed, int32_t n_
     s.seed = (unsigned)(x == 0 ? 1 : x);
     s.on_ribbons = n_ribbons >= 0 ? 1 : 0;   // the ribbon constructor sets m_SampleOnRibbons even for an empty manager
     s.n_ribbons = n_ribbons > 0 ? n_ribbons : 0;
-    if ((rc = c->samp_pos.reserve(8, false, c->stream))) return rc;
-    HIP_TRY(hipMemsetAsync(c->samp_pos.p, 0, 8 * sizeof(unsigned long long), c->stream));   // position 0, no error (in stream order: no host wait)
-    s.d_pos = c->samp_pos.p;
+    const int kPosGroups = 1024;
+    if (!c->samp_pos.p) c->samp_group = -1;
+    if ((rc = c->samp_pos.reserve((size_t)8 * kPosGroups, false, c->stream))) return rc;
+    c->samp_group = (c->samp_group + 1) % kPosGroups;
+    if (c->samp_group == 0)      // (in stream order after everything that used the old groups: no host wait)
+        HIP_TRY(hipMemsetAsync(c->samp_pos.p, 0, (size_t)8 * kPosGroups * sizeof(unsigned long long), c->stream));
+    s.d_pos = c->samp_pos.p + (size_t)8 * c->samp_group;
     s.initialised = 1;
     if (n_ribbons > 0) {
         // the generator of every iteration of a plan() call is built from the same ribbon manager (AStarPlanner.cpp:34): the table is
@@ -617,7 +624,7 @@ static int sampler_chain(ppgpu_ctx* c, long long n, long long& nq, int& nblk_q, 
     hipLaunchKernelGGL(pp_k_chain_apply_count, dim3(nblk_q), dim3(256), 0, st, proj, nq, tilefn, c->s_u32b.p);
     // 3b. rank the visited slots: slot of each sample, and of sample n
     hipLaunchKernelGGL(pp_k_chain_positions_scan, dim3(nblk_q), dim3(256), 0, st, proj, nq, c->s_u32b.p, n, c->s_u32a.p, *d_end,
-                       skip ? c->samp_pos.p : (unsigned long long*)nullptr);
+                       skip ? const_cast<unsigned long long*>(s.d_pos) : (unsigned long long*)nullptr);
     HIP_TRY(hipGetLastError());
     return PPGPU_OK;
 }
@@ -639,7 +646,7 @@ int ppgpu_sampler_skip(ppgpu_ctx* c, int64_t n_attempts) {
             // three launches; the last of them (pp_k_chain_positions_scan) advances the position itself
             if ((rc = sampler_chain(c, n, nq, nblk_q, &d_end, true))) return rc;
         } else {
-            hipLaunchKernelGGL(pp_k_sampler_advance, dim3(1), dim3(1), 0, c->stream, c->samp_pos.p, d_end, (const unsigned long long*)nullptr,
+            hipLaunchKernelGGL(pp_k_sampler_advance, dim3(1), dim3(1), 0, c->stream, const_cast<unsigned long long*>(s.d_pos), d_end, (const unsigned long long*)nullptr,
                                4ull * (unsigned long long)n, 0);
             HIP_TRY(hipGetLastError());
         }
@@ -680,13 +687,13 @@ int ppgpu_sampler_add(ppgpu_ctx* c, int64_t n_attempts, int64_t* n_total_out) {
     hipLaunchKernelGGL(pp_k_compact_scan, dim3((unsigned)nblk_n), dim3(256), 0, st, keep, n, blk32, c->s_cand.p, c->sx.p, c->sy.p,
                        c->sh.p, c->n_samples, d_total);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(pp_k_sampler_advance, dim3(1), dim3(1), 0, st, c->samp_pos.p, d_end, d_total, 4ull * (unsigned long long)n, s.on_ribbons);
+    hipLaunchKernelGGL(pp_k_sampler_advance, dim3(1), dim3(1), 0, st, const_cast<unsigned long long*>(s.d_pos), d_end, d_total, 4ull * (unsigned long long)n, s.on_ribbons);
     HIP_TRY(hipGetLastError());
     // {chain error, kept, slots consumed} come back in one copy through pinned memory (a copy to pageable memory waits for the
     // stream by itself); the position itself stays on the device
     volatile unsigned long long* h2 = c->pinned_counts;
     h2[0] = 0; h2[1] = 0; h2[2] = 0;
-    HIP_TRY(hipMemcpyAsync((void*)&h2[0], c->samp_pos.p + 1, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync((void*)&h2[0], s.d_pos + 1, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (h2[0] != 0) return fail(PPGPU_EHIP, "sampler: chain scan did not reach the end of the batch (this call or a ppgpu_sampler_skip before it)");
     c->n_samples += (long long)h2[1];
